@@ -1,0 +1,204 @@
+/*
+ * ltg.h -- C ABI of the MI355X-native Long-Tail-GAN training path (libltg_hip.so).
+ *
+ * The reference (ash-shar/Long-Tail-GAN) has no FFI of its own: its execution boundary is the
+ * five TensorFlow `sess.run` call sites of Codes/train.py / Codes/test.py.  Each entry point below
+ * replaces one of them (cited per function).  Conventions:
+ *
+ *   - plain C: pointers + sizes, no torch / C++ types; every pointer is a DEVICE pointer unless
+ *     the parameter name starts with `host_`;
+ *   - the caller owns every buffer (parameters, Adam moments, activations, workspace); the library
+ *     allocates nothing, keeps no global state and is asynchronous on the given HIP stream;
+ *   - return value: 0 on success, a negative LTG_E* code on error; never throws;
+ *   - randomness: every random tensor can be injected through an optional pointer; NULL selects the
+ *     on-device counter RNG keyed by (cfg->seed, stream id, rng_step, element index), which the CPU
+ *     oracle reproduces bit-for-bit (oracle/ltg_oracle.py rng_*).
+ *
+ * Layouts in HBM (all row-major, fp32 unless stated):
+ *   W_q0  [I][H]      encoder layer 0   (TF shape [I,600],  MultiVAE.py:199)
+ *   W_q1  [H][2Z]     encoder layer 1   (TF shape [600,400])
+ *   W_p0  [Z][H]      decoder layer 0   (TF shape [200,600])
+ *   W_p1t [I][H]      decoder layer 1 stored ITEM-MAJOR (transpose of TF's [600,I], MultiVAE.py:218)
+ *   b_q0 [H], b_q1 [2Z], b_p0 [H], b_p1 [I]
+ *   discriminator: emb [F][h0] (frozen), w1 [h0][h1], w2 [h0][h2], w3 [h1+h2][h3], w4 [h3], b*.
+ */
+#ifndef LTG_H
+#define LTG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTG_ABI_VERSION 1
+
+#define LTG_OK 0
+#define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
+#define LTG_EWORKSPACE (-2) /* workspace too small */
+#define LTG_ELAUNCH (-3)    /* HIP launch error (hipGetLastError != hipSuccess) */
+
+#define LTG_PREC_BF16 0 /* decoder GEMM operands rounded to bf16, fp32 accumulate (MFMA 16x16x32 bf16) */
+#define LTG_PREC_FP32 1 /* exact fp32 MFMA (16x16x4 f32) everywhere */
+
+typedef void* ltg_stream; /* hipStream_t */
+
+/* Model / optimiser configuration.  Codes/config.ini:2-12, Codes/generator.py:13-18,
+ * Codes/train.py:160 (AdamOptimizer defaults beta1=.9 beta2=.999 eps=1e-8). */
+typedef struct ltg_config {
+    int32_t n_items; /* I */
+    int32_t h_enc;   /* H = p_dims[1] = 600 */
+    int32_t z_dim;   /* Z = p_dims[0] = 200 */
+    int32_t d_feat;  /* FEATURE_LEN: rows of the frozen embedding table */
+    int32_t d_h0, d_h1, d_h2, d_h3;
+    int32_t precision; /* LTG_PREC_* */
+    int32_t reserved0;
+    float lr, beta1, beta2, adam_eps;
+    uint64_t seed;
+} ltg_config;
+
+/* Generator parameters + Adam moments, reference order (MultiVAE.py:129-141):
+ * 0 W_q0, 1 W_q1, 2 W_p0, 3 W_p1t, 4 b_q0, 5 b_q1, 6 b_p0, 7 b_p1. */
+typedef struct ltg_gen_state {
+    float* p[8];
+    float* m[8];
+    float* v[8];
+} ltg_gen_state;
+
+/* Discriminator: emb is read-only (discriminator.py:14 is not in d_params, :47).
+ * Trainable order (discriminator.py:47): 0 w1, 1 b1, 2 w2, 3 b2, 4 w3, 5 b3, 6 w4, 7 b4. */
+typedef struct ltg_disc_state {
+    const float* emb;
+    float* p[8];
+    float* m[8];
+    float* v[8];
+} ltg_disc_state;
+
+/* A batch of user rows in CSR form (replaces the dense [B,I] float32 feed of train.py:194-198).
+ * indptr holds absolute offsets into indices/values.  The CSC view (colptr/rowidx/csr_pos) is
+ * only required by ltg_g_step (sparse gradient of W_q0). */
+typedef struct ltg_batch {
+    int32_t n_rows;
+    int32_t reserved0;
+    const int32_t* indptr;  /* [n_rows+1] */
+    const int32_t* indices; /* item ids, ascending within a row */
+    const float* values;    /* NULL => 1.0f */
+    const int32_t* colptr;  /* [n_items+1] offsets into rowidx/csr_pos (relative to 0) */
+    const int32_t* rowidx;  /* local row of each CSC entry */
+    const int32_t* csr_pos; /* index of that entry in indices[] */
+} ltg_batch;
+
+/* Activations of one generator forward; caller-owned, sizes for n_rows rows.
+ * logits/lse are what the sampler, the G step and the metrics consume. */
+typedef struct ltg_gen_acts {
+    float* h1;      /* [n_rows][H]   tanh(enc0) */
+    float* mulv;    /* [n_rows][2Z]  mu | logvar */
+    float* z;       /* [n_rows][Z] */
+    float* h2;      /* [n_rows][H]   tanh(dec0) */
+    float* logits;  /* [n_rows][I] */
+    float* lse;     /* [n_rows]      log-sum-exp of the row */
+    float* kl_rows; /* [n_rows]      per-row KL (MultiVAE.py:161) */
+    float* row_scale; /* [n_rows]    1/(keep*||x||_2) */
+} ltg_gen_acts;
+
+typedef struct ltg_fwd_opts {
+    float keep_prob;   /* keep_prob_ph, default 0.75 (MultiVAE.py:31) -- ON at inference too (Q3) */
+    float is_training; /* is_training_ph (MultiVAE.py:101) */
+    uint64_t rng_step; /* counter for the on-device RNG */
+    const uint8_t* drop_keep; /* optional keep flags, indexed like indices[] (drop_keep[e] belongs to indices[e]) */
+    const float* eps;         /* optional [n_rows][Z] */
+} ltg_fwd_opts;
+
+/* Fake/real (popular, niche) id pairs.  Rows with id < 0 are holes (dropped pairs, Q9/Q10). */
+typedef struct ltg_pairs {
+    int32_t n;              /* number of slots */
+    int32_t reserved0;
+    const int32_t* pop;     /* [n] popular item id */
+    const int32_t* niche;   /* [n] niche / generated item id */
+    const int32_t* row;     /* [n] local user row of the pair (fake pairs; may be NULL for real) */
+} ltg_pairs;
+
+typedef struct ltg_d_opts {
+    float keep_prob;    /* 0.7 (train.py:300) */
+    int32_t adam_t;     /* shared Adam step AFTER this update (t >= 1), Q5 */
+    uint64_t rng_step;
+    const uint8_t* drop_real[3]; /* optional keep flags [n_real][h1], [n_real][h2], [n_real][h3] */
+    const uint8_t* drop_fake[3];
+} ltg_d_opts;
+
+typedef struct ltg_g_opts {
+    ltg_fwd_opts fwd;   /* keep 0.75, is_training 1 (train.py:326) */
+    float anneal;       /* anneal_ph */
+    float gan_lambda;   /* gen_lambda */
+    float d_keep_prob;  /* 0.7 */
+    int32_t adam_t;     /* shared Adam step AFTER this update */
+    uint64_t d_rng_step;
+    const uint8_t* drop_fake[3]; /* optional */
+    const int32_t* cnt;  /* device scalar: sampled_cnt (number of valid fake pairs) */
+} ltg_g_opts;
+
+/* Static per-user sampling inputs for a batch (results of the index path, data_processing.py). */
+typedef struct ltg_sample_inputs {
+    int32_t n_rows;
+    int32_t max_cand;         /* max candidate-set length in this batch (sizes the LDS key buffer; <= 16384) */
+    const int32_t* cand_ptr;  /* [n_rows+1]  USER_TAGS_TO_SAMPLE (data_processing.py:170-224) */
+    const int32_t* cand_idx;  /* ascending candidate item ids */
+    const int32_t* pop_ptr;   /* [n_rows+1]  user's popular list in file order (data_processing.py:72-96) */
+    const int32_t* pop_idx;
+    const int32_t* n_sample;  /* [n_rows] to_sample = len(user niche list); 0 => invalid user (Q8) */
+    const int32_t* slot_ptr;  /* [n_rows+1] prefix sum of n_sample: output slot range per user */
+    const uint8_t* valid_item;/* [I] 1 if the id is in ITEM_FEATURE_DICT (Q9) */
+    uint64_t rng_step;
+    const float* u_gumbel;    /* optional [n_cand total] uniforms aligned with cand_idx */
+    const float* u_pick;      /* optional [n_slots] uniforms aligned with slots */
+} ltg_sample_inputs;
+
+int32_t ltg_abi_version(void);
+
+/* Bytes of workspace needed by any entry point for at most max_rows user rows and max_pairs
+ * discriminator rows (real+fake) per call. */
+size_t ltg_workspace_bytes(const ltg_config* cfg, int32_t max_rows, int32_t max_pairs);
+
+/* Generator forward: replaces sess.run(generator_out, {input_ph: X}) -- Codes/train.py:200, :339,
+ * Codes/test.py:146 (graph: MultiVAE.py:145-186, softmax :143).  Fills `acts`; if probs_out != NULL
+ * also writes softmax probabilities [n_rows][I] (Q1). */
+int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch,
+                    const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* probs_out,
+                    void* ws, size_t ws_bytes, ltg_stream stream);
+
+/* Fake-pair sampling for one batch: replaces the Python loop Codes/train.py:212-251 including
+ * sample_from_generator_new (Codes/sample.py:40-67).  Reads logits/lse of ltg_vae_forward.
+ * Writes gen_out/pop_out [n_slots] (-1 = hole) and cnt_out[0] = number of valid pairs. */
+int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits,
+                     const float* lse, int32_t* gen_out, int32_t* pop_out, int32_t* cnt_out,
+                     ltg_stream stream);
+
+/* Discriminator update: replaces sess.run([d_trainer, d_loss_mean]) -- Codes/train.py:300
+ * (graph discriminator.py:3-58, loss train.py:142, Adam train.py:160-163).
+ * loss_out[0] = d_loss (device). */
+int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real,
+               const ltg_pairs* fake, const ltg_d_opts* opts, float* loss_out, void* ws,
+               size_t ws_bytes, ltg_stream stream);
+
+/* Generator update: replaces sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss]) --
+ * Codes/train.py:326 (losses train.py:145-157, Adam :164).  The dense mask feed `generated_tags`
+ * is replaced by the (row, gen id) list of `fake`.  loss_out (device, >= 8 floats): [0..2] = g_loss,
+ * vae_loss, gan_loss; [3] = sum_S p, [4] = sum_j y_j, [5] = c = lambda/cnt * sum_j y_j. */
+int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc,
+               const ltg_batch* batch, const ltg_pairs* fake, const ltg_g_opts* opts,
+               const ltg_gen_acts* acts, float* loss_out, void* ws, size_t ws_bytes,
+               ltg_stream stream);
+
+/* Ranking metrics on device: replaces pred[X.nonzero()] = -inf (Codes/train.py:341) +
+ * NDCG_binary_at_k_batch / Recall_at_k_batch (Codes/eval_functions.py:11-62).
+ * tr = fold-in rows (masked), te = held-out rows, same n_rows.  out [n_rows][4] =
+ * {ndcg@k_ndcg, recall@k_r1, recall@k_r2, valid flag (IDCG != 0)}. */
+int ltg_rank_metrics(const ltg_config* cfg, const float* logits, const ltg_batch* tr,
+                     const ltg_batch* te, int32_t k_ndcg, int32_t k_r1, int32_t k_r2, float* out,
+                     ltg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTG_H */

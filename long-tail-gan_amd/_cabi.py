@@ -1,0 +1,120 @@
+"""ctypes binding of the C ABI declared in include/ltg.h (libltg_hip.so).
+
+There is deliberately NO fallback: if the HIP library is missing or a symbol is absent the import
+of the product path fails loudly (the oracle under oracle/ is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
+
+LTG_PREC_BF16 = 0
+LTG_PREC_FP32 = 1
+LTG_ABI_VERSION = 1
+
+ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
+
+vp = C.c_void_p
+
+
+class ltg_config(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("h_enc", C.c_int32), ("z_dim", C.c_int32), ("d_feat", C.c_int32),
+                ("d_h0", C.c_int32), ("d_h1", C.c_int32), ("d_h2", C.c_int32), ("d_h3", C.c_int32),
+                ("precision", C.c_int32), ("reserved0", C.c_int32),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+                ("seed", C.c_uint64)]
+
+
+class ltg_gen_state(C.Structure):
+    _fields_ = [("p", vp * 8), ("m", vp * 8), ("v", vp * 8)]
+
+
+class ltg_disc_state(C.Structure):
+    _fields_ = [("emb", vp), ("p", vp * 8), ("m", vp * 8), ("v", vp * 8)]
+
+
+class ltg_batch(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("reserved0", C.c_int32), ("indptr", vp), ("indices", vp), ("values", vp),
+                ("colptr", vp), ("rowidx", vp), ("csr_pos", vp)]
+
+
+class ltg_gen_acts(C.Structure):
+    _fields_ = [("h1", vp), ("mulv", vp), ("z", vp), ("h2", vp), ("logits", vp), ("lse", vp), ("kl_rows", vp),
+                ("row_scale", vp)]
+
+
+class ltg_fwd_opts(C.Structure):
+    _fields_ = [("keep_prob", C.c_float), ("is_training", C.c_float), ("rng_step", C.c_uint64), ("drop_keep", vp),
+                ("eps", vp)]
+
+
+class ltg_pairs(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved0", C.c_int32), ("pop", vp), ("niche", vp), ("row", vp)]
+
+
+class ltg_d_opts(C.Structure):
+    _fields_ = [("keep_prob", C.c_float), ("adam_t", C.c_int32), ("rng_step", C.c_uint64), ("drop_real", vp * 3),
+                ("drop_fake", vp * 3)]
+
+
+class ltg_g_opts(C.Structure):
+    _fields_ = [("fwd", ltg_fwd_opts), ("anneal", C.c_float), ("gan_lambda", C.c_float), ("d_keep_prob", C.c_float),
+                ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp)]
+
+
+class ltg_sample_inputs(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("max_cand", C.c_int32), ("cand_ptr", vp), ("cand_idx", vp), ("pop_ptr", vp),
+                ("pop_idx", vp), ("n_sample", vp), ("slot_ptr", vp), ("valid_item", vp), ("rng_step", C.c_uint64),
+                ("u_gumbel", vp), ("u_pick", vp)]
+
+
+# every symbol include/ltg.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ltg_abi_version": (C.c_int32, []),
+    "ltg_workspace_bytes": (C.c_size_t, [C.POINTER(ltg_config), C.c_int32, C.c_int32]),
+    "ltg_vae_forward": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch),
+                                  C.POINTER(ltg_fwd_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
+    "ltg_sample_pairs": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp, vp, vp, vp]),
+    "ltg_d_step": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), C.POINTER(ltg_pairs),
+                             C.POINTER(ltg_pairs), C.POINTER(ltg_d_opts), vp, vp, C.c_size_t, vp]),
+    "ltg_g_step": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state),
+                             C.POINTER(ltg_batch), C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts),
+                             C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
+    "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,
+                                   C.c_int32, C.c_int32, vp, vp]),
+}
+
+_lib = None
+
+
+class LtgError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libltg_hip.so and bind every declared symbol.  Raises (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LtgError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C long-tail-gan_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.ltg_abi_version()
+    if got != LTG_ABI_VERSION:
+        raise LtgError("ABI version mismatch: library %d, binding %d" % (got, LTG_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LtgError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))

@@ -1,0 +1,160 @@
+// Block-level MFMA GEMM building block for gfx950 (wave64).
+//
+// C[m][n] = sum_k A(m,k) * B(k,n), one BM x BN tile per 256-thread workgroup (4 waves arranged
+// WM x WN), operands fetched through element functors (so gathers, transposes, on-the-fly
+// derivatives and ones-augmentation for bias gradients are all "just a loader"), staged in LDS as
+// k-contiguous rows, consumed by
+//   BF16 = true : v_mfma_f32_16x16x32_bf16  (operands rounded to bf16 RNE, fp32 accumulate)
+//   BF16 = false: v_mfma_f32_16x16x4_f32    (exact fp32 fma chain)
+// and handed to an epilogue functor epi(m, n, acc).
+//
+// Fragment maps (cdna_hip_programming.md section 3):
+//   16x16x32 bf16: lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7
+//   16x16x4  f32 : lane l holds A[row l&15][k = l>>4],       B[k = l>>4][col l&15]
+//   C/D (both)   : col = l&15, row = 4*(l>>4) + reg
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float ltg_f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 ltg_bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short ltg_u16x8;
+
+__device__ __forceinline__ unsigned short ltg_f2bf(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return (unsigned short)(u >> 16);
+}
+
+template <bool BF16> struct LtgGemmCfg;
+template <> struct LtgGemmCfg<true> {
+    typedef unsigned short T;
+    static constexpr int BK = 32;
+    static constexpr int LDK = 40;  // 80-byte rows: 16-B aligned fragment reads
+};
+template <> struct LtgGemmCfg<false> {
+    typedef float T;
+    static constexpr int BK = 16;
+    static constexpr int LDK = 17;
+};
+
+// M, N: logical bounds for the epilogue (loaders must return 0 outside their own bounds).
+// [kbeg, kend): K range of this block (split-K).  A_MCONTIG / B_NCONTIG choose the thread->element
+// map of the global loads so that consecutive threads walk the operand's contiguous dimension.
+template <bool BF16, int BM, int BN, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, class AF, class BF, class EF>
+__device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int kbeg, int kend, AF a, BF b, EF epi) {
+    typedef LtgGemmCfg<BF16> Cfg;
+    typedef typename Cfg::T T;
+    constexpr int BK = Cfg::BK, LDK = Cfg::LDK;
+    constexpr int NT = 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
+    static_assert(BM * BK % NT == 0 && BN * BK % NT == 0, "tile must divide over 256 threads");
+
+    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    ltg_f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float ra[EA], rb[EB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < EA; ++j) {
+            const int e = tid + NT * j;
+            const int mm = A_MCONTIG ? (e % BM) : (e / BK);
+            const int kk = A_MCONTIG ? (e / BM) : (e % BK);
+            const int gk = k0 + kk;
+            ra[j] = (gk < kend) ? a(m0 + mm, gk) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int e = tid + NT * j;
+            const int nn = B_NCONTIG ? (e % BN) : (e / BK);
+            const int kk = B_NCONTIG ? (e / BN) : (e % BK);
+            const int gk = k0 + kk;
+            rb[j] = (gk < kend) ? b(gk, n0 + nn) : 0.f;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < EA; ++j) {
+            const int e = tid + NT * j;
+            const int mm = A_MCONTIG ? (e % BM) : (e / BK);
+            const int kk = A_MCONTIG ? (e / BM) : (e % BK);
+            if constexpr (BF16) As[mm * LDK + kk] = ltg_f2bf(ra[j]);
+            else As[mm * LDK + kk] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int e = tid + NT * j;
+            const int nn = B_NCONTIG ? (e % BN) : (e / BK);
+            const int kk = B_NCONTIG ? (e / BN) : (e % BK);
+            if constexpr (BF16) Bs[nn * LDK + kk] = ltg_f2bf(rb[j]);
+            else Bs[nn * LDK + kk] = rb[j];
+        }
+    };
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();  // previous tile fully consumed
+        stash();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);  // next tile's loads fly under the MFMAs
+        if constexpr (BF16) {
+            ltg_bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const ltg_u16x8 t = *reinterpret_cast<const ltg_u16x8*>(&As[(wm * WTM + i * 16 + lr) * LDK + 8 * lq]);
+                af[i] = __builtin_bit_cast(ltg_bf16x8, t);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const ltg_u16x8 t = *reinterpret_cast<const ltg_u16x8*>(&Bs[(wn * WTN + j * 16 + lr) * LDK + 8 * lq]);
+                bfr[j] = __builtin_bit_cast(ltg_bf16x8, t);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                float af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(wm * WTM + i * 16 + lr) * LDK + kk + lq];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = Bs[(wn * WTN + j * 16 + lr) * LDK + kk + lq];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WTM + i * 16 + lq * 4 + r;
+                const int n = n0 + wn * WTN + j * 16 + lr;
+                if (m < M && n < N) epi(m, n, acc[i][j][r]);
+            }
+}

@@ -1,0 +1,993 @@
+// HIP kernels + C ABI (include/ltg.h) of the MI355X-native Long-Tail-GAN training path.
+// gfx950 only.  Reference citations are relative to /root/reference/.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/ltg.h"
+#include "ltg_gemm.h"
+#include "ltg_rng.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct AdamC {
+    float lr_t, b1, b2, eps;
+};
+
+// tf.train.AdamOptimizer update (train.py:160-164, Q5): m,v updated for EVERY element (dense).
+__device__ __forceinline__ void adam_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                            size_t i, float g, const AdamC c) {
+    const float mn = c.b1 * m[i] + (1.f - c.b1) * g;
+    const float vn = c.b2 * v[i] + (1.f - c.b2) * g * g;
+    m[i] = mn;
+    v[i] = vn;
+    p[i] = p[i] - c.lr_t * mn / (sqrtf(vn) + c.eps);
+}
+
+__device__ __forceinline__ float block_sum(float x, float* red /*[NT/64]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float x, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generator forward
+// ---------------------------------------------------------------------------------------------
+
+// enc-0 as a sparse row gather-sum (MultiVAE.py:148-155): h1 = tanh(dropout(l2norm(x)) . W_q0 + b).
+// One workgroup per user row; each thread owns columns c = tid, tid+256, ... of H; the row's
+// (item, value*keep) list is staged through LDS in chunks, W_q0 rows are read coalesced.
+__global__ __launch_bounds__(NT) void k_enc0_fwd(int H, int I, const int32_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                 const uint8_t* __restrict__ drop_keep, float keep,
+                                                 uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
+                                                 const float* __restrict__ bq0, float* __restrict__ h1,
+                                                 float* __restrict__ row_scale) {
+    __shared__ int s_idx[NT];
+    __shared__ float s_val[NT];
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int beg = indptr[b], end = indptr[b + 1];
+    float ss = 0.f;
+    for (int e = beg + tid; e < end; e += NT) {
+        const float v = values ? values[e] : 1.f;
+        ss += v * v;
+    }
+    ss = block_sum(ss, red);
+    const float scale = 1.f / (keep * sqrtf(fmaxf(ss, 1e-12f)));  // l2_normalize eps, then /keep
+    if (tid == 0) row_scale[b] = scale;
+    constexpr int MAXC = 4;  // supports H <= 1024
+    float acc[MAXC] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = beg; c0 < end; c0 += NT) {
+        __syncthreads();
+        const int e = c0 + tid;
+        if (e < end) {
+            const int it = indices[e];
+            const float v = values ? values[e] : 1.f;
+            const bool kp = drop_keep ? (drop_keep[e] != 0)
+                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)I + it, keep);
+            s_idx[tid] = it;
+            s_val[tid] = kp ? v : 0.f;
+        }
+        __syncthreads();
+        const int cnt = min(NT, end - c0);
+        for (int j = 0; j < cnt; ++j) {
+            const float v = s_val[j];
+            if (v != 0.f) {
+                const float* wr = Wq0 + (size_t)s_idx[j] * H;
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) {
+                    const int c = tid + q * NT;
+                    if (c < H) acc[q] += v * wr[c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+        const int c = tid + q * NT;
+        if (c < H) h1[(size_t)b * H + c] = tanhf(acc[q] * scale + bq0[c]);
+    }
+}
+
+// Generic dense layer  C = act(A[M][K] . B[K][N] + bias)  (fp32 MFMA); act: 0 none, 1 tanh.
+// Serves enc-1 (MultiVAE.py:152) and dec-0 (MultiVAE.py:168-172).
+template <int ACT>
+__global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const float* __restrict__ A,
+                                                  const float* __restrict__ Bw, const float* __restrict__ bias,
+                                                  float* __restrict__ C) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a = [=] __device__(int m, int k) -> float { return m < M ? A[(size_t)m * K + k] : 0.f; };
+    auto b = [=] __device__(int k, int n) -> float { return n < N ? Bw[(size_t)k * N + n] : 0.f; };
+    auto epi = [=] __device__(int m, int n, float acc) {
+        const float x = acc + bias[n];
+        C[(size_t)m * N + n] = ACT == 1 ? tanhf(x) : x;
+    };
+    ltg_gemm_block<false, 64, 64, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
+}
+
+// Reparameterisation + KL (MultiVAE.py:157-162, :178-181).
+__global__ __launch_bounds__(NT) void k_reparam(int Z, const float* __restrict__ mulv, const float* __restrict__ eps_in,
+                                                float is_training, uint64_t seed, uint64_t step,
+                                                float* __restrict__ z, float* __restrict__ kl_rows) {
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x;
+    float kl = 0.f;
+    for (int j = threadIdx.x; j < Z; j += NT) {
+        const float mu = mulv[(size_t)b * 2 * Z + j], lv = mulv[(size_t)b * 2 * Z + Z + j];
+        const float sd = expf(0.5f * lv);
+        kl += 0.5f * (-lv + expf(lv) + mu * mu - 1.f);
+        float e = 0.f;
+        if (is_training != 0.f)
+            e = eps_in ? eps_in[(size_t)b * Z + j] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)b * Z + j);
+        z[(size_t)b * Z + j] = mu + is_training * e * sd;
+    }
+    kl = block_sum(kl, red);
+    if (threadIdx.x == 0) kl_rows[b] = kl;
+}
+
+// dec-1 (MultiVAE.py:169): logits[b][i] = h2[b][:] . W_p1t[i][:] + b_p1[i]; the big GEMM.
+template <bool BF16>
+__global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const float* __restrict__ h2,
+                                                 const float* __restrict__ Wp1t, const float* __restrict__ bp1,
+                                                 float* __restrict__ logits) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a = [=] __device__(int m, int k) -> float { return m < M ? h2[(size_t)m * H + k] : 0.f; };
+    auto b = [=] __device__(int k, int n) -> float { return n < I ? Wp1t[(size_t)n * H + k] : 0.f; };
+    auto epi = [=] __device__(int m, int n, float acc) { logits[(size_t)m * I + n] = acc + bp1[n]; };
+    ltg_gemm_block<BF16, 64, 64, 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
+}
+
+// row log-sum-exp of the logits (log_softmax / softmax, MultiVAE.py:108,143)
+__global__ __launch_bounds__(NT) void k_row_lse(int I, const float* __restrict__ logits, float* __restrict__ lse) {
+    __shared__ float red[NT / 64];
+    const float* row = logits + (size_t)blockIdx.x * I;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < I; i += NT) mx = fmaxf(mx, row[i]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < I; i += NT) s += expf(row[i] - mx);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) lse[blockIdx.x] = mx + logf(s);
+}
+
+__global__ __launch_bounds__(NT) void k_softmax_write(int I, const float* __restrict__ logits, const float* __restrict__ lse,
+                                                      float* __restrict__ probs) {
+    const size_t base = (size_t)blockIdx.y * I;
+    const float l = lse[blockIdx.y];
+    for (int i = blockIdx.x * NT + threadIdx.x; i < I; i += gridDim.x * NT) probs[base + i] = expf(logits[base + i] - l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Discriminator (discriminator.py:3-58).  A "pair batch" is the logical concatenation of the real
+// tower rows [0, nr) and the fake tower rows [nr, nr+nf); both towers share the weights.
+// ---------------------------------------------------------------------------------------------
+struct PairView {
+    int nr, nf;
+    const int32_t *r_pop, *r_nic, *f_pop, *f_nic;
+    __device__ __forceinline__ int pop(int r) const { return r < nr ? r_pop[r] : f_pop[r - nr]; }
+    __device__ __forceinline__ int nic(int r) const { return r < nr ? r_nic[r] : f_nic[r - nr]; }
+    __device__ __forceinline__ bool valid(int r) const { return pop(r) >= 0 && nic(r) >= 0; }
+};
+struct DropView {
+    const uint8_t *real, *fake;  // optional injected keep flags [rows][width]
+    int nr;
+    __device__ __forceinline__ bool keep(int r, int c, int width, uint64_t seed, uint32_t stream, uint64_t step, float kp) const {
+        if (real || fake) return r < nr ? (real[(size_t)r * width + c] != 0) : (fake[(size_t)(r - nr) * width + c] != 0);
+        return ltg_rng_keep(seed, stream, step, (uint64_t)r * width + c, kp);
+    }
+};
+
+// branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular->h1, 1 niche->h2
+__global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
+                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ w2, const float* __restrict__ b2, DropView dA,
+                                             DropView dB, float keep, uint64_t seed, uint64_t step,
+                                             float* __restrict__ A1) {
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    const bool br = blockIdx.z != 0;
+    const int N = br ? h2 : h1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (n0 >= N) return;
+    const float* W = br ? w2 : w1;
+    const float* bias = br ? b2 : b1;
+    auto a = [=] __device__(int m, int k) -> float {
+        if (m >= n) return 0.f;
+        const int id = br ? pv.nic(m) : pv.pop(m);
+        return id >= 0 ? emb[(size_t)id * h0 + k] : 0.f;
+    };
+    auto b = [=] __device__(int k, int nn) -> float { return nn < N ? W[(size_t)k * N + nn] : 0.f; };
+    auto epi = [=] __device__(int m, int nn, float acc) {
+        const float t = tanhf(acc + bias[nn]);
+        const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep)
+                           : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
+        A1[(size_t)m * h12 + (br ? h1 : 0) + nn] = kp ? t / keep : 0.f;
+    };
+    ltg_gemm_block<false, 64, 64, 2, 2, false, true>(n, N, m0, n0, 0, h0, a, b, epi);
+}
+
+// fully connected layer (discriminator.py:44, :54)
+__global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float* __restrict__ A1,
+                                             const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
+                                             float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a = [=] __device__(int m, int k) -> float { return m < n ? A1[(size_t)m * h12 + k] : 0.f; };
+    auto b = [=] __device__(int k, int nn) -> float { return nn < h3 ? w3[(size_t)k * h3 + nn] : 0.f; };
+    auto epi = [=] __device__(int m, int nn, float acc) {
+        const float t = tanhf(acc + b3[nn]);
+        A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
+    };
+    ltg_gemm_block<false, 64, 64, 2, 2, false, true>(n, h3, m0, n0, 0, h12, a, b, epi);
+}
+
+// output unit + loss terms (discriminator.py:45,55; train.py:142): one wave per pair row.
+// y[r] (0 for holes), ds[r] = d d_loss / d s_r, lrow[r] = loss term.
+__global__ __launch_bounds__(NT) void k_d_out(PairView pv, int h3, const float* __restrict__ A3,
+                                              const float* __restrict__ w4, const float* __restrict__ b4,
+                                              float* __restrict__ y, float* __restrict__ ds, float* __restrict__ lrow) {
+    const int n = pv.nr + pv.nf;
+    const int r = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float s = 0.f;
+    for (int c = lane; c < h3; c += 64) s += A3[(size_t)r * h3 + c] * w4[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        s += b4[0];
+        const float yy = 1.f / (1.f + expf(-s));
+        const bool ok = pv.valid(r);
+        const bool real = r < pv.nr;
+        y[r] = ok ? yy : 0.f;
+        ds[r] = ok ? (real ? -(1.f - yy) : yy) : 0.f;
+        lrow[r] = ok ? (real ? -logf(yy) : -logf(1.f - yy)) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_sum_to(int n, const float* __restrict__ x, float* __restrict__ out) {
+    __shared__ float red[NT / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += NT) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// derivative through dropout(tanh(.)): a = t/keep*mask  =>  d pre = d a * (1 - t^2)/keep where mask=1
+__device__ __forceinline__ float dact(float a, float keep) {
+    const float t = a * keep;
+    return a != 0.f ? (1.f - t * t) / keep : 0.f;
+}
+
+// dw4 / db4 + Adam: column reduction over the pair rows; block = 32 columns x 8 row lanes
+__global__ __launch_bounds__(NT) void k_dw4_adam(int n, int h3, const float* __restrict__ A3, const float* __restrict__ ds,
+                                                 float* __restrict__ w4, float* __restrict__ mw4, float* __restrict__ vw4,
+                                                 float* __restrict__ b4, float* __restrict__ mb4, float* __restrict__ vb4,
+                                                 AdamC ad) {
+    __shared__ float part[8][33];
+    const int tn = threadIdx.x & 31, tr = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tn;  // c == h3 is the bias column
+    float acc = 0.f;
+    if (c <= h3)
+        for (int r = tr; r < n; r += 8) acc += (c < h3 ? A3[(size_t)r * h3 + c] : 1.f) * ds[r];
+    part[tr][tn] = acc;
+    __syncthreads();
+    if (tr == 0 && c <= h3) {
+        float g = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g += part[i][tn];
+        if (c < h3) adam_update(w4, mw4, vw4, c, g, ad);
+        else adam_update(b4, mb4, vb4, 0, g, ad);
+    }
+}
+
+// d hin = dpre3 . w3^T, then through the branch activations: dpre1 [n][h1+h2]
+__global__ __launch_bounds__(NT) void k_d_dA1(int n, int h12, int h3, const float* __restrict__ A1,
+                                              const float* __restrict__ A3, const float* __restrict__ ds,
+                                              const float* __restrict__ w4, const float* __restrict__ w3, float keep,
+                                              float* __restrict__ dpre1) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a = [=] __device__(int m, int k) -> float {
+        return m < n ? ds[m] * w4[k] * dact(A3[(size_t)m * h3 + k], keep) : 0.f;
+    };
+    auto b = [=] __device__(int k, int nn) -> float { return nn < h12 ? w3[(size_t)nn * h3 + k] : 0.f; };
+    auto epi = [=] __device__(int m, int nn, float acc) {
+        dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
+    };
+    ltg_gemm_block<false, 64, 64, 2, 2, false, false>(n, h12, m0, n0, 0, h3, a, b, epi);
+}
+
+// dw3 / db3 (ones-augmented row h12) + Adam
+__global__ __launch_bounds__(NT) void k_d_dw3_adam(int n, int h12, int h3, const float* __restrict__ A1,
+                                                   const float* __restrict__ A3, const float* __restrict__ ds,
+                                                   const float* __restrict__ w4, float keep, float* __restrict__ w3,
+                                                   float* __restrict__ mw3, float* __restrict__ vw3, float* __restrict__ b3,
+                                                   float* __restrict__ mb3, float* __restrict__ vb3, AdamC ad) {
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
+    const int M = h12 + 1;
+    auto a = [=] __device__(int m, int k) -> float { return m < h12 ? A1[(size_t)k * h12 + m] : (m == h12 ? 1.f : 0.f); };
+    auto b = [=] __device__(int k, int nn) -> float {
+        return nn < h3 ? ds[k] * w4[nn] * dact(A3[(size_t)k * h3 + nn], keep) : 0.f;
+    };
+    auto epi = [=] __device__(int m, int nn, float g) {
+        if (m < h12) adam_update(w3, mw3, vw3, (size_t)m * h3 + nn, g, ad);
+        else adam_update(b3, mb3, vb3, nn, g, ad);
+    };
+    ltg_gemm_block<false, 32, 64, 1, 4, true, true>(M, h3, m0, n0, 0, n, a, b, epi);
+}
+
+// dw1/db1 (blockIdx.z=0) and dw2/db2 (blockIdx.z=1) + Adam
+__global__ __launch_bounds__(NT) void k_d_dw12_adam(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
+                                                    const float* __restrict__ dpre1, ltg_disc_state st, AdamC ad) {
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    const bool br = blockIdx.z != 0;
+    const int N = br ? h2 : h1;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (n0 >= N) return;
+    const int M = h0 + 1;
+    const int coff = br ? h1 : 0;
+    float* W = st.p[br ? 2 : 0];
+    float* mW = st.m[br ? 2 : 0];
+    float* vW = st.v[br ? 2 : 0];
+    float* Bv = st.p[br ? 3 : 1];
+    float* mB = st.m[br ? 3 : 1];
+    float* vB = st.v[br ? 3 : 1];
+    auto a = [=] __device__(int m, int k) -> float {
+        if (m == h0) return 1.f;
+        if (m > h0) return 0.f;
+        const int id = br ? pv.nic(k) : pv.pop(k);
+        return id >= 0 ? emb[(size_t)id * h0 + m] : 0.f;
+    };
+    auto b = [=] __device__(int k, int nn) -> float { return nn < N ? dpre1[(size_t)k * h12 + coff + nn] : 0.f; };
+    auto epi = [=] __device__(int m, int nn, float g) {
+        if (m < h0) adam_update(W, mW, vW, (size_t)m * N + nn, g, ad);
+        else adam_update(Bv, mB, vB, nn, g, ad);
+    };
+    ltg_gemm_block<false, 32, 32, 2, 2, false, true>(M, N, m0, n0, 0, n, a, b, epi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generator step: losses (train.py:145-157) and backward (closed forms: SURVEY 8 row a10)
+// ---------------------------------------------------------------------------------------------
+
+// per-row statistics: neg_ll_row, n_b = sum x, P_b = sum_{k in S_b} p_bk
+__global__ __launch_bounds__(NT) void k_g_rowstats(int I, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                   const float* __restrict__ values, const float* __restrict__ logits,
+                                                   const float* __restrict__ lse, int nf, const int32_t* __restrict__ f_row,
+                                                   const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
+                                                   float* __restrict__ negll_row, float* __restrict__ nb, float* __restrict__ Pb) {
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x;
+    const float l = lse[b];
+    const float* row = logits + (size_t)b * I;
+    float s_ll = 0.f, s_n = 0.f, s_p = 0.f;
+    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+        const float v = values ? values[e] : 1.f;
+        s_ll -= v * (row[indices[e]] - l);
+        s_n += v;
+    }
+    for (int s = threadIdx.x; s < nf; s += NT)
+        if (f_row[s] == b && f_gen[s] >= 0 && f_pop[s] >= 0) s_p += expf(row[f_gen[s]] - l);
+    s_ll = block_sum(s_ll, red);
+    s_n = block_sum(s_n, red);
+    s_p = block_sum(s_p, red);
+    if (threadIdx.x == 0) {
+        negll_row[b] = s_ll;
+        nb[b] = s_n;
+        Pb[b] = s_p;
+    }
+}
+
+// scalars: out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
+__global__ __launch_bounds__(NT) void k_g_scalars(int B, int nf, const float* __restrict__ negll_row,
+                                                  const float* __restrict__ kl_rows, const float* __restrict__ Pb,
+                                                  const float* __restrict__ y, const int32_t* __restrict__ cnt, float anneal,
+                                                  float lam, float* __restrict__ out) {
+    __shared__ float red[NT / 64];
+    float a = 0.f, k = 0.f, p = 0.f, sy = 0.f;
+    for (int i = threadIdx.x; i < B; i += NT) {
+        a += negll_row[i];
+        k += kl_rows[i];
+        p += Pb[i];
+    }
+    for (int i = threadIdx.x; i < nf; i += NT) sy += y[i];
+    a = block_sum(a, red);
+    k = block_sum(k, red);
+    p = block_sum(p, red);
+    sy = block_sum(sy, red);
+    if (threadIdx.x == 0) {
+        const float negll = a / (float)B, KL = k / (float)B;
+        const float c = cnt[0] > 0 ? lam / (float)cnt[0] * sy : 0.f;
+        const float vae = negll + anneal * KL;
+        const float gan = -c * p;
+        out[0] = vae + gan;
+        out[1] = vae;
+        out[2] = gan;
+        out[3] = p;
+        out[4] = sy;
+        out[5] = c;
+    }
+}
+
+// dlogits[b][i] = p*(n_b/B + c*P_b) - x_bi/B - c*p*[(b,i) in S]; grid (segments, rows).
+constexpr int DL_SEG = 2048;
+__global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __restrict__ indptr,
+                                                const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                const float* __restrict__ logits, const float* __restrict__ lse,
+                                                const float* __restrict__ nb, const float* __restrict__ Pb,
+                                                const float* __restrict__ scal, int nf, const int32_t* __restrict__ f_row,
+                                                const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
+                                                float* __restrict__ dlog) {
+    __shared__ float s_x[DL_SEG];
+    __shared__ uint8_t s_s[DL_SEG];
+    const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG;
+    const int i1 = min(I, i0 + DL_SEG);
+    for (int j = threadIdx.x; j < DL_SEG; j += NT) {
+        s_x[j] = 0.f;
+        s_s[j] = 0;
+    }
+    __syncthreads();
+    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+        const int it = indices[e];
+        if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
+    }
+    for (int s = threadIdx.x; s < nf; s += NT) {
+        const int it = f_gen[s];
+        if (f_row[s] == b && it >= i0 && it < i1 && f_pop[s] >= 0) s_s[it - i0] = 1;
+    }
+    __syncthreads();
+    const float invB = 1.f / (float)B, c = scal[5], l = lse[b];
+    const float alpha = nb[b] * invB + c * Pb[b];
+    const size_t base = (size_t)b * I;
+    for (int i = i0 + threadIdx.x; i < i1; i += NT) {
+        const float p = expf(logits[base + i] - l);
+        dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
+    }
+}
+
+// dh2 partials: part[z][b][h] = sum_{i in split z} dlog[b][i] * W_p1t[i][h]   (split-K over items)
+template <bool BF16>
+__global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kchunk, const float* __restrict__ dlog,
+                                                    const float* __restrict__ Wp1t, float* __restrict__ part) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * kchunk, kend = min(I, kbeg + kchunk);
+    float* out = part + (size_t)blockIdx.z * B * H;
+    auto a = [=] __device__(int m, int k) -> float { return m < B ? dlog[(size_t)m * I + k] : 0.f; };
+    auto b = [=] __device__(int k, int n) -> float { return n < H ? Wp1t[(size_t)k * H + n] : 0.f; };
+    auto epi = [=] __device__(int m, int n, float acc) { out[(size_t)m * H + n] = acc; };
+    ltg_gemm_block<BF16, 64, 64, 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
+}
+
+// da2 = (sum_z part) * (1 - h2^2)
+__global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __restrict__ part, const float* __restrict__ h2,
+                                            float* __restrict__ da2) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
+        const float t = h2[i];
+        da2[i] = s * (1.f - t * t);
+    }
+}
+
+// dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
+template <bool BF16>
+__global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
+                                                      const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
+    auto a = [=] __device__(int m, int k) -> float { return (m < I && k < B) ? dlog[(size_t)k * I + m] : 0.f; };
+    auto b = [=] __device__(int k, int n) -> float { return k < B ? (n < H ? h2[(size_t)k * H + n] : (n == H ? 1.f : 0.f)) : 0.f; };
+    auto epi = [=] __device__(int m, int n, float g) {
+        if (n < H) adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
+        else adam_update(bb, mb, vb, m, g, ad);
+    };
+    ltg_gemm_block<BF16, 64, 64, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+}
+
+// dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)
+__global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
+                                           const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
+                                           float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const float invB = 1.f / (float)B;
+    auto a = [=] __device__(int m, int k) -> float { return m < B ? da2[(size_t)m * H + k] : 0.f; };
+    auto b = [=] __device__(int k, int n) -> float { return n < Z ? Wp0[(size_t)n * H + k] : 0.f; };
+    auto epi = [=] __device__(int m, int n, float dz) {
+        const float mu = mulv[(size_t)m * 2 * Z + n], lv = mulv[(size_t)m * 2 * Z + Z + n];
+        float e = 0.f;
+        if (is_training != 0.f)
+            e = eps_in ? eps_in[(size_t)m * Z + n] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)m * Z + n);
+        dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
+        dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
+    };
+    ltg_gemm_block<false, 64, 64, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
+}
+
+// generic "weight gradient + Adam": G[m][n] = sum_k L(k,m) * R(k,n) with ones-augmented row m == Min
+// (bias gradient).  L: [K][Min] activations, R: [K][N] upstream gradient.
+__global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const float* __restrict__ L,
+                                                   const float* __restrict__ R, float* __restrict__ W, float* __restrict__ mW,
+                                                   float* __restrict__ vW, float* __restrict__ bias, float* __restrict__ mb,
+                                                   float* __restrict__ vb, AdamC ad) {
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
+    auto a = [=] __device__(int m, int k) -> float { return m < Min ? L[(size_t)k * Min + m] : (m == Min ? 1.f : 0.f); };
+    auto b = [=] __device__(int k, int n) -> float { return n < N ? R[(size_t)k * N + n] : 0.f; };
+    auto epi = [=] __device__(int m, int n, float g) {
+        if (m < Min) adam_update(W, mW, vW, (size_t)m * N + n, g, ad);
+        else adam_update(bias, mb, vb, n, g, ad);
+    };
+    ltg_gemm_block<false, 32, 64, 1, 4, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
+}
+
+// dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)
+__global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* __restrict__ dmlv,
+                                            const float* __restrict__ Wq1, const float* __restrict__ h1, float* __restrict__ da1) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a = [=] __device__(int m, int k) -> float { return m < B ? dmlv[(size_t)m * Z2 + k] : 0.f; };
+    auto b = [=] __device__(int k, int n) -> float { return n < H ? Wq1[(size_t)n * Z2 + k] : 0.f; };
+    auto epi = [=] __device__(int m, int n, float acc) {
+        const float t = h1[(size_t)m * H + n];
+        da1[(size_t)m * H + n] = acc * (1.f - t * t);
+    };
+    ltg_gemm_block<false, 64, 64, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
+}
+
+// Dense Adam sweep over W_q0 [I][H] (+ bias row I) with the sparse gradient gathered through the
+// batch's CSC view: dW_q0[i][:] = sum_{b in col i} keep*val*row_scale[b] * da1[b][:].
+// TF's Adam touches every row every step (zero gradient still decays m, v and moves theta).
+__global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int B, int I, int H, const int32_t* __restrict__ colptr,
+                                                      const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
+                                                      const float* __restrict__ values, const uint8_t* __restrict__ drop_keep,
+                                                      float keep, uint64_t seed, uint64_t step,
+                                                      const float* __restrict__ row_scale, const float* __restrict__ da1,
+                                                      ltg_gen_state st, AdamC ad) {
+    const int H4 = H >> 2;  // H % 4 == 0 (checked on the host)
+    const size_t total = (size_t)(I + 1) * H4;
+    float4* W4 = reinterpret_cast<float4*>(st.p[0]);
+    float4* m4 = reinterpret_cast<float4*>(st.m[0]);
+    float4* v4 = reinterpret_cast<float4*>(st.v[0]);
+    float4* b4 = reinterpret_cast<float4*>(st.p[4]);
+    float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
+    float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
+    const float4* d4 = reinterpret_cast<const float4*>(da1);
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const int i = (int)(e / H4), c = (int)(e % H4);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < I) {
+            for (int q = colptr[i]; q < colptr[i + 1]; ++q) {
+                const int b = rowidx[q], pos = csr_pos[q];
+                const bool kp = drop_keep ? (drop_keep[pos] != 0)
+                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)I + i, keep);
+                if (kp) {
+                    const float s = (values ? values[pos] : 1.f) * row_scale[b];
+                    const float4 d = d4[(size_t)b * H4 + c];
+                    g.x += s * d.x;
+                    g.y += s * d.y;
+                    g.z += s * d.z;
+                    g.w += s * d.w;
+                }
+            }
+        } else {
+            for (int b = 0; b < B; ++b) {
+                const float4 d = d4[(size_t)b * H4 + c];
+                g.x += d.x;
+                g.y += d.y;
+                g.z += d.z;
+                g.w += d.w;
+            }
+        }
+        float4* P = i < I ? W4 + e : b4 + c;
+        float4* Mm = i < I ? m4 + e : mb4 + c;
+        float4* Vv = i < I ? v4 + e : vb4 + c;
+        float4 p = *P, mm = *Mm, vv = *Vv;
+#define LTG_ADAM1(f)                                              \
+    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;                    \
+    vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;              \
+    p.f = p.f - ad.lr_t * mm.f / (sqrtf(vv.f) + ad.eps);
+        LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
+#undef LTG_ADAM1
+        *P = p;
+        *Mm = mm;
+        *Vv = vv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampler: sample_from_generator_new (sample.py:40-67) + pair construction (train.py:227-251).
+// One wave per user.  Successive sampling without replacement == Gumbel-top-k on log p.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sample_pairs(int I, const int32_t* __restrict__ cand_ptr,
+                                                     const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ pop_ptr,
+                                                     const int32_t* __restrict__ pop_idx, const int32_t* __restrict__ n_sample,
+                                                     const int32_t* __restrict__ slot_ptr, const uint8_t* __restrict__ valid_item,
+                                                     const float* __restrict__ u_gumbel, const float* __restrict__ u_pick,
+                                                     uint64_t seed, uint64_t step, const float* __restrict__ logits,
+                                                     const float* __restrict__ lse, int32_t* __restrict__ gen_out,
+                                                     int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out) {
+    extern __shared__ __attribute__((aligned(16))) float s_key[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int ns = n_sample[b];
+    const int s0 = slot_ptr[b];
+    if (ns <= 0) return;
+    const int c0 = cand_ptr[b], nc = cand_ptr[b + 1] - c0;
+    const float l = lse[b];
+    const float* row = logits + (size_t)b * I;
+    int nnz = 0;
+    for (int j = lane; j < nc; j += 64) {
+        const int it = cand_idx[c0 + j];
+        const float lp = row[it] - l;
+        const bool pos = expf(lp) > 0.f;  // softmax underflow == "zero probability" of sample.py:45
+        float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, (uint64_t)b * (uint64_t)I + it);
+        u = fmaxf(u, 2.98023223876953125e-8f);  // 2^-25
+        s_key[j] = pos ? lp - logf(-logf(u)) : -INFINITY;
+        nnz += pos ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
+    __syncthreads();
+    const int k_eff = min(ns, nnz);  // Q10: exception-driven decrement of to_sample
+    const int np = pop_ptr[b + 1] - pop_ptr[b];
+    int written = 0, okcnt = 0;
+    for (int j0 = 0; j0 < nc; j0 += 64) {
+        const int j = j0 + lane;
+        bool sel = false;
+        if (j < nc) {
+            const float kj = s_key[j];
+            int rank = 0;
+            for (int t = 0; t < nc; ++t) {
+                const float kt = s_key[t];
+                rank += (kt > kj || (kt == kj && t < j)) ? 1 : 0;
+            }
+            sel = rank < k_eff;
+        }
+        const unsigned long long bal = __ballot(sel);
+        if (sel) {
+            const int pos = written + __popcll(bal & ((1ull << lane) - 1ull));
+            const int s = s0 + pos;
+            const int gid = cand_idx[c0 + j];
+            const float u = u_pick ? u_pick[s] : ltg_rng_uniform(seed, LTG_STREAM_POP_PICK, step, (uint64_t)b * (uint64_t)I + gid);
+            const int pi = min((int)(u * (float)np), np - 1);  // np.random.choice(range(n)) train.py:236
+            const int pid = pop_idx[pop_ptr[b] + pi];
+            const bool ok = valid_item[gid] != 0 && valid_item[pid] != 0;  // train.py:240
+            gen_out[s] = ok ? gid : -1;
+            pop_out[s] = ok ? pid : -1;
+            okcnt += ok ? 1 : 0;
+        }
+        written += __popcll(bal);
+    }
+    for (int s = s0 + written + lane; s < s0 + ns; s += 64) {
+        gen_out[s] = -1;
+        pop_out[s] = -1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) okcnt += __shfl_xor(okcnt, o);
+    if (lane == 0 && okcnt > 0) atomicAdd(cnt_out, okcnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ranking metrics (eval_functions.py:11-62, train.py:341).  One workgroup per user.
+// rank(h) = #{i : score_i > score_h or (score_i == score_h and i < h)}, score = -inf on fold-in items.
+// ---------------------------------------------------------------------------------------------
+constexpr int RM_T = 16;  // held-out items processed per pass
+__global__ __launch_bounds__(NT) void k_rank_metrics(int I, const float* __restrict__ logits, const int32_t* __restrict__ tr_ptr,
+                                                     const int32_t* __restrict__ tr_idx, const int32_t* __restrict__ te_ptr,
+                                                     const int32_t* __restrict__ te_idx, int k_ndcg, int k_r1, int k_r2,
+                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned s_bits[];  // ceil(I/32) words
+    __shared__ int s_cnt[RM_T];
+    __shared__ float s_sc[RM_T];
+    __shared__ int s_it[RM_T];
+    __shared__ double s_acc[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nw = (I + 31) >> 5;
+    for (int w = tid; w < nw; w += NT) s_bits[w] = 0u;
+    if (tid < 4) s_acc[tid] = 0.0;
+    __syncthreads();
+    for (int e = tr_ptr[b] + tid; e < tr_ptr[b + 1]; e += NT) {
+        const int it = tr_idx[e];
+        atomicOr(&s_bits[it >> 5], 1u << (it & 31));
+    }
+    __syncthreads();
+    const float* row = logits + (size_t)b * I;
+    const int t0 = te_ptr[b], nte = te_ptr[b + 1] - t0;
+    for (int p0 = 0; p0 < nte; p0 += RM_T) {
+        const int np = min(RM_T, nte - p0);
+        if (tid < np) {
+            const int it = te_idx[t0 + p0 + tid];
+            s_it[tid] = it;
+            s_sc[tid] = ((s_bits[it >> 5] >> (it & 31)) & 1u) ? -INFINITY : row[it];
+            s_cnt[tid] = 0;
+        }
+        __syncthreads();
+        int cnt[RM_T];
+#pragma unroll
+        for (int t = 0; t < RM_T; ++t) cnt[t] = 0;
+        for (int i = tid; i < I; i += NT) {
+            const float sc = ((s_bits[i >> 5] >> (i & 31)) & 1u) ? -INFINITY : row[i];
+#pragma unroll
+            for (int t = 0; t < RM_T; ++t)
+                if (t < np) cnt[t] += (sc > s_sc[t] || (sc == s_sc[t] && i < s_it[t])) ? 1 : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < RM_T; ++t) {
+            if (t < np) {
+                int c = cnt[t];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                if ((tid & 63) == 0) atomicAdd(&s_cnt[t], c);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int t = 0; t < np; ++t) {
+                const int r = s_cnt[t];
+                if (r < k_ndcg) s_acc[0] += 1.0 / log2((double)r + 2.0);
+                if (r < k_r1) s_acc[1] += 1.0;
+                if (r < k_r2) s_acc[2] += 1.0;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double idcg = 0.0;
+        for (int r = 0; r < min(nte, k_ndcg); ++r) idcg += 1.0 / log2((double)r + 2.0);
+        out[(size_t)b * 4 + 0] = idcg != 0.0 ? (float)(s_acc[0] / idcg) : 0.f;
+        out[(size_t)b * 4 + 1] = nte > 0 ? (float)(s_acc[1] / (double)min(k_r1, nte)) : 0.f;
+        out[(size_t)b * 4 + 2] = nte > 0 ? (float)(s_acc[2] / (double)min(k_r2, nte)) : 0.f;
+        out[(size_t)b * 4 + 3] = idcg != 0.0 ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+inline int dh2_kchunk(int I) {
+    // split the item dimension so that ~128 workgroups x (H/64) share the reduction
+    int chunk = (I + 63) / 64;
+    chunk = (chunk + 31) / 32 * 32;
+    if (chunk < 256) chunk = 256;
+    return chunk;
+}
+
+struct Workspace {
+    // generator backward
+    float *negll_row, *nb, *Pb, *scal, *dlog, *part, *da2, *dmlv, *da1;
+    // discriminator
+    float *A1, *A3, *y, *ds, *lrow, *dpre1;
+    size_t bytes;
+};
+
+Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t nfloat) {
+        float* p = reinterpret_cast<float*>(base + off);
+        off += align_up(nfloat * sizeof(float));
+        return p;
+    };
+    const size_t R = (size_t)max_rows, I = (size_t)cfg->n_items, H = (size_t)cfg->h_enc, Z = (size_t)cfg->z_dim;
+    const size_t P = (size_t)max_pairs, h12 = (size_t)cfg->d_h1 + cfg->d_h2, h3 = (size_t)cfg->d_h3;
+    const int kchunk = dh2_kchunk(cfg->n_items);
+    const size_t nsplit = (I + kchunk - 1) / kchunk;
+    w.negll_row = take(R);
+    w.nb = take(R);
+    w.Pb = take(R);
+    w.scal = take(16);
+    w.dlog = take(R * I);
+    w.part = take(nsplit * R * H);
+    w.da2 = take(R * H);
+    w.dmlv = take(R * 2 * Z);
+    w.da1 = take(R * H);
+    w.A1 = take(P * h12);
+    w.A3 = take(P * h3);
+    w.y = take(P);
+    w.ds = take(P);
+    w.lrow = take(P);
+    w.dpre1 = take(P * h12);
+    w.bytes = off;
+    return w;
+}
+
+inline AdamC make_adam(const ltg_config* cfg, int t) {
+    AdamC a;
+    const double b1 = cfg->beta1, b2 = cfg->beta2;
+    a.lr_t = (float)((double)cfg->lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+    a.b1 = cfg->beta1;
+    a.b2 = cfg->beta2;
+    a.eps = cfg->adam_eps;
+    return a;
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? LTG_OK : LTG_ELAUNCH; }
+
+inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return dim3((N + bn - 1) / bn, (M + bm - 1) / bm, z); }
+
+bool cfg_ok(const ltg_config* c) {
+    return c && c->n_items > 0 && c->h_enc > 0 && c->h_enc <= 1024 && (c->h_enc % 4) == 0 && c->z_dim > 0 &&
+           (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32);
+}
+
+int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
+                     const ltg_gen_acts* acts, float* probs_out, hipStream_t st) {
+    const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
+    if (R <= 0) return LTG_OK;
+    hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(NT), 0, st, H, I, bt->indptr, bt->indices, bt->values, o->drop_keep,
+                       o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale);
+    hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
+    hipLaunchKernelGGL(k_reparam, dim3(R), dim3(NT), 0, st, Z, acts->mulv, o->eps, o->is_training, cfg->seed, o->rng_step,
+                       acts->z, acts->kl_rows);
+    hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
+    if (cfg->precision == LTG_PREC_BF16)
+        hipLaunchKernelGGL(k_dec1_fwd<true>, grid2(I, R), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+    else
+        hipLaunchKernelGGL(k_dec1_fwd<false>, grid2(I, R), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+    hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
+    if (probs_out) {
+        const int gx = (I + NT - 1) / NT < 64 ? (I + NT - 1) / NT : 64;
+        hipLaunchKernelGGL(k_softmax_write, dim3(gx, R), dim3(NT), 0, st, I, acts->logits, acts->lse, probs_out);
+    }
+    return check_launch();
+}
+
+// forward of one or both towers into ws (A1, A3, y, ds, lrow)
+void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
+                  float keep, uint64_t step, const Workspace& w, hipStream_t st) {
+    const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
+    const int nmax = h1 > h2 ? h1 : h2;
+    hipLaunchKernelGGL(k_d_l1, grid2(nmax, n, 64, 64, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+                       d->p[3], dA, dB, keep, cfg->seed, step, w.A1);
+    hipLaunchKernelGGL(k_d_l2, grid2(h3, n), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3);
+    hipLaunchKernelGGL(k_d_out, dim3((n + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], w.y, w.ds, w.lrow);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ltg_abi_version(void) { return LTG_ABI_VERSION; }
+
+size_t ltg_workspace_bytes(const ltg_config* cfg, int32_t max_rows, int32_t max_pairs) {
+    if (!cfg_ok(cfg) || max_rows < 0 || max_pairs < 0) return 0;
+    return carve(cfg, max_rows < 1 ? 1 : max_rows, max_pairs < 1 ? 1 : max_pairs, nullptr).bytes;
+}
+
+int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_fwd_opts* opts,
+                    const ltg_gen_acts* acts, float* probs_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    (void)ws;
+    (void)ws_bytes;
+    if (!cfg_ok(cfg) || !gen || !batch || !opts || !acts || batch->n_rows < 0) return LTG_EINVAL;
+    if (!batch->indptr || !batch->indices || !acts->h1 || !acts->mulv || !acts->z || !acts->h2 || !acts->logits || !acts->lse ||
+        !acts->kl_rows || !acts->row_scale)
+        return LTG_EINVAL;
+    return vae_forward_impl(cfg, gen, batch, opts, acts, probs_out, (hipStream_t)stream);
+}
+
+int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, const float* lse,
+                     int32_t* gen_out, int32_t* pop_out, int32_t* cnt_out, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !in || !logits || !lse || !gen_out || !pop_out || !cnt_out) return LTG_EINVAL;
+    if (in->n_rows < 0 || in->max_cand < 0) return LTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(cnt_out, 0, sizeof(int32_t), st) != hipSuccess) return LTG_ELAUNCH;
+    if (in->n_rows == 0) return LTG_OK;
+    const int max_cand = in->max_cand > 0 ? in->max_cand : 1;
+    const size_t lds = (size_t)max_cand * sizeof(float);
+    if (lds > 64 * 1024) return LTG_EINVAL;
+    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(64), lds, st, cfg->n_items, in->cand_ptr, in->cand_idx, in->pop_ptr,
+                       in->pop_idx, in->n_sample, in->slot_ptr, in->valid_item, in->u_gumbel, in->u_pick, cfg->seed, in->rng_step,
+                       logits, lse, gen_out, pop_out, cnt_out);
+    return check_launch();
+}
+
+int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real, const ltg_pairs* fake,
+               const ltg_d_opts* o, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !disc || !real || !fake || !o || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
+    const int n = real->n + fake->n;
+    if (real->n < 0 || fake->n < 0) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, 1, n) > ws_bytes) return LTG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(loss_out, 0, sizeof(float), st) == hipSuccess ? LTG_OK : LTG_ELAUNCH;
+    const Workspace w = carve(cfg, 1, n, (char*)ws);
+    const int h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
+    PairView pv{real->n, fake->n, real->pop, real->niche, fake->pop, fake->niche};
+    DropView dA{o->drop_real[0], o->drop_fake[0], real->n}, dB{o->drop_real[1], o->drop_fake[1], real->n},
+        dC{o->drop_real[2], o->drop_fake[2], real->n};
+    disc_forward(cfg, disc, pv, dA, dB, dC, o->keep_prob, o->rng_step, w, st);
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(NT), 0, st, n, w.lrow, loss_out);
+    const AdamC ad = make_adam(cfg, o->adam_t);
+    // order matters: every product with the OLD weights runs before that weight's Adam epilogue
+    hipLaunchKernelGGL(k_d_dA1, grid2(h12, n), dim3(NT), 0, st, n, h12, h3, w.A1, w.A3, w.ds, disc->p[6], disc->p[4], o->keep_prob, w.dpre1);
+    hipLaunchKernelGGL(k_d_dw3_adam, grid2(h3, h12 + 1, 64, 32), dim3(NT), 0, st, n, h12, h3, w.A1, w.A3, w.ds, disc->p[6], o->keep_prob,
+                       disc->p[4], disc->m[4], disc->v[4], disc->p[5], disc->m[5], disc->v[5], ad);
+    hipLaunchKernelGGL(k_dw4_adam, dim3((h3 + 1 + 31) / 32), dim3(NT), 0, st, n, h3, w.A3, w.ds, disc->p[6], disc->m[6], disc->v[6],
+                       disc->p[7], disc->m[7], disc->v[7], ad);
+    const int nmax = h1 > h2 ? h1 : h2;
+    hipLaunchKernelGGL(k_d_dw12_adam, grid2(nmax, h0 + 1, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, disc->emb, w.dpre1, *disc, ad);
+    return check_launch();
+}
+
+int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
+               const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, float* loss_out, void* ws,
+               size_t ws_bytes, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !gen || !disc || !bt || !fake || !o || !acts || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
+    if (!bt->colptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
+    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim, nf = fake->n;
+    if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace w = carve(cfg, B, nf, (char*)ws);
+    int rc = vae_forward_impl(cfg, gen, bt, &o->fwd, acts, nullptr, st);
+    if (rc != LTG_OK) return rc;
+    // fake tower forward only (y_data is pruned from the g_trainer fetch, train.py:326)
+    if (nf > 0) {
+        PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
+        DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
+        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, st);
+    }
+    hipLaunchKernelGGL(k_g_rowstats, dim3(B), dim3(NT), 0, st, I, bt->indptr, bt->indices, bt->values, acts->logits, acts->lse, nf,
+                       fake->row, fake->niche, fake->pop, w.negll_row, w.nb, w.Pb);
+    hipLaunchKernelGGL(k_g_scalars, dim3(1), dim3(NT), 0, st, B, nf, w.negll_row, acts->kl_rows, w.Pb, w.y, o->cnt, o->anneal,
+                       o->gan_lambda, w.scal);
+    if (hipMemcpyAsync(loss_out, w.scal, 6 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return LTG_ELAUNCH;
+    hipLaunchKernelGGL(k_dlogits, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, bt->indptr, bt->indices, bt->values,
+                       acts->logits, acts->lse, w.nb, w.Pb, w.scal, nf, fake->row, fake->niche, fake->pop, w.dlog);
+    const AdamC ad = make_adam(cfg, o->adam_t);
+    const int kchunk = dh2_kchunk(I);
+    const int nsplit = (I + kchunk - 1) / kchunk;
+    const bool bf = cfg->precision == LTG_PREC_BF16;
+    if (bf) hipLaunchKernelGGL(k_dh2_partial<true>, grid2(H, B, 64, 64, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else hipLaunchKernelGGL(k_dh2_partial<false>, grid2(H, B, 64, 64, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    {
+        const int n = B * H;
+        const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
+        hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, acts->h2, w.da2);
+    }
+    if (bf) hipLaunchKernelGGL(k_dec1_bwd_adam<true>, grid2(H + 1, I), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    else hipLaunchKernelGGL(k_dec1_bwd_adam<false>, grid2(H + 1, I), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    hipLaunchKernelGGL(k_dz, grid2(Z, B), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
+                       o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 64, 32), dim3(NT), 0, st, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
+                       gen->p[6], gen->m[6], gen->v[6], ad);
+    hipLaunchKernelGGL(k_dh1, grid2(H, B), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 64, 32), dim3(NT), 0, st, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
+                       gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
+    {
+        const size_t total = (size_t)(I + 1) * (H / 4);
+        size_t gx = (total + NT - 1) / NT;
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, B, I, H, bt->colptr, bt->rowidx, bt->csr_pos, bt->values,
+                           o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, *gen, ad);
+    }
+    return check_launch();
+}
+
+int ltg_rank_metrics(const ltg_config* cfg, const float* logits, const ltg_batch* tr, const ltg_batch* te, int32_t k_ndcg,
+                     int32_t k_r1, int32_t k_r2, float* out, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !logits || !tr || !te || !out || tr->n_rows != te->n_rows || tr->n_rows < 0) return LTG_EINVAL;
+    if (tr->n_rows == 0) return LTG_OK;
+    const size_t lds = (size_t)((cfg->n_items + 31) / 32) * sizeof(unsigned);
+    if (lds > 64 * 1024) return LTG_EINVAL;
+    hipLaunchKernelGGL(k_rank_metrics, dim3(tr->n_rows), dim3(NT), lds, (hipStream_t)stream, cfg->n_items, logits, tr->indptr, tr->indices,
+                       te->indptr, te->indices, k_ndcg, k_r1, k_r2, out);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+"""Host-side engine: owns every device buffer (torch is only the allocator / stream provider) and
+drives the HIP kernels through the C ABI of include/ltg.h.
+
+One Engine == the state the reference keeps inside its TF session (Codes/train.py:125-174):
+generator variables (MultiVAE.py:188-230), discriminator variables (discriminator.py:14-41), ONE
+AdamOptimizer whose step counter is shared by the D and the G updates (train.py:160-164, Q5).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _cabi as cabi
+
+G_NAMES = ["weight_q_0to1", "weight_q_1to2", "weight_p_0to1", "weight_p_1to2",
+           "bias_q_1", "bias_q_2", "bias_p_1", "bias_p_2"]          # MultiVAE.py:196-197,216-217
+D_NAMES = ["d_w1_1", "d_b1", "d_w2", "d_b2", "d_w3", "d_b3", "d_w4", "d_b4"]  # discriminator.py:23-41
+
+
+def _ptr(t, off=0):
+    if t is None:
+        return None
+    return t.data_ptr() + off * t.element_size()
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise cabi.LtgError("no HIP device visible: the Long-Tail-GAN path has no CPU fallback")
+    return torch.device(device)
+
+
+class Acts:
+    """Caller-owned activations of one generator forward (ltg_gen_acts)."""
+
+    def __init__(self, rows, n_items, H, Z, device):
+        f = dict(dtype=torch.float32, device=device)
+        self.rows = rows
+        self.h1 = torch.empty(rows, H, **f)
+        self.mulv = torch.empty(rows, 2 * Z, **f)
+        self.z = torch.empty(rows, Z, **f)
+        self.h2 = torch.empty(rows, H, **f)
+        self.logits = torch.empty(rows, n_items, **f)
+        self.lse = torch.empty(rows, **f)
+        self.kl_rows = torch.empty(rows, **f)
+        self.row_scale = torch.empty(rows, **f)
+        self.c = cabi.ltg_gen_acts(_ptr(self.h1), _ptr(self.mulv), _ptr(self.z), _ptr(self.h2), _ptr(self.logits),
+                                   _ptr(self.lse), _ptr(self.kl_rows), _ptr(self.row_scale))
+
+
+class CsrRows:
+    """A range of user rows of a device-resident CSR matrix (ltg_batch), optionally with the CSC
+    view that the G step needs."""
+
+    def __init__(self, indptr, indices, row_lo, row_hi, values=None, colptr=None, rowidx=None, csr_pos=None,
+                 col_off=0, ent_off=0):
+        self.keep = (indptr, indices, values, colptr, rowidx, csr_pos)
+        self.n_rows = int(row_hi - row_lo)
+        self.c = cabi.ltg_batch(self.n_rows, 0, _ptr(indptr, row_lo), _ptr(indices), _ptr(values),
+                                _ptr(colptr, col_off), _ptr(rowidx, ent_off), _ptr(csr_pos, ent_off))
+
+
+class Pairs:
+    def __init__(self, pop, niche, row=None, n=None, off=0):
+        self.keep = (pop, niche, row)
+        self.n = int(pop.numel() - off if n is None else n)
+        self.c = cabi.ltg_pairs(self.n, 0, _ptr(pop, off), _ptr(niche, off), _ptr(row, off))
+
+
+class Engine:
+    def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
+                 precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lib = cabi.load()
+        self.device = _require_gpu(device)
+        torch.cuda.set_device(self.device)
+        p_dims = p_dims or [200, 600, n_items]                       # generator.py:13
+        assert p_dims[-1] == n_items
+        self.I, self.H, self.Z = n_items, p_dims[1], p_dims[0]
+        self.h0, self.h1, self.h2, self.h3 = h_sizes
+        self.feature_len = feature_len or n_items
+        self.precision = {"bf16": cabi.LTG_PREC_BF16, "fp32": cabi.LTG_PREC_FP32}[precision]
+        self.cfg = cabi.ltg_config(n_items, self.H, self.Z, self.feature_len, self.h0, self.h1, self.h2, self.h3,
+                                   self.precision, 0, lr, beta1, beta2, eps, seed)
+        self.lr, self.beta1, self.beta2 = lr, beta1, beta2
+        self.adam_t = 0                                              # shared by D and G (Q5)
+        self._init_generator(seed)
+        self._init_discriminator(d_seed)
+        self._ws = None
+        self._ws_key = (0, 0)
+        self.loss_buf = torch.zeros(8, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_generator(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        I, H, Z = self.I, self.H, self.Z
+
+        def xavier(fi, fo, shape):                                   # MultiVAE.py:199-202
+            lim = math.sqrt(6.0 / (fi + fo))
+            return (torch.rand(shape, generator=g) * 2 - 1) * lim
+
+        def tn(shape, std):                                          # MultiVAE.py:204-207
+            t = torch.empty(shape)
+            torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=g)
+            return t
+
+        host = [xavier(I, H, (I, H)), xavier(H, 2 * Z, (H, 2 * Z)), xavier(Z, H, (Z, H)),
+                xavier(H, I, (I, H)),                                # W_p1 stored item-major [I][H]
+                tn((H,), 1e-3), tn((2 * Z,), 1e-3), tn((H,), 1e-3), tn((I,), 1e-3)]
+        self.set_generator([t.numpy() for t in host])
+
+    def set_generator(self, arrays, m=None, v=None):
+        """arrays in engine layout: [W_q0 [I,H], W_q1 [H,2Z], W_p0 [Z,H], W_p1t [I,H], b_q0, b_q1, b_p0, b_p1]."""
+        dev = self.device
+        self.g_p = [torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev).contiguous() for a in arrays]
+        self.g_m = [torch.zeros_like(t) if m is None else torch.as_tensor(np.ascontiguousarray(m[i]), dtype=torch.float32).to(dev)
+                    for i, t in enumerate(self.g_p)]
+        self.g_v = [torch.zeros_like(t) if v is None else torch.as_tensor(np.ascontiguousarray(v[i]), dtype=torch.float32).to(dev)
+                    for i, t in enumerate(self.g_p)]
+        arr = lambda ts: (cabi.vp * 8)(*[_ptr(t) for t in ts])
+        self.gen_c = cabi.ltg_gen_state(arr(self.g_p), arr(self.g_m), arr(self.g_v))
+
+    def _init_discriminator(self, seed):
+        g = torch.Generator().manual_seed(seed)
+
+        def tn(shape):                                               # discriminator.py:14,23,28,36,40
+            t = torch.empty(shape)
+            torch.nn.init.trunc_normal_(t, 0.0, 0.1, -0.2, 0.2, generator=g)
+            return t
+
+        h0, h1, h2, h3 = self.h0, self.h1, self.h2, self.h3
+        emb = tn((self.feature_len, h0))
+        host = [tn((h0, h1)), torch.zeros(h1), tn((h0, h2)), torch.zeros(h2), tn((h1 + h2, h3)), torch.zeros(h3),
+                tn((h3,)), torch.zeros(1)]
+        self.set_discriminator(emb.numpy(), [t.numpy() for t in host])
+
+    def set_discriminator(self, emb, arrays, m=None, v=None):
+        dev = self.device
+        self.d_emb = torch.as_tensor(np.ascontiguousarray(emb), dtype=torch.float32).to(dev).contiguous()
+        host = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+        host[6] = host[6].reshape(-1)                                # w4 [h3,1] -> [h3]
+        host[7] = host[7].reshape(-1)
+        self.d_p = [torch.from_numpy(a).to(dev).contiguous() for a in host]
+        self.d_m = [torch.zeros_like(t) if m is None else torch.as_tensor(m[i], dtype=torch.float32).reshape(t.shape).to(dev)
+                    for i, t in enumerate(self.d_p)]
+        self.d_v = [torch.zeros_like(t) if v is None else torch.as_tensor(v[i], dtype=torch.float32).reshape(t.shape).to(dev)
+                    for i, t in enumerate(self.d_p)]
+        arr = lambda ts: (cabi.vp * 8)(*[_ptr(t) for t in ts])
+        self.disc_c = cabi.ltg_disc_state(_ptr(self.d_emb), arr(self.d_p), arr(self.d_m), arr(self.d_v))
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def workspace(self, rows, pairs):
+        rows, pairs = max(1, int(rows)), max(1, int(pairs))
+        if self._ws is None or rows > self._ws_key[0] or pairs > self._ws_key[1]:
+            rows = max(rows, self._ws_key[0])
+            pairs = max(pairs, self._ws_key[1])
+            nbytes = self.lib.ltg_workspace_bytes(C.byref(self.cfg), rows, pairs)
+            if nbytes == 0:
+                raise cabi.LtgError("ltg_workspace_bytes rejected the configuration")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_key = (rows, pairs)
+        return self._ws
+
+    def new_acts(self, rows):
+        return Acts(rows, self.I, self.H, self.Z, self.device)
+
+    def next_adam_t(self):
+        self.adam_t += 1
+        return self.adam_t
+
+    # ------------------------------------------------------------------ the five run signatures
+    def forward(self, batch, acts, keep_prob=0.75, is_training=0.0, rng_step=0, probs_out=None, drop_keep=None, eps=None):
+        """sess.run(generator_out, {input_ph: X})  -- train.py:200, :339; test.py:146."""
+        assert acts.rows >= batch.n_rows
+        o = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps))
+        rc = self.lib.ltg_vae_forward(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(o),
+                                      C.byref(acts.c), _ptr(probs_out), None, 0, self.stream())
+        cabi.check(rc, "ltg_vae_forward")
+
+    def sample_pairs(self, samp_c, acts, gen_out, pop_out, cnt_out, out_off=0):
+        """the Python loop train.py:212-251 (+ sample.py:40-67) on the device."""
+        rc = self.lib.ltg_sample_pairs(C.byref(self.cfg), C.byref(samp_c), _ptr(acts.logits), _ptr(acts.lse),
+                                       _ptr(gen_out, out_off), _ptr(pop_out, out_off), _ptr(cnt_out), self.stream())
+        cabi.check(rc, "ltg_sample_pairs")
+
+    def d_step(self, real, fake, keep_prob=0.7, rng_step=0, loss_out=None, drop_real=None, drop_fake=None):
+        """sess.run([d_trainer, d_loss_mean], ...)  -- train.py:300."""
+        loss_out = self.loss_buf if loss_out is None else loss_out
+        ws = self.workspace(1, real.n + fake.n)
+        dr = (cabi.vp * 3)(*[_ptr(t) for t in (drop_real or (None, None, None))])
+        df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
+        o = cabi.ltg_d_opts(keep_prob, self.next_adam_t(), rng_step, dr, df)
+        rc = self.lib.ltg_d_step(C.byref(self.cfg), C.byref(self.disc_c), C.byref(real.c), C.byref(fake.c), C.byref(o),
+                                 _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
+        cabi.check(rc, "ltg_d_step")
+        return loss_out
+
+    def g_step(self, batch, fake, acts, cnt, anneal, gan_lambda=1.0, keep_prob=0.75, is_training=1.0, d_keep_prob=0.7,
+               rng_step=0, d_rng_step=0, loss_out=None, drop_keep=None, eps=None, drop_fake=None):
+        """sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss], ...)  -- train.py:326."""
+        loss_out = self.loss_buf if loss_out is None else loss_out
+        ws = self.workspace(batch.n_rows, fake.n)
+        f = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps))
+        df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
+        o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt))
+        rc = self.lib.ltg_g_step(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c),
+                                 C.byref(fake.c), C.byref(o), C.byref(acts.c), _ptr(loss_out), _ptr(ws), ws.numel(),
+                                 self.stream())
+        cabi.check(rc, "ltg_g_step")
+        return loss_out
+
+    def rank_metrics(self, acts, tr, te, out, k_ndcg=100, k_r1=20, k_r2=50):
+        """pred[X.nonzero()] = -inf + NDCG@100 / Recall@20 / Recall@50  -- train.py:341-346."""
+        rc = self.lib.ltg_rank_metrics(C.byref(self.cfg), _ptr(acts.logits), C.byref(tr.c), C.byref(te.c), k_ndcg, k_r1,
+                                       k_r2, _ptr(out), self.stream())
+        cabi.check(rc, "ltg_rank_metrics")
+
+    # ------------------------------------------------------------------ views in the reference's shapes
+    def generator_params_tf(self):
+        """The 8 tensors in the reference's order and TF shapes (MultiVAE.py:129-141); W_p1 is a
+        transposed view of the item-major storage."""
+        p = self.g_p
+        return [p[0], p[1], p[2], p[3].t(), p[4], p[5], p[6], p[7]]
+
+    def discriminator_params_tf(self):
+        p = self.d_p
+        return [p[0], p[1], p[2], p[3], p[4], p[5], p[6].reshape(-1, 1), p[7]]

