@@ -1,0 +1,218 @@
+"""Index path: the loaders of the reference's Codes/data_processing.py, same names and return
+values, restated with array arithmetic (bit-exact integer / float64 outputs; pinned against the
+reference's own module by tests/test_index_path.py and tests/golden/askubuntu_golden.npz).
+
+These run once on the host before training (train.py:56-113); their outputs are uploaded to HBM
+by ltgan.dataset.  The O(I^2) overlap table is a dense float64 matrix here (the reference builds a
+dict of dicts); large-I datasets need the sparse variant (not built yet).
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+from scipy import sparse
+
+
+def load_train_data(csv_file, n_items):
+    """data_processing.py:6-17 -> (csr float32 [max(uid)+1, n_items], min uid)."""
+    tp = pd.read_csv(csv_file)
+    uid = tp["uid"].to_numpy()
+    sid = tp["sid"].to_numpy()
+    n_users = int(uid.max()) + 1
+    data = sparse.csr_matrix((np.ones(len(uid), dtype=uid.dtype), (uid, sid)), dtype="float32", shape=(n_users, n_items))
+    return data, tp["uid"].min()
+
+
+def load_tr_te_data(csv_file_tr, csv_file_te, n_items):
+    """data_processing.py:20-37 -> (csr float64 tr, csr float64 te, start uid)."""
+    tr = pd.read_csv(csv_file_tr)
+    te = pd.read_csv(csv_file_te)
+    lo = min(tr["uid"].min(), te["uid"].min())
+    hi = max(tr["uid"].max(), te["uid"].max())
+    shape = (hi - lo + 1, n_items)
+
+    def mk(tp):
+        r = tp["uid"].to_numpy() - lo
+        return sparse.csr_matrix((np.ones(len(r), dtype=r.dtype), (r, tp["sid"].to_numpy())), dtype="float64", shape=shape)
+
+    return mk(tr), mk(te), lo
+
+
+def _read_show2id(path):
+    show2id = {}
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f:
+            parts = line.strip().split("\t")
+            show2id[parts[0]] = parts[1]
+    return show2id
+
+
+def load_pop_niche_tags(show2id_path, item_list_path, niche_tags_path, n_items):
+    """data_processing.py:275-340 -> (SHOW2ID, IDs_present, NICHE_TAGS, ALL_TAGS, OTHER_TAGS)."""
+    show2id = _read_show2id(show2id_path)
+    present = set()
+    with open(item_list_path, "r", encoding="utf-8") as f:
+        for line in f:
+            key = line.strip()
+            if key in show2id:
+                present.add(show2id[key])
+    niche = set()
+    with open(niche_tags_path, "r", encoding="utf-8") as f:
+        for line in f:
+            key = line.strip()
+            if key in show2id and show2id[key] in present:
+                niche.add(int(show2id[key]))
+    all_tags = list(range(n_items))
+    other = np.asarray(sorted(set(all_tags) - niche))
+    return show2id, present, niche, all_tags, other
+
+
+def load_item_one_hot_features(item_list_path, SHOW2ID, n_items):
+    """data_processing.py:40-70 -> (dict id -> one-hot list, FEATURE_LEN, array).  Only the dict's key
+    set (the validity filter, Q9) and FEATURE_LEN are live; the array is dead in the reference (Q7) and
+    is returned with the same (mis-aligned) row selection for completeness."""
+    feat = {}
+    flen = 0
+    with open(item_list_path, "r", encoding="utf-8") as f:
+        for line in f:
+            key = line.strip()
+            if key not in SHOW2ID:
+                continue
+            idx = int(SHOW2ID[key])
+            row = [0] * n_items
+            row[idx] = 1
+            feat[idx] = row
+            flen = n_items
+    arr = np.array([feat[i] for i in range(len(feat)) if i in feat])
+    return feat, flen, arr
+
+
+def load_user_items(csv_file_path):
+    """data_processing.py:72-96 -> dict uid -> list of sids in FILE order."""
+    tp = pd.read_csv(csv_file_path)
+    uid = tp.iloc[:, 0].to_numpy()
+    sid = tp.iloc[:, 1].to_numpy()
+    out = {}
+    for u, s in zip(uid.tolist(), sid.tolist()):
+        out.setdefault(u, []).append(s)
+    return out
+
+
+def overlap_matrix(show2id_path, user_tag_matrix_path):
+    """Dense float64 matrix OC[a, b] = |U_a & U_b| / min(|U_a|, |U_b|) (data_processing.py:100-164),
+    NaN for ids that never occur in the user-tag file."""
+    show2id = _read_show2id(show2id_path)
+    tp = pd.read_csv(user_tag_matrix_path)
+    users = tp.iloc[:, 0].astype(str).to_numpy()
+    tags = tp.iloc[:, 1].astype(str).to_numpy()
+    keep = np.array([t in show2id for t in tags])
+    users, tags = users[keep], tags[keep]
+    tid = np.array([int(show2id[t]) for t in tags], dtype=np.int64)
+    _, uidx = np.unique(users, return_inverse=True)
+    n_tags = int(max(int(v) for v in show2id.values())) + 1
+    M = sparse.csr_matrix((np.ones(len(tid), np.int64), (uidx, tid)), shape=(uidx.max() + 1, n_tags))
+    M.data[:] = 1  # a (user, tag) pair counts once: TAG_SETS are sets
+    M.sum_duplicates()
+    M.data[:] = 1
+    inter = np.asarray((M.T @ M).todense(), dtype=np.int64)
+    size = np.asarray(M.sum(axis=0)).reshape(-1).astype(np.int64)
+    denom = np.minimum(size[:, None], size[None, :]).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        oc = (inter * 1.0) / (1.0 * denom)
+    missing = size == 0
+    oc[missing, :] = np.nan
+    oc[:, missing] = np.nan
+    return oc
+
+
+class _OverlapView(dict):
+    """dict-of-dicts facade over the dense matrix: OVERLAP_COEFFS[a][b] like the reference."""
+
+    def __init__(self, oc):
+        super().__init__()
+        self.matrix = oc
+        present = ~np.isnan(np.diag(oc))
+        for a in np.nonzero(present)[0].tolist():
+            self[a] = _Row(oc[a], present)
+
+
+class _Row:
+    def __init__(self, row, present):
+        self.row, self.present = row, present
+
+    def __getitem__(self, b):
+        if not self.present[b]:
+            raise KeyError(b)
+        return float(self.row[b])
+
+    def __len__(self):
+        return int(self.present.sum())
+
+
+def load_overlap_coeff(show2id_path, user_tag_matrix_path):
+    """data_processing.py:110-167 -> OVERLAP_COEFFS[a][b] (float)."""
+    return _OverlapView(overlap_matrix(show2id_path, user_tag_matrix_path))
+
+
+def _matrix(OVERLAP_COEFFS):
+    if isinstance(OVERLAP_COEFFS, _OverlapView):
+        return OVERLAP_COEFFS.matrix
+    n = max(OVERLAP_COEFFS) + 1
+    oc = np.full((n, n), np.nan)
+    for a, row in OVERLAP_COEFFS.items():
+        for b, v in row.items():
+            oc[a, b] = v
+    return oc
+
+
+def load_vectors(user_popular_data, user_niche_data, OVERLAP_COEFFS, ITEM_FEATURE_DICT, N):
+    """data_processing.py:227-271: for each niche item of a user (file order) the popular item of the
+    user with the largest overlap (first maximum wins: strict '>' at :254); pairs touching an id
+    outside ITEM_FEATURE_DICT are dropped (:258-260)."""
+    oc = _matrix(OVERLAP_COEFFS)
+    valid = np.zeros(oc.shape[0], bool)
+    valid[[k for k in ITEM_FEATURE_DICT if 0 <= k < oc.shape[0]]] = True
+    x_niche, x_pop = {}, {}
+    for u in range(N):
+        if u not in user_popular_data or u not in user_niche_data:
+            continue
+        pops = np.asarray(user_popular_data[u])
+        nics = np.asarray(user_niche_data[u])
+        sub = oc[np.ix_(nics, pops)]
+        if np.isnan(sub).any():
+            raise KeyError("overlap coefficient missing for user %d" % u)  # the reference raises KeyError
+        best = pops[np.argmax(sub, axis=1)]  # argmax returns the FIRST maximum
+        ok = valid[nics] & valid[best]
+        x_niche[u] = nics[ok].tolist()
+        x_pop[u] = best[ok].tolist()
+    return x_niche, x_pop
+
+
+def load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP_COEFFS, N):
+    """data_processing.py:170-224: candidate set = the user's niche items + the top
+    max(2n, 10-n) other niche items ranked by their max overlap with any of the user's niche items;
+    ties keep the iteration order of the Python set difference (stable sort, :214) -- reproduced by
+    performing that very set operation; ascending ids."""
+    oc = _matrix(OVERLAP_COEFFS)
+    out = {}
+    niche_set = set(NICHE_TAGS)
+    for u in range(N):
+        if u not in user_popular_data or u not in user_niche_data:
+            continue
+        nics = user_niche_data[u]
+        n = len(nics)
+        want = max(2 * n, 10 - n)
+        cur = set()
+        for t in nics:
+            cur.add(t)
+        others = np.asarray(list(niche_set - cur), dtype=np.int64)  # CPython set-difference order
+        picked = [int(t) for t in nics]
+        if len(others):
+            score = oc[np.ix_(np.asarray(nics), others)].max(axis=0)
+            if np.isnan(score).any():
+                raise KeyError("overlap coefficient missing for user %d" % u)
+            order = np.argsort(-score, kind="stable")[:min(want, len(others))]
+            picked += others[order].tolist()
+        picked.sort()
+        out[u] = np.asarray(picked)
+    return out

@@ -1,0 +1,215 @@
+"""Device-resident training data: runs the index path (ltgan.data_processing == the reference's
+train.py:56-113 set-up) once on the host and lays its outputs out in HBM as flat CSR-style arrays,
+one contiguous slice per batch of BATCH_SIZE users (train.py:192-198: batches are consecutive
+user-id ranges, fixed for the whole run).
+
+Per batch b (users [b*BS, min((b+1)*BS, N))):
+  X rows          indptr/indices               (replaces the dense float32 [B,I] feed)
+  X^T view        colptr[b] / rowidx / csr_pos (sparse gradient of W_q0 in the G step)
+  real pairs      x_popular_n / x_niche        (train.py:223-224; static)
+  sampler inputs  candidates, popular lists, to_sample, output slots (train.py:213-227)
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _cabi as cabi
+from . import data_processing as dp
+from .engine import CsrRows, Pairs, _ptr
+
+DATASET_FILES = ["item2id.txt", "niche_items.txt", "item_counts.csv", "item_list.txt", "unique_item_id.txt",
+                 "train_GAN.csv", "validation_tr.csv", "validation_te.csv", "train_GAN_popular.csv", "train_GAN_niche.csv",
+                 "test_tr.csv", "test_te.csv"]   # train.py:35-38,51,57,77,83-84,91-92; test.py:68-69
+
+
+def materialize_askubuntu(raw_npz, out_dir):
+    """Re-create the Askubuntu_Sample dataset directory from tests/golden/askubuntu_raw.npz (the
+    dataset's files stored as integer arrays)."""
+    r = np.load(raw_npz)
+    os.makedirs(out_dir, exist_ok=True)
+
+    def pairs(name):
+        with open(os.path.join(out_dir, name + ".csv"), "w") as f:
+            f.write("uid,sid\n")
+            np.savetxt(f, np.stack([r[name + "_uid"].astype(np.int64), r[name + "_sid"].astype(np.int64)], 1), fmt="%d", delimiter=",")
+
+    for name in ["train_GAN", "train_GAN_popular", "train_GAN_niche", "validation_tr", "validation_te", "test_tr", "test_te"]:
+        pairs(name)
+    with open(os.path.join(out_dir, "item_counts.csv"), "w") as f:
+        f.write("userId,tagId,rating\n")
+        for u, t, x in zip(r["item_counts_userId"].tolist(), r["item_counts_tagId"].tolist(), r["item_counts_rating"].tolist()):
+            f.write("%d,%d,%s\n" % (u, t, repr(float(x))))
+    with open(os.path.join(out_dir, "item2id.txt"), "w") as f:
+        for a, b in zip(r["item2id_raw"].tolist(), r["item2id_id"].tolist()):
+            f.write("%d\t%d\n" % (a, b))
+    for name in ["item_list", "niche_items", "unique_item_id"]:
+        with open(os.path.join(out_dir, name + ".txt"), "w") as f:
+            for a in r[name].tolist():
+                f.write("%d\n" % a)
+    return out_dir
+
+
+def count_items(pro_dir):
+    """generator.py:6-11 / train.py:56-61: n_items = number of lines of unique_item_id.txt."""
+    with open(os.path.join(pro_dir, "unique_item_id.txt"), "r") as f:
+        return sum(1 for _ in f)
+
+
+class IndexData:
+    """Host-side result of the index path in flat-array form (what gets uploaded)."""
+
+    def __init__(self, n_items, train_csr, uid_start_idx, user_pop, user_niche, x_niche, x_pop_n, cand, valid_ids):
+        self.n_items = n_items
+        self.N = train_csr.shape[0]
+        tr = train_csr.tocsr()
+        tr.sort_indices()
+        self.train = tr
+        self.uid0 = int(uid_start_idx)
+        N = self.N
+        self.valid_item = np.zeros(n_items, np.uint8)
+        self.valid_item[np.asarray(sorted(valid_ids), np.int64)] = 1
+        # user u (row index) <-> key u + uid_start_idx in the dicts (train.py:213)
+        self.user_ok = np.zeros(N, bool)
+        pop_ptr, pop_idx, cand_ptr, cand_idx, real_ptr, real_nic, real_pop = [0], [], [0], [], [0], [], []
+        n_sample = np.zeros(N, np.int32)
+        for r in range(N):
+            u = r + self.uid0
+            ok = u in user_pop and u in user_niche
+            self.user_ok[r] = ok
+            if ok:
+                pop_idx += list(user_pop[u])
+                cand_idx += list(cand[u])
+                real_nic += list(x_niche[u])
+                real_pop += list(x_pop_n[u])
+                n_sample[r] = len(user_niche[u])      # to_sample = len(curr_niche_vectors), train.py:227
+            pop_ptr.append(len(pop_idx))
+            cand_ptr.append(len(cand_idx))
+            real_ptr.append(len(real_nic))
+        i32 = lambda a: np.asarray(a, np.int32)
+        self.pop_ptr, self.pop_idx = i32(pop_ptr), i32(pop_idx)
+        self.cand_ptr, self.cand_idx = i32(cand_ptr), i32(cand_idx)
+        self.real_ptr, self.real_nic, self.real_pop = i32(real_ptr), i32(real_nic), i32(real_pop)
+        self.n_sample = n_sample
+        self.slot_ptr = np.concatenate([[0], np.cumsum(n_sample)]).astype(np.int32)
+
+    @classmethod
+    def from_dir(cls, dataset_dir, verbose=False):
+        """The set-up section of train_GAN (train.py:33-113) with the build's loaders."""
+        d = dataset_dir
+        say = (lambda *a: print(*a, flush=True)) if verbose else (lambda *a: None)
+        n_items = count_items(d)
+        say("Loading Items...")
+        show2id, ids_present, niche, _all, _other = dp.load_pop_niche_tags(os.path.join(d, "item2id.txt"), os.path.join(d, "item_list.txt"),
+                                                                       os.path.join(d, "niche_items.txt"), n_items)
+        fdict, _flen, _ = dp.load_item_one_hot_features(os.path.join(d, "item_list.txt"), show2id, n_items)
+        say("Loading Training Interaction Matrix...")
+        train, uid0 = dp.load_train_data(os.path.join(d, "train_GAN.csv"), n_items)
+        upop = dp.load_user_items(os.path.join(d, "train_GAN_popular.csv"))
+        unic = dp.load_user_items(os.path.join(d, "train_GAN_niche.csv"))
+        say("Loading item overlap coefficients....")
+        oc = dp.load_overlap_coeff(os.path.join(d, "item2id.txt"), os.path.join(d, "item_counts.csv"))
+        N = train.shape[0]
+        xn, xp = dp.load_vectors(upop, unic, oc, fdict, N)
+        say("Loading Items to Sample....")
+        cand = dp.load_items_to_sample(upop, unic, niche, oc, N)
+        return cls(n_items, train, uid0, upop, unic, xn, xp, cand, list(fdict.keys()))
+
+
+def batch_csc(tr, lo, hi, n_items):
+    """CSC view of rows [lo, hi) of a CSR matrix: (colptr [I+1], local row, csr position)."""
+    beg, end = tr.indptr[lo], tr.indptr[hi]
+    idx = tr.indices[beg:end].astype(np.int64)
+    row_of = np.repeat(np.arange(hi - lo), np.diff(tr.indptr[lo:hi + 1]))
+    pos = np.arange(beg, end, dtype=np.int64)
+    order = np.lexsort((row_of, idx))
+    colptr = np.zeros(n_items + 1, np.int64)
+    np.add.at(colptr, idx + 1, 1)
+    return np.cumsum(colptr).astype(np.int32), row_of[order].astype(np.int32), pos[order].astype(np.int32)
+
+
+class DeviceData:
+    """IndexData uploaded to HBM + per-batch views (ctypes structs with the right offsets)."""
+
+    def __init__(self, idx: IndexData, batch_size, device):
+        self.idx, self.BS, self.device = idx, int(batch_size), torch.device(device)
+        N, I = idx.N, idx.n_items
+        self.N, self.I = N, I
+        self.n_batches = (N + self.BS - 1) // self.BS
+        up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a if dt is None else a.astype(dt))).to(self.device)
+        tr = idx.train
+        self.indptr = up(tr.indptr, np.int32)
+        self.indices = up(tr.indices, np.int32)
+        ones = np.all(tr.data == 1.0)
+        self.values = None if ones else up(tr.data, np.float32)
+        colptrs, rowidx, cpos, ent_off = [], [], [], [0]
+        for b in range(self.n_batches):
+            lo, hi = b * self.BS, min(N, (b + 1) * self.BS)
+            cp, ri, ps = batch_csc(tr, lo, hi, I)
+            colptrs.append(cp)
+            rowidx.append(ri)
+            cpos.append(ps)
+            ent_off.append(ent_off[-1] + len(ri))
+        self.colptr = up(np.concatenate(colptrs))
+        self.rowidx = up(np.concatenate(rowidx))
+        self.csr_pos = up(np.concatenate(cpos))
+        self.ent_off = ent_off
+        self.pop_ptr, self.pop_idx = up(idx.pop_ptr), up(idx.pop_idx if len(idx.pop_idx) else np.zeros(1, np.int32))
+        self.cand_ptr, self.cand_idx = up(idx.cand_ptr), up(idx.cand_idx if len(idx.cand_idx) else np.zeros(1, np.int32))
+        self.n_sample, self.slot_ptr = up(idx.n_sample), up(idx.slot_ptr)
+        self.valid_item = up(idx.valid_item)
+        self.real_nic = up(idx.real_nic if len(idx.real_nic) else np.zeros(1, np.int32))
+        self.real_pop = up(idx.real_pop if len(idx.real_pop) else np.zeros(1, np.int32))
+        n_slots = int(idx.slot_ptr[-1])
+        self.n_slots = n_slots
+        # fake pairs of the current global epoch (train.py:192-269 caches them for all sub-epochs, Q6)
+        self.fake_gen = torch.full((max(1, n_slots),), -1, dtype=torch.int32, device=self.device)
+        self.fake_pop = torch.full((max(1, n_slots),), -1, dtype=torch.int32, device=self.device)
+        slot_row = np.repeat(np.arange(N) % self.BS, idx.n_sample).astype(np.int32)   # local row of each slot
+        self.fake_row = up(slot_row if n_slots else np.zeros(1, np.int32))
+        self.fake_cnt = torch.zeros(self.n_batches, dtype=torch.int32, device=self.device)
+        cand_len = np.diff(idx.cand_ptr)
+        self.max_rows = min(self.BS, N)
+        self._views = [self._make_view(b, cand_len) for b in range(self.n_batches)]
+        self.max_pairs = max(v["n_real"] + v["n_slots"] for v in self._views) if self._views else 0
+
+    def _make_view(self, b, cand_len):
+        idx = self.idx
+        lo, hi = b * self.BS, min(self.N, (b + 1) * self.BS)
+        I = self.I
+        batch = CsrRows(self.indptr, self.indices, lo, hi, values=self.values, colptr=self.colptr, rowidx=self.rowidx,
+                        csr_pos=self.csr_pos, col_off=b * (I + 1), ent_off=self.ent_off[b])
+        # csr_pos holds ABSOLUTE positions and rowidx LOCAL rows: both are already relative to the arrays given
+        r0, r1 = int(idx.real_ptr[lo]), int(idx.real_ptr[hi])
+        real = Pairs(self.real_pop, self.real_nic, None, n=r1 - r0, off=r0)
+        s0, s1 = int(idx.slot_ptr[lo]), int(idx.slot_ptr[hi])
+        fake = Pairs(self.fake_pop, self.fake_gen, self.fake_row, n=s1 - s0, off=s0)
+        mc = int(cand_len[lo:hi].max()) if hi > lo else 0
+        samp = cabi.ltg_sample_inputs(hi - lo, max(1, mc), _ptr(self.cand_ptr, lo), _ptr(self.cand_idx), _ptr(self.pop_ptr, lo),
+                                      _ptr(self.pop_idx), _ptr(self.n_sample, lo), _ptr(self.slot_ptr, lo), _ptr(self.valid_item),
+                                      0, None, None)
+        return dict(batch=batch, real=real, fake=fake, samp=samp, n_real=r1 - r0, n_slots=s1 - s0, lo=lo, hi=hi, slot0=s0)
+
+    def view(self, b):
+        return self._views[b]
+
+
+class EvalData:
+    """Fold-in / held-out CSR pair on the device (load_tr_te_data, train.py:83-84, test.py:68-69)."""
+
+    def __init__(self, tr_csr, te_csr, device):
+        dev = torch.device(device)
+        tr = tr_csr.tocsr()
+        te = te_csr.tocsr()
+        tr.sort_indices()
+        te.sort_indices()
+        self.n = tr.shape[0]
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(dev)
+        self.tr_indptr, self.tr_indices = up(tr.indptr), up(tr.indices)
+        self.te_indptr, self.te_indices = up(te.indptr), up(te.indices)
+        self.tr_host, self.te_host = tr, te
+
+    def rows(self, lo, hi):
+        return (CsrRows(self.tr_indptr, self.tr_indices, lo, hi), CsrRows(self.te_indptr, self.te_indices, lo, hi))

@@ -266,7 +266,7 @@ def g_loss_and_grads(P, X, drop_mask, keep, eps, anneal, lam, S_rows, S_cols, cn
     h2q = _q(F["h2"], quant)
     g = {}
     g["Wp1"] = h2q.T @ dlq
-    g["bp1"] = dlog.sum(0)
+    g["bp1"] = dlq.sum(0)   # the HIP path takes it from the ones-augmented column of the same (bf16) GEMM
     dh2 = dlq @ _q(f(P["Wp1"]), quant).T
     da2 = dh2 * (1 - F["h2"] ** 2)
     g["Wp0"] = F["z"].T @ da2
