@@ -1,0 +1,131 @@
+"""The adversarial training loop of the reference (Codes/train.py:180-356) on device-resident data.
+
+One global epoch = three phases (Q6):
+  C  data creation: per batch one generator forward (dropout ON, eps OFF: train.py:200 feeds only
+     input_ph) + fake-pair sampling (train.py:212-251)              -> Trainer.create_phase
+  D  NUM_SUB_EPOCHS passes of discriminator updates over the cached batches (train.py:287-303)
+  G  NUM_SUB_EPOCHS passes of generator updates (train.py:307-329), anneal = min(cap, n/20000)
+then validation (train.py:333-348).  Batches whose sampling produced no valid fake pair are
+skipped for the whole epoch (train.py:254-255); batch order is shuffled once per epoch (:284-285).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from .dataset import DeviceData, EvalData
+from .engine import Engine
+
+
+class Trainer:
+    def __init__(self, engine: Engine, data: DeviceData, num_sub_epochs=10, gan_lambda=1.0, total_anneal_steps=20000,
+                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0):
+        self.eng, self.data = engine, data
+        self.S = int(num_sub_epochs)
+        self.lam = float(gan_lambda)
+        self.total_anneal_steps, self.anneal_cap = total_anneal_steps, anneal_cap
+        self.vae_keep, self.d_keep = vae_keep, d_keep
+        self.update_count = 0.0                      # train.py:178
+        self.rng_step = 0                            # every call gets a fresh RNG counter
+        self.np_rng = np.random.RandomState(shuffle_seed)
+        self.acts = engine.new_acts(data.max_rows)
+        engine.workspace(data.max_rows, data.max_pairs)
+        self.active = list(range(data.n_batches))
+        self.order = np.arange(data.n_batches)
+        dev = engine.device
+        self.d_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
+        self.g_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
+
+    def _step(self):
+        self.rng_step += 1
+        return self.rng_step
+
+    # ---------------------------------------------------------------- phase C (train.py:192-269)
+    def create_phase(self):
+        d, eng = self.data, self.eng
+        d.fake_cnt.zero_()
+        for b in range(d.n_batches):
+            v = d.view(b)
+            st = self._step()
+            eng.forward(v["batch"], self.acts, keep_prob=self.vae_keep, is_training=0.0, rng_step=st)
+            v["samp"].rng_step = st
+            eng.sample_pairs(v["samp"], self.acts, d.fake_gen, d.fake_pop, d.fake_cnt[b:])
+        cnt = d.fake_cnt.cpu().numpy()               # the only host sync of the phase
+        self.active = [b for b in range(d.n_batches) if cnt[b] > 0]      # train.py:254-255
+        self.order = np.arange(len(self.active))
+        self.np_rng.shuffle(self.order)              # train.py:284-285
+        user_err_cnt = int((~d.idx.user_ok).sum())
+        return user_err_cnt
+
+    # ---------------------------------------------------------------- phase D (train.py:287-303)
+    def d_phase(self):
+        d, eng = self.data, self.eng
+        for j in range(self.S):
+            for k in self.order:
+                v = d.view(self.active[k])
+                eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j])
+        return self.d_losses
+
+    # ---------------------------------------------------------------- phase G (train.py:307-329)
+    def anneal(self):
+        if self.total_anneal_steps > 0:
+            return min(self.anneal_cap, 1.0 * self.update_count / self.total_anneal_steps)
+        return self.anneal_cap
+
+    def g_phase(self):
+        d, eng = self.data, self.eng
+        self.last_anneal = []
+        for j in range(self.S):
+            a = self.anneal()
+            for k in self.order:
+                b = self.active[k]
+                v = d.view(b)
+                a = self.anneal()
+                self.update_count += 1
+                eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
+                           keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=self._step(),
+                           d_rng_step=self._step(), loss_out=self.g_losses[j])
+            self.last_anneal.append(a)
+        return self.g_losses
+
+    def epoch(self):
+        """one global epoch's three phases; returns per-phase wall seconds (device-synchronised)."""
+        t = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        err = self.create_phase()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.d_phase()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        self.g_phase()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        return dict(user_err_cnt=err, t_create=t1 - t0, t_d=t2 - t1, t_g=t3 - t2, t_total=t3 - t0)
+
+
+class Evaluator:
+    """Validation / test scoring (train.py:333-348, test.py:138-173): forward with dropout ON (Q3),
+    fold-in items masked to -inf, NDCG@100 / Recall@20 / Recall@50, in chunks of `chunk` users
+    (test.py:76 uses 20000)."""
+
+    def __init__(self, engine: Engine, ev: EvalData, chunk=20000):
+        self.eng, self.ev, self.chunk = engine, ev, int(min(chunk, max(1, ev.n)))
+        self.acts = engine.new_acts(self.chunk)
+        self.out = torch.zeros(ev.n, 4, dtype=torch.float32, device=engine.device)
+
+    def run(self, rng_step=0, keep_prob=0.75):
+        eng, ev = self.eng, self.ev
+        for lo in range(0, ev.n, self.chunk):
+            hi = min(ev.n, lo + self.chunk)
+            tr, te = ev.rows(lo, hi)
+            eng.forward(tr, self.acts, keep_prob=keep_prob, is_training=0.0, rng_step=rng_step + lo)
+            eng.rank_metrics(self.acts, tr, te, self.out[lo:])
+        o = self.out.cpu().numpy().astype(np.float64)
+        ok = o[:, 3] > 0
+        n = int(ok.sum())
+        return dict(ndcg=float(o[ok, 0].mean()) if n else float("nan"), recall20=float(o[ok, 1].mean()) if n else float("nan"),
+                    recall50=float(o[ok, 2].mean()) if n else float("nan"), n_users=n)

@@ -225,3 +225,129 @@ def test_d_step_parity(nr, nf):
         move_got = eng.d_p[i].cpu().numpy().reshape(-1) - np.asarray(D[k], np.float64).reshape(-1)
         move_want = D64[k].reshape(-1) - np.asarray(D[k], np.float64).reshape(-1)
         _check_adam_move(move_got, move_want, ad.m[k].reshape(-1), ad.lr_t(3), ("theta", k))
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler (sample.py:40-67 + train.py:227-251) and ranking metrics (eval_functions.py)
+# ------------------------------------------------------------------------------------------------
+def _sampler_problem(rng, B, I, with_zero_probs):
+    cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample = [0], [], [0], [], []
+    for b in range(B):
+        if b % 7 == 3:                      # invalid user (Q8): no lists, nothing to sample
+            n_sample.append(0)
+        else:
+            n = int(rng.integers(1, 12))
+            nc = n + max(2 * n, 10 - n)
+            cand_idx += np.sort(rng.choice(I, nc, replace=False)).tolist()
+            pop_idx += rng.choice(I, int(rng.integers(1, 9)), replace=False).tolist()
+            n_sample.append(n)
+        cand_ptr.append(len(cand_idx))
+        pop_ptr.append(len(pop_idx))
+    valid = (rng.random(I) > 0.03).astype(np.uint8)
+    return (np.array(cand_ptr, np.int32), np.array(cand_idx, np.int32), np.array(pop_ptr, np.int32), np.array(pop_idx, np.int32),
+            np.array(n_sample, np.int32), valid)
+
+
+@pytest.mark.parametrize("with_zero_probs", [False, True])
+def test_sampler_matches_oracle(with_zero_probs):
+    import ctypes as C
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import _ptr
+    I, B = 1000, 100
+    rng = np.random.default_rng(5 + with_zero_probs)
+    eng = _engine(I, "fp32")
+    cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, valid = _sampler_problem(rng, B, I, with_zero_probs)
+    slot_ptr = np.concatenate([[0], np.cumsum(n_sample)]).astype(np.int32)
+    acts = eng.new_acts(B)
+    logits = rng.normal(0, 2.0, (B, I)).astype(np.float32)
+    if with_zero_probs:                     # push most candidates of some users to softmax underflow
+        for b in range(0, B, 5):
+            c = cand_idx[cand_ptr[b]:cand_ptr[b + 1]]
+            if len(c):
+                logits[b, c[1:]] = -300.0
+    mx = logits.max(1, keepdims=True).astype(np.float64)
+    lse = (mx + np.log(np.exp(logits - mx).sum(1, keepdims=True)))[:, 0]
+    acts.logits.copy_(torch.from_numpy(logits))
+    acts.lse.copy_(torch.from_numpy(lse.astype(np.float32)))
+    dev = eng.device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d = [t(x) for x in (cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, slot_ptr, valid)]
+    step = 77
+    samp = cabi.ltg_sample_inputs(B, int(np.diff(cand_ptr).max()), *[_ptr(x) for x in d], step, None, None)
+    ns = int(slot_ptr[-1])
+    gen = torch.full((ns,), -7, dtype=torch.int32, device=dev)
+    pop = torch.full((ns,), -7, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng.sample_pairs(samp, acts, gen, pop, cnt)
+    torch.cuda.synchronize()
+    gen, pop, cnt = gen.cpu().numpy(), pop.cpu().numpy(), int(cnt.cpu().numpy()[0])
+    lse32 = lse.astype(np.float32)
+    total_ok, flips = 0, 0
+    for b in range(B):
+        s0, s1 = slot_ptr[b], slot_ptr[b + 1]
+        if n_sample[b] == 0:
+            continue
+        c = cand_idx[cand_ptr[b]:cand_ptr[b + 1]]
+        lp = (logits[b, c] - lse32[b]).astype(np.float32)
+        p = np.exp(lp.astype(np.float64))
+        p[np.exp(lp).astype(np.float32) == 0] = 0.0
+        u = O.rng_uniform(SEED, O.STREAM_GUMBEL, step, np.uint64(b) * np.uint64(I) + c.astype(np.uint64))
+        want = O.sample_user(c, p, int(n_sample[b]), u)
+        k_eff = len(want)
+        got_slots = gen[s0:s0 + k_eff]
+        assert np.all(gen[s0 + k_eff:s1] == -1) and np.all(pop[s0 + k_eff:s1] == -1)     # unused slots are holes
+        up = O.rng_uniform(SEED, O.STREAM_POP_PICK, step, np.uint64(b) * np.uint64(I) + want.astype(np.uint64))
+        pl = pop_idx[pop_ptr[b]:pop_ptr[b + 1]]
+        xg, xp, kept = O.build_fake_pairs(want, pl, up.astype(np.float32), valid)
+        exp_gen = np.where(kept, want, -1)
+        if not np.array_equal(got_slots, exp_gen):
+            # a flip is only legal where the k-th and (k+1)-th Gumbel keys are within fp32 rounding
+            key = np.sort(O.gumbel_keys(p, u))[::-1]
+            assert k_eff < len(key) and abs(key[k_eff - 1] - key[k_eff]) < 1e-4, b
+            flips += 1
+            continue
+        exp_pop = np.full(k_eff, -1)
+        exp_pop[np.array(kept, bool)] = xp
+        assert np.array_equal(pop[s0:s0 + k_eff], exp_pop), b
+        total_ok += int(np.sum(kept))
+    assert flips <= 1
+    if flips == 0:
+        assert cnt == total_ok
+
+
+@pytest.mark.parametrize("n,I", [(64, 1000), (33, 257), (5, 4097)])
+def test_rank_metrics_match_oracle(n, I):
+    import torch
+    from ltgan.engine import CsrRows
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n + I)
+    eng = _engine(I, "fp32")
+    pred = rng.random((n, I)).astype(np.float32)
+    for c in range(0, I - 1, 17):
+        pred[:, c] = pred[:, c + 1]                                    # exact ties
+    held = (rng.random((n, I)) < 0.01)
+    held[3] = False                                                    # a user without held-out items is dropped
+    tr = rng.random((n, I)) < 0.05
+    tr[held] = False
+    tr[1, :] = True; tr[1, :40] = False; held[1] = False; held[1, :5] = True   # fewer than 100 finite scores
+    acts = eng.new_acts(n)
+    acts.logits.copy_(torch.from_numpy(pred))
+    dev = eng.device
+    def rows(m):
+        c = sp.csr_matrix(m.astype(np.float32)); c.sort_indices()
+        return CsrRows(torch.from_numpy(c.indptr.astype(np.int32)).to(dev), torch.from_numpy(c.indices.astype(np.int32)).to(dev), 0, n)
+    out = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+    eng.rank_metrics(acts, rows(tr), rows(held), out, 100, 20, 50)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    masked = pred.copy()
+    masked[tr] = -np.inf
+    nd = O.ndcg_binary_at_k(masked, held, 100)
+    r20 = O.recall_at_k(masked, held, 20)
+    r50 = O.recall_at_k(masked, held, 50)
+    ok = out[:, 3] > 0
+    assert ok.sum() == len(nd) and not ok[3]
+    np.testing.assert_allclose(out[ok, 0], nd, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(out[ok, 1], r20, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(out[ok, 2], r50, rtol=2e-6, atol=1e-7)
