@@ -26,24 +26,26 @@ __device__ __forceinline__ unsigned short ltg_f2bf(float x) {
     return (unsigned short)(u >> 16);
 }
 
-template <bool BF16> struct LtgGemmCfg;
-template <> struct LtgGemmCfg<true> {
+template <bool BF16, int BK_> struct LtgGemmCfg;
+template <int BK_> struct LtgGemmCfg<true, BK_> {
     typedef unsigned short T;
-    static constexpr int BK = 32;
-    static constexpr int LDK = 40;  // 80-byte rows: 16-B aligned fragment reads
+    static constexpr int BK = BK_;
+    static constexpr int LDK = BK_ + 8;  // rows stay 16-B aligned for the 16-byte fragment reads
+    static_assert(BK_ % 32 == 0, "bf16 K-step is 32");
 };
-template <> struct LtgGemmCfg<false> {
+template <int BK_> struct LtgGemmCfg<false, BK_> {
     typedef float T;
-    static constexpr int BK = 16;
-    static constexpr int LDK = 17;
+    static constexpr int BK = BK_;
+    static constexpr int LDK = BK_ + 1;  // odd word stride: conflict-free column walks
+    static_assert(BK_ % 4 == 0, "fp32 K-step is 4");
 };
 
 // M, N: logical bounds for the epilogue (loaders must return 0 outside their own bounds).
 // [kbeg, kend): K range of this block (split-K).  A_MCONTIG / B_NCONTIG choose the thread->element
 // map of the global loads so that consecutive threads walk the operand's contiguous dimension.
-template <bool BF16, int BM, int BN, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, class AF, class BF, class EF>
+template <bool BF16, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, class AF, class BF, class EF>
 __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int kbeg, int kend, AF a, BF b, EF epi) {
-    typedef LtgGemmCfg<BF16> Cfg;
+    typedef LtgGemmCfg<BF16, BK_> Cfg;
     typedef typename Cfg::T T;
     constexpr int BK = Cfg::BK, LDK = Cfg::LDK;
     constexpr int NT = 256;
@@ -114,22 +116,25 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);  // next tile's loads fly under the MFMAs
         if constexpr (BF16) {
-            ltg_bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const ltg_u16x8 t = *reinterpret_cast<const ltg_u16x8*>(&As[(wm * WTM + i * 16 + lr) * LDK + 8 * lq]);
-                af[i] = __builtin_bit_cast(ltg_bf16x8, t);
+            for (int ks = 0; ks < BK; ks += 32) {
+                ltg_bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const ltg_u16x8 t = *reinterpret_cast<const ltg_u16x8*>(&As[(wm * WTM + i * 16 + lr) * LDK + ks + 8 * lq]);
+                    af[i] = __builtin_bit_cast(ltg_bf16x8, t);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const ltg_u16x8 t = *reinterpret_cast<const ltg_u16x8*>(&Bs[(wn * WTN + j * 16 + lr) * LDK + ks + 8 * lq]);
+                    bfr[j] = __builtin_bit_cast(ltg_bf16x8, t);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const ltg_u16x8 t = *reinterpret_cast<const ltg_u16x8*>(&Bs[(wn * WTN + j * 16 + lr) * LDK + 8 * lq]);
-                bfr[j] = __builtin_bit_cast(ltg_bf16x8, t);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {

@@ -54,30 +54,44 @@ __device__ __forceinline__ float block_max(float x, float* red) {
 // ---------------------------------------------------------------------------------------------
 
 // enc-0 as a sparse row gather-sum (MultiVAE.py:148-155): h1 = tanh(dropout(l2norm(x)) . W_q0 + b).
-// One workgroup per user row; each thread owns columns c = tid, tid+256, ... of H; the row's
-// (item, value*keep) list is staged through LDS in chunks, W_q0 rows are read coalesced.
-__global__ __launch_bounds__(NT) void k_enc0_fwd(int H, int I, const int32_t* __restrict__ indptr,
-                                                 const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                 const uint8_t* __restrict__ drop_keep, float keep,
-                                                 uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
-                                                 const float* __restrict__ bq0, float* __restrict__ h1,
-                                                 float* __restrict__ row_scale) {
-    __shared__ int s_idx[NT];
-    __shared__ float s_val[NT];
-    __shared__ float red[NT / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// One 512-thread workgroup per user row.  The row's (item, value*keep) list is staged through LDS;
+// the 8 waves split the row's entries (so a 900-item history does not serialise on one wave), each
+// lane owning float4 column chunks of the gathered W_q0 rows (coalesced 16-B loads); the wave
+// partials meet in LDS.
+constexpr int ENC_NT = 512;
+constexpr int ENC_NW = ENC_NT / 64;
+__global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                     const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed,
+                                                     uint64_t step, const float* __restrict__ Wq0,
+                                                     const float* __restrict__ bq0, float* __restrict__ h1,
+                                                     float* __restrict__ row_scale) {
+    extern __shared__ __attribute__((aligned(16))) float s_part[];  // [ENC_NW][H]
+    __shared__ int s_idx[ENC_NT];
+    __shared__ float s_val[ENC_NT];
+    __shared__ float red[ENC_NW];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int beg = indptr[b], end = indptr[b + 1];
     float ss = 0.f;
-    for (int e = beg + tid; e < end; e += NT) {
+    for (int e = beg + tid; e < end; e += ENC_NT) {
         const float v = values ? values[e] : 1.f;
         ss += v * v;
     }
-    ss = block_sum(ss, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) red[w] = ss;
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < ENC_NW; ++i) ss += red[i];
     const float scale = 1.f / (keep * sqrtf(fmaxf(ss, 1e-12f)));  // l2_normalize eps, then /keep
     if (tid == 0) row_scale[b] = scale;
-    constexpr int MAXC = 4;  // supports H <= 1024
-    float acc[MAXC] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = beg; c0 < end; c0 += NT) {
+    const int H4 = H >> 2;
+    constexpr int MAXQ = 4;  // H <= 1024
+    float4 acc[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = beg; c0 < end; c0 += ENC_NT) {
         __syncthreads();
         const int e = c0 + tid;
         if (e < end) {
@@ -89,23 +103,37 @@ __global__ __launch_bounds__(NT) void k_enc0_fwd(int H, int I, const int32_t* __
             s_val[tid] = kp ? v : 0.f;
         }
         __syncthreads();
-        const int cnt = min(NT, end - c0);
-        for (int j = 0; j < cnt; ++j) {
-            const float v = s_val[j];
-            if (v != 0.f) {
-                const float* wr = Wq0 + (size_t)s_idx[j] * H;
+        const int cnt = min(ENC_NT, end - c0);
+        for (int j = w; j < cnt; j += 2 * ENC_NW) {
+            const int j2 = j + ENC_NW;
+            const float v0 = s_val[j];
+            const float v1 = j2 < cnt ? s_val[j2] : 0.f;
+            const float4* w0 = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[j] * H);
+            const float4* w1 = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[j2 < cnt ? j2 : j] * H);
 #pragma unroll
-                for (int q = 0; q < MAXC; ++q) {
-                    const int c = tid + q * NT;
-                    if (c < H) acc[q] += v * wr[c];
+            for (int q = 0; q < MAXQ; ++q) {
+                const int c4 = lane + 64 * q;
+                if (c4 < H4) {
+                    const float4 x0 = w0[c4], x1 = w1[c4];
+                    acc[q].x += v0 * x0.x + v1 * x1.x;
+                    acc[q].y += v0 * x0.y + v1 * x1.y;
+                    acc[q].z += v0 * x0.z + v1 * x1.z;
+                    acc[q].w += v0 * x0.w + v1 * x1.w;
                 }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < MAXC; ++q) {
-        const int c = tid + q * NT;
-        if (c < H) h1[(size_t)b * H + c] = tanhf(acc[q] * scale + bq0[c]);
+    for (int q = 0; q < MAXQ; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < H4) reinterpret_cast<float4*>(s_part + (size_t)w * H)[c4] = acc[q];
+    }
+    __syncthreads();
+    for (int c = tid; c < H; c += ENC_NT) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < ENC_NW; ++i) t += s_part[(size_t)i * H + c];
+        h1[(size_t)b * H + c] = tanhf(t * scale + bq0[c]);
     }
 }
 
@@ -115,14 +143,14 @@ template <int ACT>
 __global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const float* __restrict__ A,
                                                   const float* __restrict__ Bw, const float* __restrict__ bias,
                                                   float* __restrict__ C) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     auto a = [=] __device__(int m, int k) -> float { return m < M ? A[(size_t)m * K + k] : 0.f; };
     auto b = [=] __device__(int k, int n) -> float { return n < N ? Bw[(size_t)k * N + n] : 0.f; };
     auto epi = [=] __device__(int m, int n, float acc) {
         const float x = acc + bias[n];
         C[(size_t)m * N + n] = ACT == 1 ? tanhf(x) : x;
     };
-    ltg_gemm_block<false, 64, 64, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
 }
 
 // Reparameterisation + KL (MultiVAE.py:157-162, :178-181).
@@ -150,11 +178,11 @@ template <bool BF16>
 __global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const float* __restrict__ h2,
                                                  const float* __restrict__ Wp1t, const float* __restrict__ bp1,
                                                  float* __restrict__ logits) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     auto a = [=] __device__(int m, int k) -> float { return m < M ? h2[(size_t)m * H + k] : 0.f; };
     auto b = [=] __device__(int k, int n) -> float { return n < I ? Wp1t[(size_t)n * H + k] : 0.f; };
     auto epi = [=] __device__(int m, int n, float acc) { logits[(size_t)m * I + n] = acc + bp1[n]; };
-    ltg_gemm_block<BF16, 64, 64, 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
+    ltg_gemm_block<BF16, 32, 32, 128, 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
 }
 
 // row log-sum-exp of the logits (log_softmax / softmax, MultiVAE.py:108,143)
@@ -206,7 +234,7 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const bool br = blockIdx.z != 0;
     const int N = br ? h2 : h1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     if (n0 >= N) return;
     const float* W = br ? w2 : w1;
     const float* bias = br ? b2 : b1;
@@ -222,28 +250,31 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
                            : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + (br ? h1 : 0) + nn] = kp ? t / keep : 0.f;
     };
-    ltg_gemm_block<false, 64, 64, 2, 2, false, true>(n, N, m0, n0, 0, h0, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(n, N, m0, n0, 0, h0, a, b, epi);
 }
 
 // fully connected layer (discriminator.py:44, :54)
 __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float* __restrict__ A1,
                                              const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
                                              float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     auto a = [=] __device__(int m, int k) -> float { return m < n ? A1[(size_t)m * h12 + k] : 0.f; };
     auto b = [=] __device__(int k, int nn) -> float { return nn < h3 ? w3[(size_t)k * h3 + nn] : 0.f; };
     auto epi = [=] __device__(int m, int nn, float acc) {
         const float t = tanhf(acc + b3[nn]);
         A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
     };
-    ltg_gemm_block<false, 64, 64, 2, 2, false, true>(n, h3, m0, n0, 0, h12, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(n, h3, m0, n0, 0, h12, a, b, epi);
 }
 
 // output unit + loss terms (discriminator.py:45,55; train.py:142): one wave per pair row.
-// y[r] (0 for holes), ds[r] = d d_loss / d s_r, lrow[r] = loss term.
+// y[r] (0 for holes), ds[r] = d d_loss / d s_r, lrow[r] = loss term, and (WITH_BWD) the gradient at
+// the fc layer's pre-activation dpre3[r][c] = ds * w4[c] * dact(A3[r][c]) for the backward GEMMs.
+template <bool WITH_BWD>
 __global__ __launch_bounds__(NT) void k_d_out(PairView pv, int h3, const float* __restrict__ A3,
-                                              const float* __restrict__ w4, const float* __restrict__ b4,
-                                              float* __restrict__ y, float* __restrict__ ds, float* __restrict__ lrow) {
+                                              const float* __restrict__ w4, const float* __restrict__ b4, float keep,
+                                              float* __restrict__ y, float* __restrict__ ds, float* __restrict__ lrow,
+                                              float* __restrict__ dpre3) {
     const int n = pv.nr + pv.nf;
     const int r = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -252,23 +283,24 @@ __global__ __launch_bounds__(NT) void k_d_out(PairView pv, int h3, const float* 
     for (int c = lane; c < h3; c += 64) s += A3[(size_t)r * h3 + c] * w4[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s += b4[0];
+    const float yy = 1.f / (1.f + expf(-s));
+    const bool ok = pv.valid(r);
+    const bool real = r < pv.nr;
+    const float dsr = ok ? (real ? -(1.f - yy) : yy) : 0.f;
     if (lane == 0) {
-        s += b4[0];
-        const float yy = 1.f / (1.f + expf(-s));
-        const bool ok = pv.valid(r);
-        const bool real = r < pv.nr;
         y[r] = ok ? yy : 0.f;
-        ds[r] = ok ? (real ? -(1.f - yy) : yy) : 0.f;
+        ds[r] = dsr;
         lrow[r] = ok ? (real ? -logf(yy) : -logf(1.f - yy)) : 0.f;
     }
-}
-
-__global__ __launch_bounds__(NT) void k_sum_to(int n, const float* __restrict__ x, float* __restrict__ out) {
-    __shared__ float red[NT / 64];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += NT) s += x[i];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) out[0] = s;
+    if (WITH_BWD) {
+        const float ik = 1.f / keep;
+        for (int c = lane; c < h3; c += 64) {
+            const float a = A3[(size_t)r * h3 + c];
+            const float t = a * keep;
+            dpre3[(size_t)r * h3 + c] = a != 0.f ? dsr * w4[c] * (1.f - t * t) * ik : 0.f;
+        }
+    }
 }
 
 // derivative through dropout(tanh(.)): a = t/keep*mask  =>  d pre = d a * (1 - t^2)/keep where mask=1
@@ -277,79 +309,101 @@ __device__ __forceinline__ float dact(float a, float keep) {
     return a != 0.f ? (1.f - t * t) / keep : 0.f;
 }
 
-// dw4 / db4 + Adam: column reduction over the pair rows; block = 32 columns x 8 row lanes
-__global__ __launch_bounds__(NT) void k_dw4_adam(int n, int h3, const float* __restrict__ A3, const float* __restrict__ ds,
-                                                 float* __restrict__ w4, float* __restrict__ mw4, float* __restrict__ vw4,
-                                                 float* __restrict__ b4, float* __restrict__ mb4, float* __restrict__ vb4,
-                                                 AdamC ad) {
-    __shared__ float part[8][33];
-    const int tn = threadIdx.x & 31, tr = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tn;  // c == h3 is the bias column
-    float acc = 0.f;
-    if (c <= h3)
-        for (int r = tr; r < n; r += 8) acc += (c < h3 ? A3[(size_t)r * h3 + c] : 1.f) * ds[r];
-    part[tr][tn] = acc;
-    __syncthreads();
-    if (tr == 0 && c <= h3) {
-        float g = 0.f;
+// Flat layout of the discriminator's trainable tensors (discriminator.py:47 order) used by the
+// split-K gradient slabs and the single Adam sweep.
+struct DLayout {
+    int off[9];  // off[i] = start of tensor i, off[8] = total
+};
+__host__ __device__ inline DLayout d_layout(int h0, int h1, int h2, int h3) {
+    DLayout L;
+    const int sz[8] = {h0 * h1, h1, h0 * h2, h2, (h1 + h2) * h3, h3, h3, 1};
+    L.off[0] = 0;
+    for (int i = 0; i < 8; ++i) L.off[i + 1] = L.off[i] + sz[i];
+    return L;
+}
+constexpr int D_KCHUNK = 256;  // pair rows per split-K slab
+
+// Backward stage 1, ONE launch, three independent jobs selected by the block index:
+//   job A  dpre1 = (dpre3 . w3^T) * dact(A1)                       [n][h1+h2]     tiles 64x64
+//   job B  slab[z] += A1^T . dpre3 (+ ones row -> db3), split-K     [(h12+1)][h3]  tiles 32x32
+//   job C  slab[z] += A3^T . ds, sum ds (dw4, db4), split-K         column reduce
+__global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, int nB, int ks, DLayout L,
+                                               const float* __restrict__ A1, const float* __restrict__ A3,
+                                               const float* __restrict__ ds, const float* __restrict__ dpre3,
+                                               const float* __restrict__ w3, float keep, float* __restrict__ dpre1,
+                                               float* __restrict__ slab) {
+    int bid = blockIdx.x;
+    if (bid < nA) {
+        const int tn = (h12 + 31) / 32;
+        const int m0 = (bid / tn) * 32, n0 = (bid % tn) * 32;
+        auto a = [=] __device__(int m, int k) -> float { return m < n ? dpre3[(size_t)m * h3 + k] : 0.f; };
+        auto b = [=] __device__(int k, int nn) -> float { return nn < h12 ? w3[(size_t)nn * h3 + k] : 0.f; };
+        auto epi = [=] __device__(int m, int nn, float acc) {
+            dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
+        };
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(n, h12, m0, n0, 0, h3, a, b, epi);
+        return;
+    }
+    bid -= nA;
+    const int P = L.off[8];
+    if (bid < nB) {
+        const int tm = (h12 + 1 + 31) / 32, tn = (h3 + 31) / 32;
+        const int z = bid / (tm * tn), t = bid % (tm * tn);
+        const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+        const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
+        float* out = slab + (size_t)z * P;
+        const int ow = L.off[4], ob = L.off[5];
+        auto a = [=] __device__(int m, int k) -> float { return m < h12 ? A1[(size_t)k * h12 + m] : (m == h12 ? 1.f : 0.f); };
+        auto b = [=] __device__(int k, int nn) -> float { return nn < h3 ? dpre3[(size_t)k * h3 + nn] : 0.f; };
+        auto epi = [=] __device__(int m, int nn, float g) {
+            if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
+            else out[ob + nn] = g;
+        };
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
+        return;
+    }
+    bid -= nB;
+    {
+        __shared__ float part[8][33];
+        const int tc = (h3 + 1 + 31) / 32;
+        const int z = bid / tc;
+        const int tn = threadIdx.x & 31, tr = threadIdx.x >> 5;
+        const int c = (bid % tc) * 32 + tn;  // c == h3 is the bias column
+        const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
+        float acc = 0.f;
+        if (c <= h3) {
+#pragma unroll 8
+            for (int r = kbeg + tr; r < kend; r += 8) acc += (c < h3 ? A3[(size_t)r * h3 + c] : 1.f) * ds[r];
+        }
+        part[tr][tn] = acc;
+        __syncthreads();
+        if (tr == 0 && c <= h3) {
+            float g = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g += part[i][tn];
-        if (c < h3) adam_update(w4, mw4, vw4, c, g, ad);
-        else adam_update(b4, mb4, vb4, 0, g, ad);
+            for (int i = 0; i < 8; ++i) g += part[i][tn];
+            slab[(size_t)z * P + (c < h3 ? L.off[6] + c : L.off[7])] = g;
+        }
     }
 }
 
-// d hin = dpre3 . w3^T, then through the branch activations: dpre1 [n][h1+h2]
-__global__ __launch_bounds__(NT) void k_d_dA1(int n, int h12, int h3, const float* __restrict__ A1,
-                                              const float* __restrict__ A3, const float* __restrict__ ds,
-                                              const float* __restrict__ w4, const float* __restrict__ w3, float keep,
-                                              float* __restrict__ dpre1) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    auto a = [=] __device__(int m, int k) -> float {
-        return m < n ? ds[m] * w4[k] * dact(A3[(size_t)m * h3 + k], keep) : 0.f;
-    };
-    auto b = [=] __device__(int k, int nn) -> float { return nn < h12 ? w3[(size_t)nn * h3 + k] : 0.f; };
-    auto epi = [=] __device__(int m, int nn, float acc) {
-        dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
-    };
-    ltg_gemm_block<false, 64, 64, 2, 2, false, false>(n, h12, m0, n0, 0, h3, a, b, epi);
-}
-
-// dw3 / db3 (ones-augmented row h12) + Adam
-__global__ __launch_bounds__(NT) void k_d_dw3_adam(int n, int h12, int h3, const float* __restrict__ A1,
-                                                   const float* __restrict__ A3, const float* __restrict__ ds,
-                                                   const float* __restrict__ w4, float keep, float* __restrict__ w3,
-                                                   float* __restrict__ mw3, float* __restrict__ vw3, float* __restrict__ b3,
-                                                   float* __restrict__ mb3, float* __restrict__ vb3, AdamC ad) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
-    const int M = h12 + 1;
-    auto a = [=] __device__(int m, int k) -> float { return m < h12 ? A1[(size_t)k * h12 + m] : (m == h12 ? 1.f : 0.f); };
-    auto b = [=] __device__(int k, int nn) -> float {
-        return nn < h3 ? ds[k] * w4[nn] * dact(A3[(size_t)k * h3 + nn], keep) : 0.f;
-    };
-    auto epi = [=] __device__(int m, int nn, float g) {
-        if (m < h12) adam_update(w3, mw3, vw3, (size_t)m * h3 + nn, g, ad);
-        else adam_update(b3, mb3, vb3, nn, g, ad);
-    };
-    ltg_gemm_block<false, 32, 64, 1, 4, true, true>(M, h3, m0, n0, 0, n, a, b, epi);
-}
-
-// dw1/db1 (blockIdx.z=0) and dw2/db2 (blockIdx.z=1) + Adam
-__global__ __launch_bounds__(NT) void k_d_dw12_adam(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
-                                                    const float* __restrict__ dpre1, ltg_disc_state st, AdamC ad) {
+// Backward stage 2: dw1/db1 and dw2/db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), split-K.
+__global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int h2, int ks, DLayout L,
+                                               const float* __restrict__ emb, const float* __restrict__ dpre1,
+                                               float* __restrict__ slab) {
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
-    const bool br = blockIdx.z != 0;
+    const int tm = (h0 + 1 + 31) / 32;
+    const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
+    const int per_z = tm * (tn1 + tn2);
+    const int z = blockIdx.x / per_z, t = blockIdx.x % per_z;
+    const int m0 = (t / (tn1 + tn2)) * 32;
+    const int tcol = t % (tn1 + tn2);
+    const bool br = tcol >= tn1;
+    const int n0 = (br ? tcol - tn1 : tcol) * 32;
     const int N = br ? h2 : h1;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    if (n0 >= N) return;
-    const int M = h0 + 1;
     const int coff = br ? h1 : 0;
-    float* W = st.p[br ? 2 : 0];
-    float* mW = st.m[br ? 2 : 0];
-    float* vW = st.v[br ? 2 : 0];
-    float* Bv = st.p[br ? 3 : 1];
-    float* mB = st.m[br ? 3 : 1];
-    float* vB = st.v[br ? 3 : 1];
+    const int ow = L.off[br ? 2 : 0], ob = L.off[br ? 3 : 1];
+    const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
+    float* out = slab + (size_t)z * L.off[8];
     auto a = [=] __device__(int m, int k) -> float {
         if (m == h0) return 1.f;
         if (m > h0) return 0.f;
@@ -358,10 +412,32 @@ __global__ __launch_bounds__(NT) void k_d_dw12_adam(PairView pv, int h0, int h1,
     };
     auto b = [=] __device__(int k, int nn) -> float { return nn < N ? dpre1[(size_t)k * h12 + coff + nn] : 0.f; };
     auto epi = [=] __device__(int m, int nn, float g) {
-        if (m < h0) adam_update(W, mW, vW, (size_t)m * N + nn, g, ad);
-        else adam_update(Bv, mB, vB, nn, g, ad);
+        if (m < h0) out[ow + (size_t)m * N + nn] = g;
+        else out[ob + nn] = g;
     };
-    ltg_gemm_block<false, 32, 32, 2, 2, false, true>(M, N, m0, n0, 0, n, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
+}
+
+// One Adam sweep over all 8 discriminator tensors (train.py:163): g = sum of the split-K slabs.
+// Block 0 additionally reduces the per-row loss terms into loss_out[0] (d_loss, train.py:142).
+__global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, const float* __restrict__ slab, ltg_disc_state st, AdamC ad,
+                                               int n, const float* __restrict__ lrow, float* __restrict__ loss_out) {
+    __shared__ float red[NT / 64];
+    const int P = L.off[8];
+    for (int e = blockIdx.x * NT + threadIdx.x; e < P; e += gridDim.x * NT) {
+        float g = 0.f;
+        for (int z = 0; z < ks; ++z) g += slab[(size_t)z * P + e];
+        int t = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += e >= L.off[i] ? 1 : 0;
+        adam_update(st.p[t], st.m[t], st.v[t], (size_t)(e - L.off[t]), g, ad);
+    }
+    if (blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += NT) s += lrow[i];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) loss_out[0] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,13 +543,13 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
 template <bool BF16>
 __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kchunk, const float* __restrict__ dlog,
                                                     const float* __restrict__ Wp1t, float* __restrict__ part) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int kbeg = blockIdx.z * kchunk, kend = min(I, kbeg + kchunk);
     float* out = part + (size_t)blockIdx.z * B * H;
     auto a = [=] __device__(int m, int k) -> float { return m < B ? dlog[(size_t)m * I + k] : 0.f; };
     auto b = [=] __device__(int k, int n) -> float { return n < H ? Wp1t[(size_t)k * H + n] : 0.f; };
     auto epi = [=] __device__(int m, int n, float acc) { out[(size_t)m * H + n] = acc; };
-    ltg_gemm_block<BF16, 64, 64, 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
+    ltg_gemm_block<BF16, 32, 32, 128, 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
 }
 
 // da2 = (sum_z part) * (1 - h2^2)
@@ -491,7 +567,7 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
 template <bool BF16>
 __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
                                                       const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
     auto a = [=] __device__(int m, int k) -> float { return (m < I && k < B) ? dlog[(size_t)k * I + m] : 0.f; };
     auto b = [=] __device__(int k, int n) -> float { return k < B ? (n < H ? h2[(size_t)k * H + n] : (n == H ? 1.f : 0.f)) : 0.f; };
@@ -499,14 +575,14 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
         if (n < H) adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
         else adam_update(bb, mb, vb, m, g, ad);
     };
-    ltg_gemm_block<BF16, 64, 64, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+    ltg_gemm_block<BF16, 32, 32, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)
 __global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
                                            const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
                                            float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const float invB = 1.f / (float)B;
     auto a = [=] __device__(int m, int k) -> float { return m < B ? da2[(size_t)m * H + k] : 0.f; };
     auto b = [=] __device__(int k, int n) -> float { return n < Z ? Wp0[(size_t)n * H + k] : 0.f; };
@@ -518,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __r
         dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
         dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
     };
-    ltg_gemm_block<false, 64, 64, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
 }
 
 // generic "weight gradient + Adam": G[m][n] = sum_k L(k,m) * R(k,n) with ones-augmented row m == Min
@@ -527,27 +603,27 @@ __global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const 
                                                    const float* __restrict__ R, float* __restrict__ W, float* __restrict__ mW,
                                                    float* __restrict__ vW, float* __restrict__ bias, float* __restrict__ mb,
                                                    float* __restrict__ vb, AdamC ad) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     auto a = [=] __device__(int m, int k) -> float { return m < Min ? L[(size_t)k * Min + m] : (m == Min ? 1.f : 0.f); };
     auto b = [=] __device__(int k, int n) -> float { return n < N ? R[(size_t)k * N + n] : 0.f; };
     auto epi = [=] __device__(int m, int n, float g) {
         if (m < Min) adam_update(W, mW, vW, (size_t)m * N + n, g, ad);
         else adam_update(bias, mb, vb, n, g, ad);
     };
-    ltg_gemm_block<false, 32, 64, 1, 4, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
 }
 
 // dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)
 __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* __restrict__ dmlv,
                                             const float* __restrict__ Wq1, const float* __restrict__ h1, float* __restrict__ da1) {
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     auto a = [=] __device__(int m, int k) -> float { return m < B ? dmlv[(size_t)m * Z2 + k] : 0.f; };
     auto b = [=] __device__(int k, int n) -> float { return n < H ? Wq1[(size_t)n * Z2 + k] : 0.f; };
     auto epi = [=] __device__(int m, int n, float acc) {
         const float t = h1[(size_t)m * H + n];
         da1[(size_t)m * H + n] = acc * (1.f - t * t);
     };
-    ltg_gemm_block<false, 64, 64, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
+    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
 }
 
 // Dense Adam sweep over W_q0 [I][H] (+ bias row I) with the sparse gradient gathered through the
@@ -614,7 +690,7 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int B, int I, int H, const
 // Sampler: sample_from_generator_new (sample.py:40-67) + pair construction (train.py:227-251).
 // One wave per user.  Successive sampling without replacement == Gumbel-top-k on log p.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sample_pairs(int I, const int32_t* __restrict__ cand_ptr,
+__global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __restrict__ cand_ptr,
                                                      const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ pop_ptr,
                                                      const int32_t* __restrict__ pop_idx, const int32_t* __restrict__ n_sample,
                                                      const int32_t* __restrict__ slot_ptr, const uint8_t* __restrict__ valid_item,
@@ -623,31 +699,32 @@ __global__ __launch_bounds__(64) void k_sample_pairs(int I, const int32_t* __res
                                                      const float* __restrict__ lse, int32_t* __restrict__ gen_out,
                                                      int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out) {
     extern __shared__ __attribute__((aligned(16))) float s_key[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_w[NT / 64];
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ns = n_sample[b];
     const int s0 = slot_ptr[b];
-    if (ns <= 0) return;
+    if (ns <= 0) return;  // uniform for the whole workgroup
     const int c0 = cand_ptr[b], nc = cand_ptr[b + 1] - c0;
     const float l = lse[b];
     const float* row = logits + (size_t)b * I;
-    int nnz = 0;
-    for (int j = lane; j < nc; j += 64) {
+    float nnzf = 0.f;
+    for (int j = tid; j < nc; j += NT) {
         const int it = cand_idx[c0 + j];
         const float lp = row[it] - l;
         const bool pos = expf(lp) > 0.f;  // softmax underflow == "zero probability" of sample.py:45
         float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, (uint64_t)b * (uint64_t)I + it);
         u = fmaxf(u, 2.98023223876953125e-8f);  // 2^-25
         s_key[j] = pos ? lp - logf(-logf(u)) : -INFINITY;
-        nnz += pos ? 1 : 0;
+        nnzf += pos ? 1.f : 0.f;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
-    __syncthreads();
+    const int nnz = (int)block_sum(nnzf, red);  // includes the barrier that publishes s_key
     const int k_eff = min(ns, nnz);  // Q10: exception-driven decrement of to_sample
     const int np = pop_ptr[b + 1] - pop_ptr[b];
-    int written = 0, okcnt = 0;
-    for (int j0 = 0; j0 < nc; j0 += 64) {
-        const int j = j0 + lane;
+    int written = 0;
+    float okf = 0.f;
+    for (int j0 = 0; j0 < nc; j0 += NT) {
+        const int j = j0 + tid;
         bool sel = false;
         if (j < nc) {
             const float kj = s_key[j];
@@ -659,8 +736,17 @@ __global__ __launch_bounds__(64) void k_sample_pairs(int I, const int32_t* __res
             sel = rank < k_eff;
         }
         const unsigned long long bal = __ballot(sel);
+        __syncthreads();
+        if (lane == 0) s_w[w] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) {
+            before += i < w ? s_w[i] : 0;
+            total += s_w[i];
+        }
         if (sel) {
-            const int pos = written + __popcll(bal & ((1ull << lane) - 1ull));
+            const int pos = written + before + __popcll(bal & ((1ull << lane) - 1ull));
             const int s = s0 + pos;
             const int gid = cand_idx[c0 + j];
             const float u = u_pick ? u_pick[s] : ltg_rng_uniform(seed, LTG_STREAM_POP_PICK, step, (uint64_t)b * (uint64_t)I + gid);
@@ -669,17 +755,16 @@ __global__ __launch_bounds__(64) void k_sample_pairs(int I, const int32_t* __res
             const bool ok = valid_item[gid] != 0 && valid_item[pid] != 0;  // train.py:240
             gen_out[s] = ok ? gid : -1;
             pop_out[s] = ok ? pid : -1;
-            okcnt += ok ? 1 : 0;
+            okf += ok ? 1.f : 0.f;
         }
-        written += __popcll(bal);
+        written += total;
     }
-    for (int s = s0 + written + lane; s < s0 + ns; s += 64) {
+    for (int s = s0 + written + tid; s < s0 + ns; s += NT) {
         gen_out[s] = -1;
         pop_out[s] = -1;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) okcnt += __shfl_xor(okcnt, o);
-    if (lane == 0 && okcnt > 0) atomicAdd(cnt_out, okcnt);
+    const int okcnt = (int)block_sum(okf, red);
+    if (tid == 0 && okcnt > 0) atomicAdd(cnt_out, okcnt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,7 +858,7 @@ struct Workspace {
     // generator backward
     float *negll_row, *nb, *Pb, *scal, *dlog, *part, *da2, *dmlv, *da1;
     // discriminator
-    float *A1, *A3, *y, *ds, *lrow, *dpre1;
+    float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     size_t bytes;
 };
 
@@ -804,6 +889,12 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.ds = take(P);
     w.lrow = take(P);
     w.dpre1 = take(P * h12);
+    w.dpre3 = take(P * h3);
+    {
+        const DLayout L = d_layout(cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3);
+        const size_t ks = (P + D_KCHUNK - 1) / D_KCHUNK;
+        w.slab = take(ks * (size_t)L.off[8]);
+    }
     w.bytes = off;
     return w;
 }
@@ -831,16 +922,16 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
                      const ltg_gen_acts* acts, float* probs_out, hipStream_t st) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     if (R <= 0) return LTG_OK;
-    hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(NT), 0, st, H, I, bt->indptr, bt->indices, bt->values, o->drop_keep,
+    hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices, bt->values, o->drop_keep,
                        o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale);
-    hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
+    hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
     hipLaunchKernelGGL(k_reparam, dim3(R), dim3(NT), 0, st, Z, acts->mulv, o->eps, o->is_training, cfg->seed, o->rng_step,
                        acts->z, acts->kl_rows);
-    hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
+    hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
     if (cfg->precision == LTG_PREC_BF16)
-        hipLaunchKernelGGL(k_dec1_fwd<true>, grid2(I, R), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        hipLaunchKernelGGL(k_dec1_fwd<true>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
     else
-        hipLaunchKernelGGL(k_dec1_fwd<false>, grid2(I, R), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        hipLaunchKernelGGL(k_dec1_fwd<false>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
     hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
     if (probs_out) {
         const int gx = (I + NT - 1) / NT < 64 ? (I + NT - 1) / NT : 64;
@@ -851,13 +942,15 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
 
 // forward of one or both towers into ws (A1, A3, y, ds, lrow)
 void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
-                  float keep, uint64_t step, const Workspace& w, hipStream_t st) {
+                  float keep, uint64_t step, const Workspace& w, bool with_bwd, hipStream_t st) {
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    hipLaunchKernelGGL(k_d_l1, grid2(nmax, n, 64, 64, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+    hipLaunchKernelGGL(k_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                        d->p[3], dA, dB, keep, cfg->seed, step, w.A1);
-    hipLaunchKernelGGL(k_d_l2, grid2(h3, n), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3);
-    hipLaunchKernelGGL(k_d_out, dim3((n + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], w.y, w.ds, w.lrow);
+    hipLaunchKernelGGL(k_d_l2, grid2(h3, n, 32, 32), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3);
+    const dim3 go((n + NT / 64 - 1) / (NT / 64));
+    if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
+    else hipLaunchKernelGGL(k_d_out<false>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
 }
 
 }  // namespace
@@ -892,7 +985,7 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
     const int max_cand = in->max_cand > 0 ? in->max_cand : 1;
     const size_t lds = (size_t)max_cand * sizeof(float);
     if (lds > 64 * 1024) return LTG_EINVAL;
-    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(64), lds, st, cfg->n_items, in->cand_ptr, in->cand_idx, in->pop_ptr,
+    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(NT), lds, st, cfg->n_items, in->cand_ptr, in->cand_idx, in->pop_ptr,
                        in->pop_idx, in->n_sample, in->slot_ptr, in->valid_item, in->u_gumbel, in->u_pick, cfg->seed, in->rng_step,
                        logits, lse, gen_out, pop_out, cnt_out);
     return check_launch();
@@ -911,17 +1004,21 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     PairView pv{real->n, fake->n, real->pop, real->niche, fake->pop, fake->niche};
     DropView dA{o->drop_real[0], o->drop_fake[0], real->n}, dB{o->drop_real[1], o->drop_fake[1], real->n},
         dC{o->drop_real[2], o->drop_fake[2], real->n};
-    disc_forward(cfg, disc, pv, dA, dB, dC, o->keep_prob, o->rng_step, w, st);
-    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(NT), 0, st, n, w.lrow, loss_out);
+    disc_forward(cfg, disc, pv, dA, dB, dC, o->keep_prob, o->rng_step, w, true, st);
     const AdamC ad = make_adam(cfg, o->adam_t);
-    // order matters: every product with the OLD weights runs before that weight's Adam epilogue
-    hipLaunchKernelGGL(k_d_dA1, grid2(h12, n), dim3(NT), 0, st, n, h12, h3, w.A1, w.A3, w.ds, disc->p[6], disc->p[4], o->keep_prob, w.dpre1);
-    hipLaunchKernelGGL(k_d_dw3_adam, grid2(h3, h12 + 1, 64, 32), dim3(NT), 0, st, n, h12, h3, w.A1, w.A3, w.ds, disc->p[6], o->keep_prob,
-                       disc->p[4], disc->m[4], disc->v[4], disc->p[5], disc->m[5], disc->v[5], ad);
-    hipLaunchKernelGGL(k_dw4_adam, dim3((h3 + 1 + 31) / 32), dim3(NT), 0, st, n, h3, w.A3, w.ds, disc->p[6], disc->m[6], disc->v[6],
-                       disc->p[7], disc->m[7], disc->v[7], ad);
-    const int nmax = h1 > h2 ? h1 : h2;
-    hipLaunchKernelGGL(k_d_dw12_adam, grid2(nmax, h0 + 1, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, disc->emb, w.dpre1, *disc, ad);
+    const DLayout L = d_layout(h0, h1, h2, h3);
+    const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
+    // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
+    const int nA = ((n + 31) / 32) * ((h12 + 31) / 32);
+    const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
+    const int nC = ks * ((h3 + 1 + 31) / 32);
+    hipLaunchKernelGGL(k_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, h12, h3, nA, nB, ks, L, w.A1, w.A3, w.ds, w.dpre3, disc->p[4],
+                       o->keep_prob, w.dpre1, w.slab);
+    const int n2 = ks * ((h0 + 1 + 31) / 32) * ((h1 + 31) / 32 + (h2 + 31) / 32);
+    hipLaunchKernelGGL(k_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab);
+    int ga = (L.off[8] + NT - 1) / NT;
+    if (ga > 1024) ga = 1024;
+    hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, w.slab, *disc, ad, n, w.lrow, loss_out);
     return check_launch();
 }
 
@@ -940,7 +1037,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     if (nf > 0) {
         PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
         DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
-        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, st);
+        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, st);
     }
     hipLaunchKernelGGL(k_g_rowstats, dim3(B), dim3(NT), 0, st, I, bt->indptr, bt->indices, bt->values, acts->logits, acts->lse, nf,
                        fake->row, fake->niche, fake->pop, w.negll_row, w.nb, w.Pb);
@@ -953,21 +1050,21 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     const int kchunk = dh2_kchunk(I);
     const int nsplit = (I + kchunk - 1) / kchunk;
     const bool bf = cfg->precision == LTG_PREC_BF16;
-    if (bf) hipLaunchKernelGGL(k_dh2_partial<true>, grid2(H, B, 64, 64, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
-    else hipLaunchKernelGGL(k_dh2_partial<false>, grid2(H, B, 64, 64, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    if (bf) hipLaunchKernelGGL(k_dh2_partial<true>, grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else hipLaunchKernelGGL(k_dh2_partial<false>, grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, acts->h2, w.da2);
     }
-    if (bf) hipLaunchKernelGGL(k_dec1_bwd_adam<true>, grid2(H + 1, I), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-    else hipLaunchKernelGGL(k_dec1_bwd_adam<false>, grid2(H + 1, I), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-    hipLaunchKernelGGL(k_dz, grid2(Z, B), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
+    if (bf) hipLaunchKernelGGL(k_dec1_bwd_adam<true>, grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    else hipLaunchKernelGGL(k_dec1_bwd_adam<false>, grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
                        o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 64, 32), dim3(NT), 0, st, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, st, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
                        gen->p[6], gen->m[6], gen->v[6], ad);
-    hipLaunchKernelGGL(k_dh1, grid2(H, B), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 64, 32), dim3(NT), 0, st, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
+    hipLaunchKernelGGL(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
                        gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
     {
         const size_t total = (size_t)(I + 1) * (H / 4);
