@@ -54,6 +54,140 @@ def load_workload(name, batch_size, device):
     return idx, DeviceData(idx, batch_size, device), desc
 
 
+PEAK = {"hbm": 8.0e12, "mfma_bf16": 2.5e15, "mfma_fp32": 157.3e12}   # MI355X_MICROARCH.md chip-level parameters
+
+
+class KernelProfiler:
+    """Times individual kernels of the D / G step with HIP events recorded inside the library
+    (ltg_probe) and prices them against the roofline with ALGORITHMIC flops / bytes."""
+
+    D_KERNELS = ["d_l1", "d_l2", "d_bwd1", "d_bwd2", "d_adam"]
+    G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "wgrad_p0", "dh1", "wgrad_q1",
+                 "enc0_bwd_adam"]
+
+    def __init__(self, eng, tr, data, args):
+        from ltgan import _cabi as cabi
+        from ltgan._hip import EventPair
+        self.cabi, self.EventPair = cabi, EventPair
+        self.eng, self.tr, self.data, self.a = eng, tr, data, args
+        self.samples = []        # (event pair, n_pairs, nnz) recorded in the timed region
+
+    def _probe(self, name):
+        ev = self.EventPair()
+        p = self.cabi.ltg_probe(self.cabi.KERNEL_IDS[name], 0, ev.start, ev.stop)
+        return ev, p
+
+    def _shapes(self, b):
+        v = self.data.view(b)
+        nnz = int(self.data.idx.train.indptr[v["hi"]] - self.data.idx.train.indptr[v["lo"]])
+        return dict(B=v["hi"] - v["lo"], n_real=v["n_real"], n_fake=v["n_slots"], nnz=nnz)
+
+    def work(self, name, sh):
+        """algorithmic (flops, bytes) of one launch; DESIGN.md section 'Kernels' has the derivations"""
+        e = self.eng
+        B, I, H, Z = sh["B"], e.I, e.H, e.Z
+        h0, h1, h2, h3 = e.h0, e.h1, e.h2, e.h3
+        h12 = h1 + h2
+        n = sh["n"]
+        P = h0 * h1 + h1 + h0 * h2 + h2 + h12 * h3 + h3 + h3 + 1
+        ks = (n + 255) // 256
+        kchunk = max(256, -(-(-(-I // 64)) // 32) * 32)      # dh2_kchunk() of csrc/ltg_kernels.hip
+        nsplit = -(-I // kchunk)
+        w = {
+            "enc0_fwd": (2 * sh["nnz"] * H, 4 * (sh["nnz"] * H + B * H)),
+            "enc1": (2 * B * H * 2 * Z, 4 * (B * H + H * 2 * Z + B * 2 * Z)),
+            "dec0": (2 * B * Z * H, 4 * (B * Z + Z * H + B * H)),
+            "dec1_fwd": (2 * B * H * I, 4 * (I * H + I + B * H + B * I)),
+            "d_l1": (2 * n * h0 * h12, 4 * (2 * n * h0 + h0 * h12 + n * h12)),
+            "d_l2": (2 * n * h12 * h3, 4 * (n * h12 + h12 * h3 + n * h3)),
+            "d_bwd1": (2 * n * h3 * h12 + 2 * n * (h12 + 1) * h3 + 2 * n * h3,
+                       4 * (n * h3 + h12 * h3 + 2 * n * h12 + n * h3 + ks * (h12 * h3 + 2 * h3 + 1))),
+            "d_bwd2": (2 * n * (h0 + 1) * h12, 4 * (2 * n * h0 + n * h12 + ks * ((h0 + 1) * h12))),
+            "d_adam": (0, P * (4 * ks + 24)),
+            "dh2": (2 * B * I * H, 4 * (B * I + I * H + nsplit * B * H)),
+            "dec1_bwd_adam": (2 * I * (H + 1) * B, 24 * (I * H + I) + 4 * (B * I + B * H)),
+            "dz": (2 * B * H * Z, 4 * (B * H + Z * H + 2 * B * 2 * Z)),
+            "wgrad_p0": (2 * B * (Z + 1) * H, 24 * (Z + 1) * H + 4 * (B * Z + B * H)),
+            "dh1": (2 * B * 2 * Z * H, 4 * (B * 2 * Z + H * 2 * Z + 2 * B * H)),
+            "wgrad_q1": (2 * B * (H + 1) * 2 * Z, 24 * (H + 1) * 2 * Z + 4 * (B * H + B * 2 * Z)),
+            "enc0_bwd_adam": (2 * sh["nnz"] * H, 24 * (I + 1) * H + 4 * B * H),
+        }
+        return w[name]
+
+    def _run_probed(self, name, b, probe):
+        tr, d, eng = self.tr, self.data, self.eng
+        v = d.view(b)
+        if name in self.D_KERNELS:
+            eng.d_step(v["real"], v["fake"], keep_prob=tr.d_keep, rng_step=tr._step(), probe=probe)
+            n = v["n_real"] + v["n_slots"]
+        else:
+            eng.g_step(v["batch"], v["fake"], tr.acts, d.fake_cnt[b:], anneal=tr.anneal(), gan_lambda=tr.lam, rng_step=tr._step(),
+                       d_rng_step=tr._step(), probe=probe)
+            n = v["n_slots"]
+        return n
+
+    def calibrate(self, reps=6):
+        import torch
+        out = {}
+        act = self.tr.active or [0]
+        nb, S = len(act), self.tr.S
+        for name in self.D_KERNELS + self.G_KERNELS:
+            evs = []
+            for r in range(reps):
+                b = act[(7 * r + 3) % nb]
+                ev, p = self._probe(name)
+                n = self._run_probed(name, b, p)
+                sh = self._shapes(b)
+                sh["n"] = n
+                evs.append((ev, sh, p))
+            torch.cuda.synchronize()
+            ms = [e.elapsed_ms() for e, _, _ in evs]
+            ms = [m for m in ms if m is not None]
+            fl = np.mean([self.work(name, sh)[0] for _, sh, _ in evs])
+            by = np.mean([self.work(name, sh)[1] for _, sh, _ in evs])
+            launches = S * nb * (2 if name in ("d_l1", "d_l2") else 1) + (nb if name in ("enc0_fwd", "enc1", "dec0", "dec1_fwd") else 0)
+            out[name] = dict(avg_ms=float(np.mean(ms)), flops=float(fl), bytes=float(by), epoch_ms=float(np.mean(ms)) * launches)
+        return out
+
+    def hook(self, name):
+        """called by the trainer for every D / G step of the timed region; probes every 8th one"""
+        state = {"i": 0}
+
+        def h(kind, b):
+            if (kind == "d") != (name in self.D_KERNELS):
+                return None
+            state["i"] += 1
+            if state["i"] % 8 or len(self.samples) >= 2048:
+                return None
+            ev, p = self._probe(name)
+            sh = self._shapes(b)
+            v = self.data.view(b)
+            sh["n"] = (v["n_real"] + v["n_slots"]) if kind == "d" else v["n_slots"]
+            self.samples.append((ev, sh, p))
+            return p
+        return h
+
+    def roofline(self, name, calib):
+        ms = [e.elapsed_ms() for e, _, _ in self.samples]
+        ms = [m for m in ms if m is not None]
+        if ms:
+            avg = float(np.mean(ms))
+            fl = float(np.mean([self.work(name, sh)[0] for _, sh, _ in self.samples]))
+            by = float(np.mean([self.work(name, sh)[1] for _, sh, _ in self.samples]))
+        else:
+            avg, fl, by = calib[name]["avg_ms"], calib[name]["flops"], calib[name]["bytes"]
+        bf = self.a.precision == "bf16" and name in ("dec1_fwd", "dh2", "dec1_bwd_adam")
+        peak_f = PEAK["mfma_bf16"] if bf else PEAK["mfma_fp32"]
+        t_f, t_b = fl / peak_f, by / PEAK["hbm"]
+        if t_b >= t_f:
+            ach, peak, unit, bound = by / (avg * 1e-3) / 1e9, PEAK["hbm"] / 1e9, "GB/s", "hbm"
+        else:
+            ach, peak, unit, bound = fl / (avg * 1e-3) / 1e12, peak_f / 1e12, "TFLOP/s", "mfma"
+        return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+                "avg_us": avg * 1e3, "launches_timed": len(ms), "algorithmic_flops": fl, "algorithmic_bytes": by,
+                "note": "dominant kernel = largest (avg duration x launches per step) among the probed kernels"}
+
+
 def main():
     a = parse()
     import torch
@@ -82,6 +216,11 @@ def main():
 
     for _ in range(a.warmup):
         tr.epoch()
+    # ---- live per-kernel timing (HIP events recorded by the library around ONE kernel per call)
+    prof = KernelProfiler(eng, tr, data, a)
+    calib = prof.calibrate() if rank == 0 else None
+    dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
+    tr.probe_hook = prof.hook(dominant) if dominant else None
     barrier()
     t0 = time.perf_counter()
     phases = []
@@ -89,6 +228,7 @@ def main():
         phases.append(tr.epoch())
     barrier()
     dt = time.perf_counter() - t0
+    tr.probe_hook = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -105,6 +245,11 @@ def main():
         "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
     }
     if rank == 0:
+        res["roofline"] = prof.roofline(dominant, calib)
+        res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
+        if not a.no_cpu_baseline:
+            from oracle.cpu_port import time_cpu_baseline   # oracle/ is only ever the baseline / checker
+            res["cpu_baseline"] = time_cpu_baseline(idx, budget_s=a.cpu_seconds, S=a.sub_epochs, batch_size=a.batch_size)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

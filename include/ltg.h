@@ -102,12 +102,39 @@ typedef struct ltg_gen_acts {
     float* row_scale; /* [n_rows]    1/(keep*||x||_2) */
 } ltg_gen_acts;
 
+/* Optional timing probe: the library records the two HIP events (hipEvent_t) around the launch of the
+ * kernel `kernel_id` on the call's stream.  Measurement only; NULL = off. */
+#define LTG_K_ENC0_FWD 1
+#define LTG_K_ENC1 2
+#define LTG_K_DEC0 3
+#define LTG_K_DEC1_FWD 4
+#define LTG_K_D_L1 5
+#define LTG_K_D_L2 6
+#define LTG_K_D_BWD1 7
+#define LTG_K_D_BWD2 8
+#define LTG_K_D_ADAM 9
+#define LTG_K_DH2 10
+#define LTG_K_DEC1_BWD_ADAM 11
+#define LTG_K_ENC0_BWD_ADAM 12
+#define LTG_K_DZ 13
+#define LTG_K_DH1 14
+#define LTG_K_WGRAD_P0 15
+#define LTG_K_WGRAD_Q1 16
+#define LTG_K_COUNT 17
+typedef struct ltg_probe {
+    int32_t kernel_id;
+    int32_t reserved0;
+    void* ev_start;
+    void* ev_stop;
+} ltg_probe;
+
 typedef struct ltg_fwd_opts {
     float keep_prob;   /* keep_prob_ph, default 0.75 (MultiVAE.py:31) -- ON at inference too (Q3) */
     float is_training; /* is_training_ph (MultiVAE.py:101) */
     uint64_t rng_step; /* counter for the on-device RNG */
     const uint8_t* drop_keep; /* optional keep flags, indexed like indices[] (drop_keep[e] belongs to indices[e]) */
     const float* eps;         /* optional [n_rows][Z] */
+    const ltg_probe* probe;   /* optional */
 } ltg_fwd_opts;
 
 /* Fake/real (popular, niche) id pairs.  Rows with id < 0 are holes (dropped pairs, Q9/Q10). */
@@ -125,6 +152,7 @@ typedef struct ltg_d_opts {
     uint64_t rng_step;
     const uint8_t* drop_real[3]; /* optional keep flags [n_real][h1], [n_real][h2], [n_real][h3] */
     const uint8_t* drop_fake[3];
+    const ltg_probe* probe; /* optional */
 } ltg_d_opts;
 
 typedef struct ltg_g_opts {
@@ -136,6 +164,7 @@ typedef struct ltg_g_opts {
     uint64_t d_rng_step;
     const uint8_t* drop_fake[3]; /* optional */
     const int32_t* cnt;  /* device scalar: sampled_cnt (number of valid fake pairs) */
+    const ltg_probe* probe; /* optional (the forward part uses fwd.probe) */
 } ltg_g_opts;
 
 /* Static per-user sampling inputs for a batch (results of the index path, data_processing.py). */

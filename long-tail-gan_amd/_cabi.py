@@ -46,9 +46,17 @@ class ltg_gen_acts(C.Structure):
                 ("row_scale", vp)]
 
 
+class ltg_probe(C.Structure):
+    _fields_ = [("kernel_id", C.c_int32), ("reserved0", C.c_int32), ("ev_start", vp), ("ev_stop", vp)]
+
+
+KERNEL_IDS = {"enc0_fwd": 1, "enc1": 2, "dec0": 3, "dec1_fwd": 4, "d_l1": 5, "d_l2": 6, "d_bwd1": 7, "d_bwd2": 8, "d_adam": 9,
+              "dh2": 10, "dec1_bwd_adam": 11, "enc0_bwd_adam": 12, "dz": 13, "dh1": 14, "wgrad_p0": 15, "wgrad_q1": 16}
+
+
 class ltg_fwd_opts(C.Structure):
     _fields_ = [("keep_prob", C.c_float), ("is_training", C.c_float), ("rng_step", C.c_uint64), ("drop_keep", vp),
-                ("eps", vp)]
+                ("eps", vp), ("probe", C.POINTER(ltg_probe))]
 
 
 class ltg_pairs(C.Structure):
@@ -57,12 +65,12 @@ class ltg_pairs(C.Structure):
 
 class ltg_d_opts(C.Structure):
     _fields_ = [("keep_prob", C.c_float), ("adam_t", C.c_int32), ("rng_step", C.c_uint64), ("drop_real", vp * 3),
-                ("drop_fake", vp * 3)]
+                ("drop_fake", vp * 3), ("probe", C.POINTER(ltg_probe))]
 
 
 class ltg_g_opts(C.Structure):
     _fields_ = [("fwd", ltg_fwd_opts), ("anneal", C.c_float), ("gan_lambda", C.c_float), ("d_keep_prob", C.c_float),
-                ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp)]
+                ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp), ("probe", C.POINTER(ltg_probe))]
 
 
 class ltg_sample_inputs(C.Structure):

@@ -909,6 +909,23 @@ inline AdamC make_adam(const ltg_config* cfg, int t) {
     return a;
 }
 
+struct Probe {
+    const ltg_probe* p;
+    hipStream_t st;
+    inline void before(int id) const {
+        if (p && p->kernel_id == id && p->ev_start) (void)hipEventRecord((hipEvent_t)p->ev_start, st);
+    }
+    inline void after(int id) const {
+        if (p && p->kernel_id == id && p->ev_stop) (void)hipEventRecord((hipEvent_t)p->ev_stop, st);
+    }
+};
+#define LTG_PROBED(pr, id, stmt) \
+    do {                         \
+        (pr).before(id);         \
+        stmt;                    \
+        (pr).after(id);          \
+    } while (0)
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LTG_OK : LTG_ELAUNCH; }
 
 inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return dim3((N + bn - 1) / bn, (M + bm - 1) / bm, z); }
@@ -922,16 +939,17 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
                      const ltg_gen_acts* acts, float* probs_out, hipStream_t st) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     if (R <= 0) return LTG_OK;
-    hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices, bt->values, o->drop_keep,
-                       o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale);
-    hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
+    const Probe pr{o->probe, st};
+    LTG_PROBED(pr, LTG_K_ENC0_FWD, hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices, bt->values, o->drop_keep,
+                       o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale));
+    LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv));
     hipLaunchKernelGGL(k_reparam, dim3(R), dim3(NT), 0, st, Z, acts->mulv, o->eps, o->is_training, cfg->seed, o->rng_step,
                        acts->z, acts->kl_rows);
-    hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
+    LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2));
     if (cfg->precision == LTG_PREC_BF16)
-        hipLaunchKernelGGL(k_dec1_fwd<true>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        LTG_PROBED(pr, LTG_K_DEC1_FWD, hipLaunchKernelGGL(k_dec1_fwd<true>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits));
     else
-        hipLaunchKernelGGL(k_dec1_fwd<false>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        LTG_PROBED(pr, LTG_K_DEC1_FWD, hipLaunchKernelGGL(k_dec1_fwd<false>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits));
     hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
     if (probs_out) {
         const int gx = (I + NT - 1) / NT < 64 ? (I + NT - 1) / NT : 64;
@@ -942,12 +960,13 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
 
 // forward of one or both towers into ws (A1, A3, y, ds, lrow)
 void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
-                  float keep, uint64_t step, const Workspace& w, bool with_bwd, hipStream_t st) {
+                  float keep, uint64_t step, const Workspace& w, bool with_bwd, const ltg_probe* probe, hipStream_t st) {
+    const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    hipLaunchKernelGGL(k_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
-                       d->p[3], dA, dB, keep, cfg->seed, step, w.A1);
-    hipLaunchKernelGGL(k_d_l2, grid2(h3, n, 32, 32), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3);
+    LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(k_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+                       d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
+    LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(k_d_l2, grid2(h3, n, 32, 32), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
     const dim3 go((n + NT / 64 - 1) / (NT / 64));
     if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
     else hipLaunchKernelGGL(k_d_out<false>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
@@ -1004,7 +1023,8 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     PairView pv{real->n, fake->n, real->pop, real->niche, fake->pop, fake->niche};
     DropView dA{o->drop_real[0], o->drop_fake[0], real->n}, dB{o->drop_real[1], o->drop_fake[1], real->n},
         dC{o->drop_real[2], o->drop_fake[2], real->n};
-    disc_forward(cfg, disc, pv, dA, dB, dC, o->keep_prob, o->rng_step, w, true, st);
+    disc_forward(cfg, disc, pv, dA, dB, dC, o->keep_prob, o->rng_step, w, true, o->probe, st);
+    const Probe pr{o->probe, st};
     const AdamC ad = make_adam(cfg, o->adam_t);
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
@@ -1012,13 +1032,13 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const int nA = ((n + 31) / 32) * ((h12 + 31) / 32);
     const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
     const int nC = ks * ((h3 + 1 + 31) / 32);
-    hipLaunchKernelGGL(k_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, h12, h3, nA, nB, ks, L, w.A1, w.A3, w.ds, w.dpre3, disc->p[4],
-                       o->keep_prob, w.dpre1, w.slab);
+    LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(k_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, h12, h3, nA, nB, ks, L, w.A1, w.A3, w.ds, w.dpre3, disc->p[4],
+                       o->keep_prob, w.dpre1, w.slab));
     const int n2 = ks * ((h0 + 1 + 31) / 32) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-    hipLaunchKernelGGL(k_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab);
+    LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(k_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
     int ga = (L.off[8] + NT - 1) / NT;
     if (ga > 1024) ga = 1024;
-    hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, w.slab, *disc, ad, n, w.lrow, loss_out);
+    LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, w.slab, *disc, ad, n, w.lrow, loss_out));
     return check_launch();
 }
 
@@ -1031,13 +1051,14 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const Workspace w = carve(cfg, B, nf, (char*)ws);
+    const Probe pr{o->probe, st};
     int rc = vae_forward_impl(cfg, gen, bt, &o->fwd, acts, nullptr, st);
     if (rc != LTG_OK) return rc;
     // fake tower forward only (y_data is pruned from the g_trainer fetch, train.py:326)
     if (nf > 0) {
         PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
         DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
-        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, st);
+        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
     }
     hipLaunchKernelGGL(k_g_rowstats, dim3(B), dim3(NT), 0, st, I, bt->indptr, bt->indices, bt->values, acts->logits, acts->lse, nf,
                        fake->row, fake->niche, fake->pop, w.negll_row, w.nb, w.Pb);
@@ -1050,28 +1071,42 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     const int kchunk = dh2_kchunk(I);
     const int nsplit = (I + kchunk - 1) / kchunk;
     const bool bf = cfg->precision == LTG_PREC_BF16;
+    pr.before(LTG_K_DH2);
     if (bf) hipLaunchKernelGGL(k_dh2_partial<true>, grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else hipLaunchKernelGGL(k_dh2_partial<false>, grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    pr.after(LTG_K_DH2);
     {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, acts->h2, w.da2);
     }
+    pr.before(LTG_K_DEC1_BWD_ADAM);
     if (bf) hipLaunchKernelGGL(k_dec1_bwd_adam<true>, grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
     else hipLaunchKernelGGL(k_dec1_bwd_adam<false>, grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    pr.after(LTG_K_DEC1_BWD_ADAM);
+    pr.before(LTG_K_DZ);
     hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
                        o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
+    pr.after(LTG_K_DZ);
+    pr.before(LTG_K_WGRAD_P0);
     hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, st, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
                        gen->p[6], gen->m[6], gen->v[6], ad);
+    pr.after(LTG_K_WGRAD_P0);
+    pr.before(LTG_K_DH1);
     hipLaunchKernelGGL(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
+    pr.after(LTG_K_DH1);
+    pr.before(LTG_K_WGRAD_Q1);
     hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
                        gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
+    pr.after(LTG_K_WGRAD_Q1);
     {
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
         if (gx > 4096) gx = 4096;
+        pr.before(LTG_K_ENC0_BWD_ADAM);
         hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, B, I, H, bt->colptr, bt->rowidx, bt->csr_pos, bt->values,
                            o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, *gen, ad);
+        pr.after(LTG_K_ENC0_BWD_ADAM);
     }
     return check_launch();
 }

@@ -26,6 +26,10 @@ def _ptr(t, off=0):
     return t.data_ptr() + off * t.element_size()
 
 
+def _pp(probe):
+    return C.pointer(probe) if probe is not None else None
+
+
 def _require_gpu(device):
     if not torch.cuda.is_available():
         raise cabi.LtgError("no HIP device visible: the Long-Tail-GAN path has no CPU fallback")
@@ -173,10 +177,11 @@ class Engine:
         return self.adam_t
 
     # ------------------------------------------------------------------ the five run signatures
-    def forward(self, batch, acts, keep_prob=0.75, is_training=0.0, rng_step=0, probs_out=None, drop_keep=None, eps=None):
+    def forward(self, batch, acts, keep_prob=0.75, is_training=0.0, rng_step=0, probs_out=None, drop_keep=None, eps=None,
+                probe=None):
         """sess.run(generator_out, {input_ph: X})  -- train.py:200, :339; test.py:146."""
         assert acts.rows >= batch.n_rows
-        o = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps))
+        o = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
         rc = self.lib.ltg_vae_forward(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(o),
                                       C.byref(acts.c), _ptr(probs_out), None, 0, self.stream())
         cabi.check(rc, "ltg_vae_forward")
@@ -187,26 +192,26 @@ class Engine:
                                        _ptr(gen_out, out_off), _ptr(pop_out, out_off), _ptr(cnt_out), self.stream())
         cabi.check(rc, "ltg_sample_pairs")
 
-    def d_step(self, real, fake, keep_prob=0.7, rng_step=0, loss_out=None, drop_real=None, drop_fake=None):
+    def d_step(self, real, fake, keep_prob=0.7, rng_step=0, loss_out=None, drop_real=None, drop_fake=None, probe=None):
         """sess.run([d_trainer, d_loss_mean], ...)  -- train.py:300."""
         loss_out = self.loss_buf if loss_out is None else loss_out
         ws = self.workspace(1, real.n + fake.n)
         dr = (cabi.vp * 3)(*[_ptr(t) for t in (drop_real or (None, None, None))])
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
-        o = cabi.ltg_d_opts(keep_prob, self.next_adam_t(), rng_step, dr, df)
+        o = cabi.ltg_d_opts(keep_prob, self.next_adam_t(), rng_step, dr, df, _pp(probe))
         rc = self.lib.ltg_d_step(C.byref(self.cfg), C.byref(self.disc_c), C.byref(real.c), C.byref(fake.c), C.byref(o),
                                  _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
         cabi.check(rc, "ltg_d_step")
         return loss_out
 
     def g_step(self, batch, fake, acts, cnt, anneal, gan_lambda=1.0, keep_prob=0.75, is_training=1.0, d_keep_prob=0.7,
-               rng_step=0, d_rng_step=0, loss_out=None, drop_keep=None, eps=None, drop_fake=None):
+               rng_step=0, d_rng_step=0, loss_out=None, drop_keep=None, eps=None, drop_fake=None, probe=None):
         """sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss], ...)  -- train.py:326."""
         loss_out = self.loss_buf if loss_out is None else loss_out
         ws = self.workspace(batch.n_rows, fake.n)
-        f = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps))
+        f = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
-        o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt))
+        o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe))
         rc = self.lib.ltg_g_step(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c),
                                  C.byref(fake.c), C.byref(o), C.byref(acts.c), _ptr(loss_out), _ptr(ws), ws.numel(),
                                  self.stream())

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Training CLI with the reference's surface (Codes/train.py:359-381):
+
+    cd <dir holding config.ini> && python <repo>/long-tail-gan_amd/train.py <dataset_dir>
+
+reads ./config.ini (section [Long-Tail-GAN], keys h0_size h1_size h2_size h3_size NUM_EPOCH BATCH_SIZE
+DISPLAY_ITER LEARNING_RATE to_restore model_name GANLAMBDA; NUM_SUB_EPOCHS = int(NUM_EPOCH/8)), trains
+the VAE-CF generator against the MLP discriminator and prints the reference's progress lines
+(train.py:280,303,329,348).  Checkpoints: chkpt/<dataset>_<model_name>_<GANLAMBDA>/model_<epoch>.pt
+(own format keyed by the reference's variable names; `to_restore=1` resumes from the latest one --
+the reference parses that key and ignores it, train.py:374).
+"""
+from __future__ import annotations
+
+import configparser
+import glob
+import os
+import sys
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import ltgan  # noqa: F401  (alias of this package directory)
+    from ltgan import data_processing as dp
+    from ltgan.dataset import DeviceData, EvalData, IndexData
+    from ltgan.discriminator import discriminator
+    from ltgan.engine import D_NAMES, G_NAMES
+    from ltgan.generator import generator_VAECF as generator
+    from ltgan.trainer import Evaluator, Trainer
+else:
+    from . import data_processing as dp
+    from .dataset import DeviceData, EvalData, IndexData
+    from .discriminator import discriminator
+    from .engine import D_NAMES, G_NAMES
+    from .generator import generator_VAECF as generator
+    from .trainer import Evaluator, Trainer
+
+
+def save_checkpoint(path, eng, tr, epoch):
+    import torch
+    st = {"epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step, "d_w1": eng.d_emb.cpu()}
+    for i, n in enumerate(G_NAMES):
+        st[n], st[n + "/Adam"], st[n + "/Adam_1"] = eng.g_p[i].cpu(), eng.g_m[i].cpu(), eng.g_v[i].cpu()
+    for i, n in enumerate(D_NAMES):
+        st[n], st[n + "/Adam"], st[n + "/Adam_1"] = eng.d_p[i].cpu(), eng.d_m[i].cpu(), eng.d_v[i].cpu()
+    torch.save(st, path)
+
+
+def load_checkpoint(path, eng, tr):
+    import torch
+    st = torch.load(path, map_location="cpu")
+    eng.set_generator([st[n].numpy() for n in G_NAMES], [st[n + "/Adam"].numpy() for n in G_NAMES],
+                      [st[n + "/Adam_1"].numpy() for n in G_NAMES])
+    eng.set_discriminator(st["d_w1"].numpy(), [st[n].numpy() for n in D_NAMES], [st[n + "/Adam"].numpy() for n in D_NAMES],
+                          [st[n + "/Adam_1"].numpy() for n in D_NAMES])
+    eng.adam_t, tr.update_count, tr.rng_step = st["adam_t"], st["update_count"], st["rng_step"]
+    return st["epoch"]
+
+
+def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BATCH_SIZE, DISPLAY_ITER, LEARNING_RATE, to_restore,
+              model_name, dataset, GANLAMBDA, precision="bf16", device="cuda:0", max_epochs=None):
+    """Codes/train.py:30-356 (same argument list)."""
+    DATA_DIR = dataset + "/"
+    dataset_name = dataset.split("/")[-1].strip() or dataset.split("/")[-2].strip()
+    output_path = "chkpt/" + dataset_name + "_" + model_name + "_" + str(GANLAMBDA) + "/"   # train.py:45 (relative to CWD, Q14)
+    os.makedirs(output_path, exist_ok=True)
+    idx = IndexData.from_dir(DATA_DIR, verbose=True)
+    n_items, N = idx.n_items, idx.N
+    vtr, vte, _ = dp.load_tr_te_data(os.path.join(DATA_DIR, "validation_tr.csv"), os.path.join(DATA_DIR, "validation_te.csv"), n_items)
+    print("Number of Users: ", N)
+    print("Batches Per Epoch: ", (N + BATCH_SIZE - 1) // BATCH_SIZE)
+    gen_net, generator_out, g_vae_loss, g_params, p_dims, total_anneal_steps, anneal_cap = generator(
+        DATA_DIR, h_sizes=(h0_size, h1_size, h2_size, h3_size), lr=LEARNING_RATE, precision=precision, device=device)
+    eng = gen_net.engine
+    discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size, engine=eng)
+    data = DeviceData(idx, BATCH_SIZE, eng.device)
+    tr = Trainer(eng, data, num_sub_epochs=NUM_SUB_EPOCHS, gan_lambda=GANLAMBDA, total_anneal_steps=total_anneal_steps,
+                 anneal_cap=anneal_cap)
+    ev = Evaluator(eng, EvalData(vtr, vte, eng.device))
+    start = 0
+    if to_restore:
+        ck = sorted(glob.glob(os.path.join(output_path, "model_*.pt")), key=lambda p: int(p.split("_")[-1][:-3]))
+        if ck:
+            start = load_checkpoint(ck[-1], eng, tr) + 1
+            print("Restored", ck[-1])
+    last = None
+    for i in range(start, NUM_EPOCH if max_epochs is None else min(NUM_EPOCH, start + max_epochs)):
+        err = tr.create_phase()
+        print("global-epoch:", i, "Data Creation Finished", "user_err_cnt:", err)
+        dl = tr.d_phase().cpu().numpy()
+        for j in range(NUM_SUB_EPOCHS):
+            print("global-epoch:%s, discr-epoch:%s, d_loss:%.5f" % (i, j, dl[j, 0]))
+        print("")
+        gl = tr.g_phase().cpu().numpy()
+        for j in range(NUM_SUB_EPOCHS):
+            print("global-epoch:%s, generator-epoch:%s, g_loss:%.5f (vae_loss: %.5f + gan_loss: %.5f, anneal: %.5f)" %
+                  (i, j, gl[j, 0], gl[j, 1], gl[j, 2], tr.last_anneal[j]))
+        print("")
+        m = ev.run(rng_step=10 ** 9 + i)
+        print("global-epoch:", i, "gen-epoch:", NUM_SUB_EPOCHS - 1, "Vad: NDCG:", m["ndcg"], "Recall@20:", m["recall20"], "Recall@50:",
+              m["recall50"], "Num_users:", m["n_users"], m["n_users"], m["n_users"])
+        print("")
+        save_checkpoint(os.path.join(output_path, "model_%d.pt" % i), eng, tr, i)
+        print("Model saved at global-epoch", i)
+        last = m
+    return last
+
+
+def read_config(path="config.ini"):
+    cp = configparser.RawConfigParser()
+    if not cp.read(path):
+        raise FileNotFoundError("config.ini not found in the current directory (train.py:360 reads it from CWD)")
+    g = lambda k: cp.get("Long-Tail-GAN", k)
+    NUM_EPOCH = int(g("NUM_EPOCH"))
+    return dict(h0_size=int(g("h0_size")), h1_size=int(g("h1_size")), h2_size=int(g("h2_size")), h3_size=int(g("h3_size")),
+                NUM_EPOCH=NUM_EPOCH, NUM_SUB_EPOCHS=int(NUM_EPOCH / 8), BATCH_SIZE=int(g("BATCH_SIZE")),
+                DISPLAY_ITER=int(g("DISPLAY_ITER")), LEARNING_RATE=float(g("LEARNING_RATE")), to_restore=int(g("to_restore")),
+                model_name=g("model_name"), GANLAMBDA=float(g("GANLAMBDA")))
+
+
+if __name__ == "__main__":
+    cfg = read_config()
+    train_GAN(dataset=sys.argv[1], **cfg)

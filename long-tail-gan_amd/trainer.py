@@ -37,6 +37,7 @@ class Trainer:
         dev = engine.device
         self.d_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
         self.g_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
+        self.probe_hook = None                       # bench.py: (kind, batch) -> ltg_probe or None
 
     def _step(self):
         self.rng_step += 1
@@ -65,7 +66,8 @@ class Trainer:
         for j in range(self.S):
             for k in self.order:
                 v = d.view(self.active[k])
-                eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j])
+                pr = self.probe_hook("d", self.active[k]) if self.probe_hook else None
+                eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j], probe=pr)
         return self.d_losses
 
     # ---------------------------------------------------------------- phase G (train.py:307-329)
@@ -86,7 +88,8 @@ class Trainer:
                 self.update_count += 1
                 eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
                            keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=self._step(),
-                           d_rng_step=self._step(), loss_out=self.g_losses[j])
+                           d_rng_step=self._step(), loss_out=self.g_losses[j],
+                           probe=self.probe_hook("g", b) if self.probe_hook else None)
             self.last_anneal.append(a)
         return self.g_losses
 

@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol
+include/ltg.h declares (no compute without a GPU), struct layouts match, argument validation
+returns error codes instead of crashing, and the product path refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ltg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltg_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from ltgan import _cabi as cabi
+    names = _declared()
+    assert names == sorted(cabi.SYMBOLS), (names, sorted(cabi.SYMBOLS))
+    lib = cabi.load()
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 1
+
+
+def test_struct_layouts_match_header():
+    from ltgan import _cabi as cabi
+    assert C.sizeof(cabi.ltg_config) == 64 and cabi.ltg_config.seed.offset == 56
+    assert C.sizeof(cabi.ltg_gen_state) == 24 * 8 and C.sizeof(cabi.ltg_disc_state) == 25 * 8
+    assert C.sizeof(cabi.ltg_batch) == 8 + 6 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
+    assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8
+    assert C.sizeof(cabi.ltg_pairs) == 8 + 3 * 8
+    assert C.sizeof(cabi.ltg_d_opts) == 8 + 8 + 7 * 8
+    assert C.sizeof(cabi.ltg_g_opts) == C.sizeof(cabi.ltg_fwd_opts) + 16 + 8 + 5 * 8
+    assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 2 * 8
+    assert C.sizeof(cabi.ltg_probe) == 8 + 16
+
+
+def test_argument_validation_returns_codes_without_gpu():
+    from ltgan import _cabi as cabi
+    lib = cabi.load()
+    good = cabi.ltg_config(1000, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
+    assert lib.ltg_workspace_bytes(C.byref(good), 100, 2000) > 0
+    bad = cabi.ltg_config(0, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
+    assert lib.ltg_workspace_bytes(C.byref(bad), 100, 2000) == 0
+    odd = cabi.ltg_config(1000, 602, 200, 1000, 100, 150, 250, 300, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1)   # H % 4 != 0
+    assert lib.ltg_workspace_bytes(C.byref(odd), 100, 2000) == 0
+    # NULL structs -> LTG_EINVAL, before any HIP call
+    assert lib.ltg_vae_forward(C.byref(good), None, None, None, None, None, None, 0, None) == -1
+    assert lib.ltg_d_step(C.byref(good), None, None, None, None, None, None, 0, None) == -1
+    assert lib.ltg_g_step(C.byref(good), None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ltg_sample_pairs(C.byref(good), None, None, None, None, None, None, None) == -1
+    assert lib.ltg_rank_metrics(C.byref(good), None, None, None, 100, 20, 50, None, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ltgan import _cabi as cabi
+    from ltgan.engine import Engine
+    with pytest.raises(cabi.LtgError):
+        Engine(100)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "long-tail-gan_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_wrapper_contract_shapes():
+    """generator.py:4-22 / discriminator.py:3-58 signatures (no device work: handles only)."""
+    from ltgan.generator import MultiVAE, Placeholder
+    vae = MultiVAE([200, 600, 1000])
+    for name, default in (("input_ph", None), ("keep_prob_ph", 0.75), ("is_training_ph", 0.0), ("anneal_ph", 1.0)):
+        ph = getattr(vae, name)
+        assert isinstance(ph, Placeholder) and ph.default == default
+    assert vae.q_dims == [1000, 600, 200] and vae.dims == [1000, 600, 200, 600, 1000]
+    with pytest.raises(NotImplementedError):
+        MultiVAE([200, 600, 1000], lam=0.01)

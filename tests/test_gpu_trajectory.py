@@ -1,0 +1,61 @@
+"""Multi-epoch parity: the device Trainer on Askubuntu_Sample (rebuilt from the committed fixture)
+against the fp64 oracle trajectory tests/golden/oracle_trajectory.npz (oracle/trajectory.py, made
+by tests/golden/make_trajectory.py).  Same initial weights, same counter-RNG streams, same batch
+order.  Bounds: loss triplet 1e-3 relative per sub-epoch, NDCG@100 within 0.002."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ltg_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_two_epoch_trajectory_matches_oracle(tmp_path):
+    import torch
+    import helpers as Hh
+    from ltgan import data_processing as dp
+    from ltgan.dataset import DeviceData, EvalData, IndexData, materialize_askubuntu
+    from ltgan.engine import Engine
+    from ltgan.trainer import Evaluator, Trainer
+    gold = np.load(os.path.join(G, "oracle_trajectory.npz"))
+    d = str(tmp_path / "ds")
+    materialize_askubuntu(os.path.join(G, "askubuntu_raw.npz"), d)
+    idx = IndexData.from_dir(d)
+    hs = tuple(int(x) for x in gold["hs"])
+    eng = Engine(idx.n_items, h_sizes=hs, lr=float(gold["lr"]), precision="bf16", seed=int(gold["seed"]))
+    P = O.init_generator(idx.n_items, seed=int(gold["gen_seed"]))
+    D = O.init_discriminator(idx.n_items, *hs, seed=int(gold["disc_seed"]))
+    eng.set_generator(Hh.gen_to_engine(P))
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    data = DeviceData(idx, 100, eng.device)
+    S = int(gold["S"])
+    tr = Trainer(eng, data, num_sub_epochs=S, shuffle_seed=0)
+    vtr, vte, _ = dp.load_tr_te_data(os.path.join(d, "validation_tr.csv"), os.path.join(d, "validation_te.csv"), idx.n_items)
+    ev = Evaluator(eng, EvalData(vtr, vte, eng.device))
+    for e in range(int(gold["epochs"])):
+        tr.create_phase()
+        cnt = data.fake_cnt.cpu().numpy()
+        want_cnt = gold["e%d_cnt" % e]
+        assert np.abs(cnt - want_cnt).sum() <= 2, (e, np.abs(cnt - want_cnt).sum())      # sampler flips are rare
+        gen = data.fake_gen.cpu().numpy()
+        same = np.array_equal(np.sort(gen[gen >= 0]), np.sort(gold["e%d_fake_gen" % e].astype(np.int64)))
+        assert np.array_equal(tr.order, gold["e%d_order" % e])
+        dl = tr.d_phase().cpu().numpy()[:S, 0]
+        gl = tr.g_phase().cpu().numpy()[:S, :3]
+        tol = 1e-3 if same else 3e-3
+        np.testing.assert_allclose(dl, gold["e%d_d_loss" % e], rtol=tol)
+        want_g = gold["e%d_g_loss" % e]
+        np.testing.assert_allclose(gl[:, 0], want_g[:, 0], rtol=tol)
+        np.testing.assert_allclose(gl[:, 1], want_g[:, 1], rtol=tol)
+        np.testing.assert_allclose(gl[:, 2], want_g[:, 2], rtol=5 * tol, atol=1e-5)     # small-magnitude GAN term
+        assert abs(tr.last_anneal[-1] - want_g[-1, 3]) < 1e-12
+        m = ev.run(rng_step=1000 + e)
+        wm = gold["e%d_metrics" % e]
+        assert abs(m["ndcg"] - wm[0]) < 2e-3 and abs(m["recall20"] - wm[1]) < 2e-3 and abs(m["recall50"] - wm[2]) < 2e-3, (m, wm)
+    np.testing.assert_allclose(eng.g_p[7].cpu().numpy()[:64], gold["final_bp1_head"], atol=2e-5)
+    # 404 Adam steps of lr 1e-4 travel up to 4e-2; fp32-vs-fp64 drift through the sign-like Adam normalisation stays ~1% of that
+    np.testing.assert_allclose(eng.d_p[6].cpu().numpy()[:64], gold["final_w4_head"], atol=5e-4)
