@@ -35,12 +35,14 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--sub-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=100)
+    ap.add_argument("--users", type=int, default=None, help="synthetic workloads: number of user rows to generate (default: a bounded sample)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
-def load_workload(name, batch_size, device):
+def load_workload(name, batch_size, device, users=None):
     from ltgan.dataset import DeviceData, IndexData, materialize_askubuntu
     if name == "askubuntu":
         raw = os.path.join(ROOT, "tests", "golden", "askubuntu_raw.npz")
@@ -50,7 +52,7 @@ def load_workload(name, batch_size, device):
         desc = "Askubuntu_Sample (10001 users x 1000 items, 179368 interactions; dataset files rebuilt from tests/golden/askubuntu_raw.npz)"
     else:
         from ltgan.synthetic import synthetic_index
-        idx, desc = synthetic_index(name)
+        idx, desc = synthetic_index(name, users=users or 6400)   # bounded sample: 64 batches of the named shape
     return idx, DeviceData(idx, batch_size, device), desc
 
 
@@ -204,8 +206,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from ltgan.engine import Engine
     from ltgan.trainer import Trainer
-    idx, data, desc = load_workload(a.workload, a.batch_size, device)
+    idx, data, desc = load_workload(a.workload, a.batch_size, device, a.users)
     eng = Engine(idx.n_items, precision=a.precision, device=device)
+    eng.cfg.reserved0 = a.variant
     tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
 
     def barrier():

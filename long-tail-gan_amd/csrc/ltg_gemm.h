@@ -40,10 +40,10 @@ template <int BK_> struct LtgGemmCfg<false, BK_> {
     static_assert(BK_ % 4 == 0, "fp32 K-step is 4");
 };
 
-// M, N: logical bounds for the epilogue (loaders must return 0 outside their own bounds).
+// M, N: logical bounds of the tile grid (rows of A / columns of B); loaders are only called in range.
 // [kbeg, kend): K range of this block (split-K).  A_MCONTIG / B_NCONTIG choose the thread->element
 // map of the global loads so that consecutive threads walk the operand's contiguous dimension.
-template <bool BF16, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, class AF, class BF, class EF>
+template <bool BF16, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, bool VEC_EPI = false, class AF, class BF, class EF>
 __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int kbeg, int kend, AF a, BF b, EF epi) {
     typedef LtgGemmCfg<BF16, BK_> Cfg;
     typedef typename Cfg::T T;
@@ -56,8 +56,13 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
     constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
     static_assert(BM * BK % NT == 0 && BN * BK % NT == 0, "tile must divide over 256 threads");
 
-    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+    // one LDS block: operand tiles during the K loop, re-used as the fp32 output tile by VEC_EPI
+    constexpr int OPER_BYTES = (BM + BN) * LDK * (int)sizeof(T);
+    constexpr int CS_BYTES = VEC_EPI ? BM * (BN + 4) * 4 : 0;
+    constexpr int SMEM_BYTES = OPER_BYTES > CS_BYTES ? OPER_BYTES : CS_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    T* const As = reinterpret_cast<T*>(smem);
+    T* const Bs = As + BM * LDK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,22 +77,27 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
         for (int j = 0; j < TN; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
 
     float ra[EA], rb[EB];
+    // Loads are UNCONDITIONAL: indices are clamped into [0,M) x [kbeg,kend) (resp. [0,N)) and the value
+    // is zeroed by a select afterwards, so the loaders never branch (a divergent branch per element
+    // costs ~25 instructions and serialises dependent gathers).  Loaders may assume in-range indices.
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < EA; ++j) {
             const int e = tid + NT * j;
             const int mm = A_MCONTIG ? (e % BM) : (e / BK);
             const int kk = A_MCONTIG ? (e / BM) : (e % BK);
-            const int gk = k0 + kk;
-            ra[j] = (gk < kend) ? a(m0 + mm, gk) : 0.f;
+            const int gk = k0 + kk, gm = m0 + mm;
+            const float v = a(min(gm, M - 1), min(gk, kend - 1));
+            ra[j] = (gk < kend && gm < M) ? v : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < EB; ++j) {
             const int e = tid + NT * j;
             const int nn = B_NCONTIG ? (e % BN) : (e / BK);
             const int kk = B_NCONTIG ? (e / BN) : (e % BK);
-            const int gk = k0 + kk;
-            rb[j] = (gk < kend) ? b(gk, n0 + nn) : 0.f;
+            const int gk = k0 + kk, gn = n0 + nn;
+            const float v = b(min(gk, kend - 1), min(gn, N - 1));
+            rb[j] = (gk < kend && gn < N) ? v : 0.f;
         }
     };
     auto stash = [&]() {
@@ -152,14 +162,37 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
         }
     }
 
+    if constexpr (VEC_EPI) {
+        // The accumulator tile takes a round trip through LDS so that the epilogue walks the output
+        // row-major in float4 (16 B per lane, whole 128-B lines per row): epi(m, n, float4) with n % 4 == 0.
+        constexpr int LDC = BN + 4;
+        float* const Cs = reinterpret_cast<float*>(smem);
+        __syncthreads();  // every wave is done reading the operand tiles
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * WTM + i * 16 + lq * 4 + r;
-                const int n = n0 + wn * WTN + j * 16 + lr;
-                if (m < M && n < N) epi(m, n, acc[i][j][r]);
-            }
+                for (int r = 0; r < 4; ++r)
+                    Cs[(wm * WTM + i * 16 + lq * 4 + r) * LDC + wn * WTN + j * 16 + lr] = acc[i][j][r];
+        __syncthreads();
+        constexpr int N4 = BN / 4;
+#pragma unroll
+        for (int e = tid; e < BM * N4; e += NT) {
+            const int mm = e / N4, c4 = e % N4;
+            const int m = m0 + mm, n = n0 + c4 * 4;
+            if (m < M && n < N) epi(m, n, *reinterpret_cast<const float4*>(&Cs[mm * LDC + c4 * 4]));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WTM + i * 16 + lq * 4 + r;
+                    const int n = n0 + wn * WTN + j * 16 + lr;
+                    if (m < M && n < N) epi(m, n, acc[i][j][r]);
+                }
+    }
 }

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const flo
                                                   const float* __restrict__ Bw, const float* __restrict__ bias,
                                                   float* __restrict__ C) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return m < M ? A[(size_t)m * K + k] : 0.f; };
-    auto b = [=] __device__(int k, int n) -> float { return n < N ? Bw[(size_t)k * N + n] : 0.f; };
+    auto a = [=] __device__(int m, int k) -> float { return A[(size_t)m * K + k]; };
+    auto b = [=] __device__(int k, int n) -> float { return Bw[(size_t)k * N + n]; };
     auto epi = [=] __device__(int m, int n, float acc) {
         const float x = acc + bias[n];
         C[(size_t)m * N + n] = ACT == 1 ? tanhf(x) : x;
@@ -174,15 +174,18 @@ __global__ __launch_bounds__(NT) void k_reparam(int Z, const float* __restrict__
 }
 
 // dec-1 (MultiVAE.py:169): logits[b][i] = h2[b][:] . W_p1t[i][:] + b_p1[i]; the big GEMM.
-template <bool BF16>
+template <bool BF16, bool BIG>
 __global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const float* __restrict__ h2,
                                                  const float* __restrict__ Wp1t, const float* __restrict__ bp1,
                                                  float* __restrict__ logits) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return m < M ? h2[(size_t)m * H + k] : 0.f; };
-    auto b = [=] __device__(int k, int n) -> float { return n < I ? Wp1t[(size_t)n * H + k] : 0.f; };
+    // BIG: 128 x 64 tiles (a whole training batch per tile: W_p1t leaves HBM once); small item counts
+    // use 32 x 32 tiles to spread the few tiles over more CUs.
+    constexpr int BM = BIG ? 128 : 32, BN = BIG ? 64 : 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    auto a = [=] __device__(int m, int k) -> float { return h2[(size_t)m * H + k]; };
+    auto b = [=] __device__(int k, int n) -> float { return Wp1t[(size_t)n * H + k]; };
     auto epi = [=] __device__(int m, int n, float acc) { logits[(size_t)m * I + n] = acc + bp1[n]; };
-    ltg_gemm_block<BF16, 32, 32, 128, 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
+    ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
 }
 
 // row log-sum-exp of the logits (log_softmax / softmax, MultiVAE.py:108,143)
@@ -212,8 +215,15 @@ __global__ __launch_bounds__(NT) void k_softmax_write(int I, const float* __rest
 struct PairView {
     int nr, nf;
     const int32_t *r_pop, *r_nic, *f_pop, *f_nic;
-    __device__ __forceinline__ int pop(int r) const { return r < nr ? r_pop[r] : f_pop[r - nr]; }
-    __device__ __forceinline__ int nic(int r) const { return r < nr ? r_nic[r] : f_nic[r - nr]; }
+    // pointer/index selects + ONE unconditional load (no divergent branch around the load)
+    __device__ __forceinline__ int pop(int r) const {
+        const int32_t* p = r < nr ? r_pop : f_pop;
+        return p[r < nr ? r : r - nr];
+    }
+    __device__ __forceinline__ int nic(int r) const {
+        const int32_t* p = r < nr ? r_nic : f_nic;
+        return p[r < nr ? r : r - nr];
+    }
     __device__ __forceinline__ bool valid(int r) const { return pop(r) >= 0 && nic(r) >= 0; }
 };
 struct DropView {
@@ -239,11 +249,11 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
     const float* W = br ? w2 : w1;
     const float* bias = br ? b2 : b1;
     auto a = [=] __device__(int m, int k) -> float {
-        if (m >= n) return 0.f;
         const int id = br ? pv.nic(m) : pv.pop(m);
-        return id >= 0 ? emb[(size_t)id * h0 + k] : 0.f;
+        const float v = emb[(size_t)max(id, 0) * h0 + k];
+        return id >= 0 ? v : 0.f;
     };
-    auto b = [=] __device__(int k, int nn) -> float { return nn < N ? W[(size_t)k * N + nn] : 0.f; };
+    auto b = [=] __device__(int k, int nn) -> float { return W[(size_t)k * N + nn]; };
     auto epi = [=] __device__(int m, int nn, float acc) {
         const float t = tanhf(acc + bias[nn]);
         const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep)
@@ -258,8 +268,8 @@ __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float
                                              const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
                                              float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return m < n ? A1[(size_t)m * h12 + k] : 0.f; };
-    auto b = [=] __device__(int k, int nn) -> float { return nn < h3 ? w3[(size_t)k * h3 + nn] : 0.f; };
+    auto a = [=] __device__(int m, int k) -> float { return A1[(size_t)m * h12 + k]; };
+    auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)k * h3 + nn]; };
     auto epi = [=] __device__(int m, int nn, float acc) {
         const float t = tanhf(acc + b3[nn]);
         A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
@@ -336,8 +346,8 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
     if (bid < nA) {
         const int tn = (h12 + 31) / 32;
         const int m0 = (bid / tn) * 32, n0 = (bid % tn) * 32;
-        auto a = [=] __device__(int m, int k) -> float { return m < n ? dpre3[(size_t)m * h3 + k] : 0.f; };
-        auto b = [=] __device__(int k, int nn) -> float { return nn < h12 ? w3[(size_t)nn * h3 + k] : 0.f; };
+        auto a = [=] __device__(int m, int k) -> float { return dpre3[(size_t)m * h3 + k]; };
+        auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)nn * h3 + k]; };
         auto epi = [=] __device__(int m, int nn, float acc) {
             dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
         };
@@ -353,8 +363,11 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
         const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
         float* out = slab + (size_t)z * P;
         const int ow = L.off[4], ob = L.off[5];
-        auto a = [=] __device__(int m, int k) -> float { return m < h12 ? A1[(size_t)k * h12 + m] : (m == h12 ? 1.f : 0.f); };
-        auto b = [=] __device__(int k, int nn) -> float { return nn < h3 ? dpre3[(size_t)k * h3 + nn] : 0.f; };
+        auto a = [=] __device__(int m, int k) -> float {
+            const float v = A1[(size_t)k * h12 + min(m, h12 - 1)];
+            return m < h12 ? v : 1.f;
+        };
+        auto b = [=] __device__(int k, int nn) -> float { return dpre3[(size_t)k * h3 + nn]; };
         auto epi = [=] __device__(int m, int nn, float g) {
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
@@ -405,12 +418,11 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
     const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
     float* out = slab + (size_t)z * L.off[8];
     auto a = [=] __device__(int m, int k) -> float {
-        if (m == h0) return 1.f;
-        if (m > h0) return 0.f;
         const int id = br ? pv.nic(k) : pv.pop(k);
-        return id >= 0 ? emb[(size_t)id * h0 + m] : 0.f;
+        const float v = emb[(size_t)max(id, 0) * h0 + min(m, h0 - 1)];
+        return m < h0 ? (id >= 0 ? v : 0.f) : 1.f;
     };
-    auto b = [=] __device__(int k, int nn) -> float { return nn < N ? dpre1[(size_t)k * h12 + coff + nn] : 0.f; };
+    auto b = [=] __device__(int k, int nn) -> float { return dpre1[(size_t)k * h12 + coff + nn]; };
     auto epi = [=] __device__(int m, int nn, float g) {
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
@@ -540,16 +552,17 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
 }
 
 // dh2 partials: part[z][b][h] = sum_{i in split z} dlog[b][i] * W_p1t[i][h]   (split-K over items)
-template <bool BF16>
+template <bool BF16, bool BIG>
 __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kchunk, const float* __restrict__ dlog,
                                                     const float* __restrict__ Wp1t, float* __restrict__ part) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    constexpr int BM = BIG ? 128 : 32, BN = BIG ? 64 : 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * kchunk, kend = min(I, kbeg + kchunk);
     float* out = part + (size_t)blockIdx.z * B * H;
-    auto a = [=] __device__(int m, int k) -> float { return m < B ? dlog[(size_t)m * I + k] : 0.f; };
-    auto b = [=] __device__(int k, int n) -> float { return n < H ? Wp1t[(size_t)k * H + n] : 0.f; };
+    auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)m * I + k]; };
+    auto b = [=] __device__(int k, int n) -> float { return Wp1t[(size_t)k * H + n]; };
     auto epi = [=] __device__(int m, int n, float acc) { out[(size_t)m * H + n] = acc; };
-    ltg_gemm_block<BF16, 32, 32, 128, 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
+    ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
 }
 
 // da2 = (sum_z part) * (1 - h2^2)
@@ -564,18 +577,46 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
 }
 
 // dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
-template <bool BF16>
+template <bool BF16, int VAR>
 __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
                                                       const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    // VAR 0: 32x32 tiles, scalar Adam epilogue; 1: 64x128, 2: 64x64, 3: 32x128 tiles with the float4 epilogue
+    constexpr bool BIG = VAR != 0;
+    constexpr int BM = VAR == 0 ? 32 : (VAR == 3 ? 32 : 64), BN = VAR == 0 ? 32 : (VAR == 2 ? 64 : 128);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
-    auto a = [=] __device__(int m, int k) -> float { return (m < I && k < B) ? dlog[(size_t)k * I + m] : 0.f; };
-    auto b = [=] __device__(int k, int n) -> float { return k < B ? (n < H ? h2[(size_t)k * H + n] : (n == H ? 1.f : 0.f)) : 0.f; };
-    auto epi = [=] __device__(int m, int n, float g) {
-        if (n < H) adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
-        else adam_update(bb, mb, vb, m, g, ad);
+    auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)k * I + m]; };
+    auto b = [=] __device__(int k, int n) -> float {
+        const float v = h2[(size_t)k * H + min(n, H - 1)];
+        return n < H ? v : 1.f;
     };
-    ltg_gemm_block<BF16, 32, 32, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+    if constexpr (BIG) {
+        // Adam epilogue in float4 over whole 512-B row segments of W_p1t / m / v (H % 4 == 0)
+        auto epi = [=] __device__(int m, int n, float4 g) {
+            if (n < H) {
+                const size_t o = ((size_t)m * H + n) >> 2;
+                float4 p = reinterpret_cast<float4*>(W)[o], mm = reinterpret_cast<float4*>(mW)[o], vv = reinterpret_cast<float4*>(vW)[o];
+#define LTG_ADAM4(f)                                  \
+    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;        \
+    vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;  \
+    p.f = p.f - ad.lr_t * mm.f / (sqrtf(vv.f) + ad.eps);
+                LTG_ADAM4(x) LTG_ADAM4(y) LTG_ADAM4(z) LTG_ADAM4(w)
+#undef LTG_ADAM4
+                reinterpret_cast<float4*>(W)[o] = p;
+                reinterpret_cast<float4*>(mW)[o] = mm;
+                reinterpret_cast<float4*>(vW)[o] = vv;
+            } else {
+                adam_update(bb, mb, vb, m, g.x, ad);  // n == H: the ones column = bias gradient
+            }
+        };
+        ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+    } else {
+        auto epi = [=] __device__(int m, int n, float g) {
+            if (n < H) adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
+            else adam_update(bb, mb, vb, m, g, ad);
+        };
+        ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+    }
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)
@@ -584,8 +625,8 @@ __global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __r
                                            float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const float invB = 1.f / (float)B;
-    auto a = [=] __device__(int m, int k) -> float { return m < B ? da2[(size_t)m * H + k] : 0.f; };
-    auto b = [=] __device__(int k, int n) -> float { return n < Z ? Wp0[(size_t)n * H + k] : 0.f; };
+    auto a = [=] __device__(int m, int k) -> float { return da2[(size_t)m * H + k]; };
+    auto b = [=] __device__(int k, int n) -> float { return Wp0[(size_t)n * H + k]; };
     auto epi = [=] __device__(int m, int n, float dz) {
         const float mu = mulv[(size_t)m * 2 * Z + n], lv = mulv[(size_t)m * 2 * Z + Z + n];
         float e = 0.f;
@@ -604,8 +645,11 @@ __global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const 
                                                    float* __restrict__ vW, float* __restrict__ bias, float* __restrict__ mb,
                                                    float* __restrict__ vb, AdamC ad) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return m < Min ? L[(size_t)k * Min + m] : (m == Min ? 1.f : 0.f); };
-    auto b = [=] __device__(int k, int n) -> float { return n < N ? R[(size_t)k * N + n] : 0.f; };
+    auto a = [=] __device__(int m, int k) -> float {
+        const float v = L[(size_t)k * Min + min(m, Min - 1)];
+        return m < Min ? v : 1.f;
+    };
+    auto b = [=] __device__(int k, int n) -> float { return R[(size_t)k * N + n]; };
     auto epi = [=] __device__(int m, int n, float g) {
         if (m < Min) adam_update(W, mW, vW, (size_t)m * N + n, g, ad);
         else adam_update(bias, mb, vb, n, g, ad);
@@ -617,8 +661,8 @@ __global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const 
 __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* __restrict__ dmlv,
                                             const float* __restrict__ Wq1, const float* __restrict__ h1, float* __restrict__ da1) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return m < B ? dmlv[(size_t)m * Z2 + k] : 0.f; };
-    auto b = [=] __device__(int k, int n) -> float { return n < H ? Wq1[(size_t)n * Z2 + k] : 0.f; };
+    auto a = [=] __device__(int m, int k) -> float { return dmlv[(size_t)m * Z2 + k]; };
+    auto b = [=] __device__(int k, int n) -> float { return Wq1[(size_t)n * Z2 + k]; };
     auto epi = [=] __device__(int m, int n, float acc) {
         const float t = h1[(size_t)m * H + n];
         da1[(size_t)m * H + n] = acc * (1.f - t * t);
@@ -946,10 +990,15 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
     hipLaunchKernelGGL(k_reparam, dim3(R), dim3(NT), 0, st, Z, acts->mulv, o->eps, o->is_training, cfg->seed, o->rng_step,
                        acts->z, acts->kl_rows);
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2));
-    if (cfg->precision == LTG_PREC_BF16)
-        LTG_PROBED(pr, LTG_K_DEC1_FWD, hipLaunchKernelGGL(k_dec1_fwd<true>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits));
-    else
-        LTG_PROBED(pr, LTG_K_DEC1_FWD, hipLaunchKernelGGL(k_dec1_fwd<false>, grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits));
+    {
+        const bool bf = cfg->precision == LTG_PREC_BF16, big = I >= 8192;
+        pr.before(LTG_K_DEC1_FWD);
+        if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        else if (bf) hipLaunchKernelGGL((k_dec1_fwd<true, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        else if (big) hipLaunchKernelGGL((k_dec1_fwd<false, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        else hipLaunchKernelGGL((k_dec1_fwd<false, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        pr.after(LTG_K_DEC1_FWD);
+    }
     hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
     if (probs_out) {
         const int gx = (I + NT - 1) / NT < 64 ? (I + NT - 1) / NT : 64;
@@ -1071,9 +1120,12 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     const int kchunk = dh2_kchunk(I);
     const int nsplit = (I + kchunk - 1) / kchunk;
     const bool bf = cfg->precision == LTG_PREC_BF16;
+    const bool big = I >= 8192;
     pr.before(LTG_K_DH2);
-    if (bf) hipLaunchKernelGGL(k_dh2_partial<true>, grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
-    else hipLaunchKernelGGL(k_dh2_partial<false>, grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else if (bf) hipLaunchKernelGGL((k_dh2_partial<true, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else if (big) hipLaunchKernelGGL((k_dh2_partial<false, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else hipLaunchKernelGGL((k_dh2_partial<false, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     pr.after(LTG_K_DH2);
     {
         const int n = B * H;
@@ -1081,8 +1133,16 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, acts->h2, w.da2);
     }
     pr.before(LTG_K_DEC1_BWD_ADAM);
-    if (bf) hipLaunchKernelGGL(k_dec1_bwd_adam<true>, grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-    else hipLaunchKernelGGL(k_dec1_bwd_adam<false>, grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    {
+        const int var = cfg->reserved0 > 0 ? cfg->reserved0 - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
+        if (!bf) {
+            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+    }
     pr.after(LTG_K_DEC1_BWD_ADAM);
     pr.before(LTG_K_DZ);
     hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
@@ -1102,7 +1162,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     {
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
-        if (gx > 4096) gx = 4096;
+        if (gx > 262144) gx = 262144;
         pr.before(LTG_K_ENC0_BWD_ADAM);
         hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, B, I, H, bt->colptr, bt->rowidx, bt->csr_pos, bt->values,
                            o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, *gen, ad);

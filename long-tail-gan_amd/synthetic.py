@@ -1,0 +1,105 @@
+"""Synthetic user x item workloads of BASELINE.json: there is no network for real
+datasets, and the reference's O(I^2) overlap table cannot be built at these sizes, so the index
+path's OUTPUTS are synthesised directly with the same shape statistics as Askubuntu_Sample:
+
+  * item popularity ~ Zipf(s=1) over I items; history length max(5, round(LogNormal(2.2, 0.9)))
+    clipped to min(I/2, 2000); items drawn ~ popularity without replacement;
+  * popular set = top 10 % of items by interaction count, niche = the rest; a user's popular / niche
+    lists = the history split by that set (users missing either list stay invalid, Q8);
+  * real pairs: each niche item of a user paired with one of the user's popular items (uniform:
+    timing-only stand-in for the max-overlap partner);
+  * candidate set = the user's n niche items + max(2n, 10-n) other niche items drawn ~ popularity;
+  * every item id is valid.
+
+Workloads:  ml20m  = 136 000 users x 20 000 items (configs[2]);
+            c4     = 200 000 items (configs[3]'s item count), `users` rows generated on demand.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import sparse
+
+from .dataset import IndexData
+
+WORKLOADS = {"ml20m": dict(I=20000, N=136000), "c4": dict(I=200000, N=1000000)}
+
+
+def _histories(rng, n_users, I):
+    pop = 1.0 / np.arange(1, I + 1)
+    cdf = np.cumsum(pop / pop.sum())
+    L = np.maximum(5, np.rint(rng.lognormal(2.2, 0.9, n_users))).astype(np.int64)
+    L = np.minimum(L, min(I // 2, 2000))
+    draws = (L * 1.6 + 8).astype(np.int64)
+    total = int(draws.sum())
+    row = np.repeat(np.arange(n_users), draws)
+    item = np.searchsorted(cdf, rng.random(total), side="right").clip(0, I - 1)
+    key = row * I + item
+    key = np.unique(key)                       # dedup within a user, sorted by (row, item)
+    row, item = key // I, key % I
+    # truncate each user to L items (keep a random subset so that popular items are not favoured twice)
+    order = np.lexsort((rng.random(len(row)), row))
+    row, item = row[order], item[order]
+    start = np.concatenate([[0], np.cumsum(np.bincount(row, minlength=n_users))])
+    rank = np.arange(len(row)) - start[row]
+    keep = rank < L[row]
+    row, item = row[keep], item[keep]
+    order = np.lexsort((item, row))
+    return row[order], item[order], pop
+
+
+def synthetic_index(name, users=None, seed=1234):
+    spec = WORKLOADS[name]
+    I = spec["I"]
+    N = int(users or spec["N"])
+    rng = np.random.default_rng(seed)
+    row, item, pop = _histories(rng, N, I)
+    train = sparse.csr_matrix((np.ones(len(row), np.float32), (row, item)), shape=(N, I))
+    train.sort_indices()
+    counts = np.bincount(item, minlength=I)
+    n_pop = max(1, I // 10)
+    popular = np.zeros(I, bool)
+    popular[np.argsort(-counts, kind="stable")[:n_pop]] = True
+    is_pop = popular[item]
+    indptr = train.indptr
+    npop_u = np.add.reduceat(is_pop.astype(np.int64), indptr[:-1]) if len(item) else np.zeros(N, np.int64)
+    npop_u[np.diff(indptr) == 0] = 0
+    nnic_u = np.diff(indptr) - npop_u
+    ok = (npop_u > 0) & (nnic_u > 0)
+    niche_ids = np.nonzero(~popular)[0]
+    nic_cdf = np.cumsum(pop[niche_ids] / pop[niche_ids].sum())
+
+    idx = IndexData.__new__(IndexData)
+    idx.n_items, idx.N, idx.train, idx.uid0 = I, N, train, 0
+    idx.valid_item = np.ones(I, np.uint8)
+    idx.user_ok = ok
+    pop_ptr, cand_ptr, real_ptr = np.zeros(N + 1, np.int64), np.zeros(N + 1, np.int64), np.zeros(N + 1, np.int64)
+    pop_idx, cand_idx, real_nic, real_pop = [], [], [], []
+    n_sample = np.where(ok, nnic_u, 0).astype(np.int32)
+    for u in range(N):
+        if ok[u]:
+            it = item[indptr[u]:indptr[u + 1]]
+            pm = is_pop[indptr[u]:indptr[u + 1]]
+            pl, nl = it[pm], it[~pm]
+            n = len(nl)
+            want = max(2 * n, 10 - n)
+            extra = niche_ids[np.searchsorted(nic_cdf, rng.random(want + 8), side="right").clip(0, len(niche_ids) - 1)]
+            extra = np.setdiff1d(np.unique(extra), nl)[:want]
+            cand = np.sort(np.concatenate([nl, extra]))
+            pop_idx.append(pl)
+            cand_idx.append(cand)
+            real_nic.append(nl)
+            real_pop.append(pl[rng.integers(0, len(pl), n)])
+            pop_ptr[u + 1] = pop_ptr[u] + len(pl)
+            cand_ptr[u + 1] = cand_ptr[u] + len(cand)
+            real_ptr[u + 1] = real_ptr[u] + n
+        else:
+            pop_ptr[u + 1], cand_ptr[u + 1], real_ptr[u + 1] = pop_ptr[u], cand_ptr[u], real_ptr[u]
+    cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
+    idx.pop_ptr, idx.pop_idx = pop_ptr.astype(np.int32), cat(pop_idx)
+    idx.cand_ptr, idx.cand_idx = cand_ptr.astype(np.int32), cat(cand_idx)
+    idx.real_ptr, idx.real_nic, idx.real_pop = real_ptr.astype(np.int32), cat(real_nic), cat(real_pop)
+    idx.n_sample = n_sample
+    idx.slot_ptr = np.concatenate([[0], np.cumsum(n_sample)]).astype(np.int32)
+    desc = "synthetic %s-shaped: %d users x %d items, %d interactions (Zipf popularity, log-normal history length; SURVEY 8/d2), seed %d" % (
+        name, N, I, train.nnz, seed)
+    return idx, desc
