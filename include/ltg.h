@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 1
+#define LTG_ABI_VERSION 2
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -53,7 +53,12 @@ typedef struct ltg_config {
     int32_t d_feat;  /* FEATURE_LEN: rows of the frozen embedding table */
     int32_t d_h0, d_h1, d_h2, d_h3;
     int32_t precision; /* LTG_PREC_* */
-    int32_t reserved0;
+    int32_t reserved0; /* kernel tuning knob, 0 = auto */
+    /* item shard of this rank: it owns global items [item_lo, item_lo + n_items); n_items_global = 0 means
+     * unsharded (n_items_global = n_items, item_lo = 0).  W_q0 / W_p1t / b_p1 and their Adam moments hold
+     * only the local rows; CSR indices are local; fake-pair and candidate ids stay global. */
+    int32_t item_lo;
+    int32_t n_items_global;
     float lr, beta1, beta2, adam_eps;
     uint64_t seed;
 } ltg_config;
@@ -87,6 +92,7 @@ typedef struct ltg_batch {
     const int32_t* colptr;  /* [n_items+1] offsets into rowidx/csr_pos (relative to 0) */
     const int32_t* rowidx;  /* local row of each CSC entry */
     const int32_t* csr_pos; /* index of that entry in indices[] */
+    const float* row_norm2; /* optional [n_rows]: sum x^2 over the FULL row (needed when the items are sharded) */
 } ltg_batch;
 
 /* Activations of one generator forward; caller-owned, sizes for n_rows rows.
@@ -181,6 +187,7 @@ typedef struct ltg_sample_inputs {
     uint64_t rng_step;
     const float* u_gumbel;    /* optional [n_cand total] uniforms aligned with cand_idx */
     const float* u_pick;      /* optional [n_slots] uniforms aligned with slots */
+    const float* cand_logit;  /* optional, aligned with cand_idx: replaces the [B,I] logits (item-sharded runs) */
 } ltg_sample_inputs;
 
 int32_t ltg_abi_version(void);
@@ -218,6 +225,30 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
                const ltg_batch* batch, const ltg_pairs* fake, const ltg_g_opts* opts,
                const ltg_gen_acts* acts, float* loss_out, void* ws, size_t ws_bytes,
                ltg_stream stream);
+
+/* ---- The generator step cut at its three exchange points, for item-sharded multi-GPU runs (one process per
+ * GPU; the collectives between the stages are issued by the host with RCCL, the library itself never
+ * communicates).  ltg_g_step == the four stages back to back with n_ranks = 1.
+ *   ltg_g_fwd_enc   enc-0 over the local item slab -> acts->h1 = partial PRE-activation   [all-reduce sum h1]
+ *   ltg_g_fwd_rest  bias+tanh, enc-1, reparam, dec-0, local logits, row partials [n_rows][5] [all-gather]
+ *   ltg_g_bwd_dec   combine partials (lse, losses), fake tower, dlogits, local dh2 [n_rows][H] [all-reduce sum]
+ *   ltg_g_bwd_rest  Adam on the local W_p1t/b_p1 rows, replicated middle layers, local W_q0 rows
+ * ltg_rowstats_combine: lse of the full rows from all-gathered partials (phase C / evaluation).
+ * ltg_gather_cand_logits: this rank's candidate logits, 0 elsewhere (all-reduce -> ltg_sample_inputs.cand_logit). */
+int ltg_g_fwd_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_fwd_opts* opts,
+                  const ltg_gen_acts* acts, ltg_stream stream);
+int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
+                   const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, ltg_stream stream);
+int ltg_rowstats_combine(const ltg_config* cfg, const float* rowpart_all, int32_t n_ranks, int32_t n_rows, float* lse_out,
+                         void* ws, size_t ws_bytes, ltg_stream stream);
+int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,
+                  const ltg_pairs* fake, const ltg_g_opts* opts, const ltg_gen_acts* acts, const float* rowpart_all,
+                  int32_t n_ranks, float* loss_out, float* dh2_out, void* ws, size_t ws_bytes, ltg_stream stream);
+int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
+                   const ltg_g_opts* opts, const ltg_gen_acts* acts, const float* dh2, void* ws, size_t ws_bytes,
+                   ltg_stream stream);
+int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out,
+                           ltg_stream stream);
 
 /* Ranking metrics on device: replaces pred[X.nonzero()] = -inf (Codes/train.py:341) +
  * NDCG_binary_at_k_batch / Recall_at_k_batch (Codes/eval_functions.py:11-62).

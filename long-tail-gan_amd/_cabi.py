@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
-LTG_ABI_VERSION = 1
+LTG_ABI_VERSION = 2
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -23,7 +23,7 @@ vp = C.c_void_p
 class ltg_config(C.Structure):
     _fields_ = [("n_items", C.c_int32), ("h_enc", C.c_int32), ("z_dim", C.c_int32), ("d_feat", C.c_int32),
                 ("d_h0", C.c_int32), ("d_h1", C.c_int32), ("d_h2", C.c_int32), ("d_h3", C.c_int32),
-                ("precision", C.c_int32), ("reserved0", C.c_int32),
+                ("precision", C.c_int32), ("reserved0", C.c_int32), ("item_lo", C.c_int32), ("n_items_global", C.c_int32),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("seed", C.c_uint64)]
 
@@ -38,7 +38,7 @@ class ltg_disc_state(C.Structure):
 
 class ltg_batch(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("reserved0", C.c_int32), ("indptr", vp), ("indices", vp), ("values", vp),
-                ("colptr", vp), ("rowidx", vp), ("csr_pos", vp)]
+                ("colptr", vp), ("rowidx", vp), ("csr_pos", vp), ("row_norm2", vp)]
 
 
 class ltg_gen_acts(C.Structure):
@@ -76,7 +76,7 @@ class ltg_g_opts(C.Structure):
 class ltg_sample_inputs(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("max_cand", C.c_int32), ("cand_ptr", vp), ("cand_idx", vp), ("pop_ptr", vp),
                 ("pop_idx", vp), ("n_sample", vp), ("slot_ptr", vp), ("valid_item", vp), ("rng_step", C.c_uint64),
-                ("u_gumbel", vp), ("u_pick", vp)]
+                ("u_gumbel", vp), ("u_pick", vp), ("cand_logit", vp)]
 
 
 # every symbol include/ltg.h declares: name -> (restype, argtypes)
@@ -91,6 +91,17 @@ SYMBOLS = {
     "ltg_g_step": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state),
                              C.POINTER(ltg_batch), C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts),
                              C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
+    "ltg_g_fwd_enc": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_fwd_opts),
+                                C.POINTER(ltg_gen_acts), vp]),
+    "ltg_g_fwd_rest": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pairs),
+                                 C.POINTER(ltg_fwd_opts), C.POINTER(ltg_gen_acts), vp, vp]),
+    "ltg_rowstats_combine": (C.c_int, [C.POINTER(ltg_config), vp, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
+    "ltg_g_bwd_dec": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state), C.POINTER(ltg_batch),
+                                C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, C.c_int32, vp, vp, vp,
+                                C.c_size_t, vp]),
+    "ltg_g_bwd_rest": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pairs),
+                                 C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
+    "ltg_gather_cand_logits": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,
                                    C.c_int32, C.c_int32, vp, vp]),
 }

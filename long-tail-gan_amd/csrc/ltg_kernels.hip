@@ -65,7 +65,12 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
                                                      const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed,
                                                      uint64_t step, const float* __restrict__ Wq0,
                                                      const float* __restrict__ bq0, float* __restrict__ h1,
-                                                     float* __restrict__ row_scale) {
+                                                     float* __restrict__ row_scale, const float* __restrict__ row_norm2,
+                                                     int item_lo, int Ig, int pre_only) {
+    // item shard: `indices` are LOCAL item ids of this rank's slab [item_lo, item_lo + I); the dropout
+    // RNG is keyed by the GLOBAL id so every shard draws the mask the unsharded run draws; row_norm2
+    // (sum x^2 over the FULL row) replaces the local sum; pre_only writes the partial pre-activation
+    // (no bias, no tanh) that the ranks all-reduce.
     extern __shared__ __attribute__((aligned(16))) float s_part[];  // [ENC_NW][H]
     __shared__ int s_idx[ENC_NT];
     __shared__ float s_val[ENC_NT];
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
     ss = 0.f;
 #pragma unroll
     for (int i = 0; i < ENC_NW; ++i) ss += red[i];
+    if (row_norm2) ss = row_norm2[b];
     const float scale = 1.f / (keep * sqrtf(fmaxf(ss, 1e-12f)));  // l2_normalize eps, then /keep
     if (tid == 0) row_scale[b] = scale;
     const int H4 = H >> 2;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
             const int it = indices[e];
             const float v = values ? values[e] : 1.f;
             const bool kp = drop_keep ? (drop_keep[e] != 0)
-                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)I + it, keep);
+                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
             s_idx[tid] = it;
             s_val[tid] = kp ? v : 0.f;
         }
@@ -133,8 +139,13 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < ENC_NW; ++i) t += s_part[(size_t)i * H + c];
-        h1[(size_t)b * H + c] = tanhf(t * scale + bq0[c]);
+        h1[(size_t)b * H + c] = pre_only ? t * scale : tanhf(t * scale + bq0[c]);
     }
+}
+
+// h1 = tanh(h1_pre + b) after the partial pre-activations of the item shards were all-reduced
+__global__ __launch_bounds__(NT) void k_bias_tanh(int n, int H, const float* __restrict__ bias, float* __restrict__ h) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) h[i] = tanhf(h[i] + bias[i % H]);
 }
 
 // Generic dense layer  C = act(A[M][K] . B[K][N] + bias)  (fp32 MFMA); act: 0 none, 1 tanh.
@@ -456,54 +467,87 @@ __global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, const float* _
 // Generator step: losses (train.py:145-157) and backward (closed forms: SURVEY 8 row a10)
 // ---------------------------------------------------------------------------------------------
 
-// per-row statistics: neg_ll_row, n_b = sum x, P_b = sum_{k in S_b} p_bk
-__global__ __launch_bounds__(NT) void k_g_rowstats(int I, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-                                                   const float* __restrict__ values, const float* __restrict__ logits,
-                                                   const float* __restrict__ lse, int nf, const int32_t* __restrict__ f_row,
-                                                   const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
-                                                   float* __restrict__ negll_row, float* __restrict__ nb, float* __restrict__ Pb) {
+// Per-row partial statistics over THIS rank's item slab (5 floats per row):
+//   [0] m  = max_i logit            [1] s  = sum_i exp(logit - m)
+//   [2] xl = sum_i x_bi * logit     [3] ps = sum_{(b,i) in S, i local} exp(logit - m)     [4] nx = sum_i x_bi
+// Fake pairs carry GLOBAL item ids.  The shards' partials are all-gathered and combined in k_g_combine.
+constexpr int RP = 5;
+__global__ __launch_bounds__(NT) void k_row_partial(int I, int item_lo, const int32_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                    const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
+                                                    const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
+                                                    float* __restrict__ rowpart) {
     __shared__ float red[NT / 64];
     const int b = blockIdx.x;
-    const float l = lse[b];
     const float* row = logits + (size_t)b * I;
-    float s_ll = 0.f, s_n = 0.f, s_p = 0.f;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < I; i += NT) mx = fmaxf(mx, row[i]);
+    mx = block_max(mx, red);
+    float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
+    for (int i = threadIdx.x; i < I; i += NT) s += expf(row[i] - mx);
     for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
         const float v = values ? values[e] : 1.f;
-        s_ll -= v * (row[indices[e]] - l);
-        s_n += v;
+        xl += v * row[indices[e]];
+        nx += v;
     }
-    for (int s = threadIdx.x; s < nf; s += NT)
-        if (f_row[s] == b && f_gen[s] >= 0 && f_pop[s] >= 0) s_p += expf(row[f_gen[s]] - l);
-    s_ll = block_sum(s_ll, red);
-    s_n = block_sum(s_n, red);
-    s_p = block_sum(s_p, red);
+    for (int q = threadIdx.x; q < nf; q += NT) {
+        const int it = f_gen[q] - item_lo;
+        if (f_row[q] == b && f_gen[q] >= 0 && f_pop[q] >= 0 && it >= 0 && it < I) ps += expf(row[it] - mx);
+    }
+    s = block_sum(s, red);
+    xl = block_sum(xl, red);
+    nx = block_sum(nx, red);
+    ps = block_sum(ps, red);
     if (threadIdx.x == 0) {
-        negll_row[b] = s_ll;
-        nb[b] = s_n;
-        Pb[b] = s_p;
+        float* o = rowpart + (size_t)b * RP;
+        o[0] = mx;
+        o[1] = s;
+        o[2] = xl;
+        o[3] = ps;
+        o[4] = nx;
     }
 }
 
-// scalars: out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
-__global__ __launch_bounds__(NT) void k_g_scalars(int B, int nf, const float* __restrict__ negll_row,
-                                                  const float* __restrict__ kl_rows, const float* __restrict__ Pb,
-                                                  const float* __restrict__ y, const int32_t* __restrict__ cnt, float anneal,
-                                                  float lam, float* __restrict__ out) {
+// Combine the R shards' row partials: lse, n_b, P_b per row, then the step scalars (train.py:145-157):
+// out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
+__global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __restrict__ rowpart_all, int nf,
+                                                  const float* __restrict__ kl_rows, const float* __restrict__ y,
+                                                  const int32_t* __restrict__ cnt, float anneal, float lam, float* __restrict__ lse,
+                                                  float* __restrict__ nb, float* __restrict__ Pb, float* __restrict__ out) {
     __shared__ float red[NT / 64];
     float a = 0.f, k = 0.f, p = 0.f, sy = 0.f;
-    for (int i = threadIdx.x; i < B; i += NT) {
-        a += negll_row[i];
-        k += kl_rows[i];
-        p += Pb[i];
+    for (int b = threadIdx.x; b < B; b += NT) {
+        float M = -INFINITY;
+        for (int r = 0; r < R; ++r) M = fmaxf(M, rowpart_all[((size_t)r * B + b) * RP]);
+        float se = 0.f, xl = 0.f, nx = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float* q = rowpart_all + ((size_t)r * B + b) * RP;
+            se += q[1] * expf(q[0] - M);
+            xl += q[2];
+            nx += q[4];
+        }
+        const float l = M + logf(se);
+        float pb = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float* q = rowpart_all + ((size_t)r * B + b) * RP;
+            pb += q[3] * expf(q[0] - l);
+        }
+        lse[b] = l;
+        nb[b] = nx;
+        Pb[b] = pb;
+        a += -xl + nx * l;  // neg_ll_row = -sum x (logit - lse)
+        if (kl_rows) k += kl_rows[b];
+        p += pb;
     }
-    for (int i = threadIdx.x; i < nf; i += NT) sy += y[i];
+    if (y)
+        for (int i = threadIdx.x; i < nf; i += NT) sy += y[i];
     a = block_sum(a, red);
     k = block_sum(k, red);
     p = block_sum(p, red);
     sy = block_sum(sy, red);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && out) {
         const float negll = a / (float)B, KL = k / (float)B;
-        const float c = cnt[0] > 0 ? lam / (float)cnt[0] * sy : 0.f;
+        const float c = (cnt && cnt[0] > 0) ? lam / (float)cnt[0] * sy : 0.f;
         const float vae = negll + anneal * KL;
         const float gan = -c * p;
         out[0] = vae + gan;
@@ -515,6 +559,18 @@ __global__ __launch_bounds__(NT) void k_g_scalars(int B, int nf, const float* __
     }
 }
 
+// candidate logits of this rank's slab (0 elsewhere): summed over ranks they give every rank the
+// logits of all candidates (the sampler needs nothing else of the [B, I] matrix)
+__global__ __launch_bounds__(NT) void k_gather_cand(int I, int item_lo, const int32_t* __restrict__ cand_ptr,
+                                                    const int32_t* __restrict__ cand_idx, const float* __restrict__ logits,
+                                                    float* __restrict__ out) {
+    const int b = blockIdx.x;
+    for (int j = cand_ptr[b] + threadIdx.x; j < cand_ptr[b + 1]; j += NT) {
+        const int it = cand_idx[j] - item_lo;
+        out[j] = (it >= 0 && it < I) ? logits[(size_t)b * I + it] : 0.f;
+    }
+}
+
 // dlogits[b][i] = p*(n_b/B + c*P_b) - x_bi/B - c*p*[(b,i) in S]; grid (segments, rows).
 constexpr int DL_SEG = 2048;
 __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __restrict__ indptr,
@@ -523,7 +579,7 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
                                                 const float* __restrict__ nb, const float* __restrict__ Pb,
                                                 const float* __restrict__ scal, int nf, const int32_t* __restrict__ f_row,
                                                 const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
-                                                float* __restrict__ dlog) {
+                                                float* __restrict__ dlog, int item_lo) {
     __shared__ float s_x[DL_SEG];
     __shared__ uint8_t s_s[DL_SEG];
     const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG;
@@ -538,8 +594,8 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
         if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
     }
     for (int s = threadIdx.x; s < nf; s += NT) {
-        const int it = f_gen[s];
-        if (f_row[s] == b && it >= i0 && it < i1 && f_pop[s] >= 0) s_s[it - i0] = 1;
+        const int it = f_gen[s] - item_lo;  // fake pairs carry global item ids
+        if (f_row[s] == b && f_gen[s] >= 0 && it >= i0 && it < i1 && f_pop[s] >= 0) s_s[it - i0] = 1;
     }
     __syncthreads();
     const float invB = 1.f / (float)B, c = scal[5], l = lse[b];
@@ -571,7 +627,7 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
-        const float t = h2[i];
+        const float t = h2 ? h2[i] : 0.f;
         da2[i] = s * (1.f - t * t);
     }
 }
@@ -678,7 +734,7 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int B, int I, int H, const
                                                       const float* __restrict__ values, const uint8_t* __restrict__ drop_keep,
                                                       float keep, uint64_t seed, uint64_t step,
                                                       const float* __restrict__ row_scale, const float* __restrict__ da1,
-                                                      ltg_gen_state st, AdamC ad) {
+                                                      ltg_gen_state st, AdamC ad, int item_lo, int Ig) {
     const int H4 = H >> 2;  // H % 4 == 0 (checked on the host)
     const size_t total = (size_t)(I + 1) * H4;
     float4* W4 = reinterpret_cast<float4*>(st.p[0]);
@@ -695,7 +751,7 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int B, int I, int H, const
             for (int q = colptr[i]; q < colptr[i + 1]; ++q) {
                 const int b = rowidx[q], pos = csr_pos[q];
                 const bool kp = drop_keep ? (drop_keep[pos] != 0)
-                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)I + i, keep);
+                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + i, keep);
                 if (kp) {
                     const float s = (values ? values[pos] : 1.f) * row_scale[b];
                     const float4 d = d4[(size_t)b * H4 + c];
@@ -741,7 +797,10 @@ __global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __res
                                                      const float* __restrict__ u_gumbel, const float* __restrict__ u_pick,
                                                      uint64_t seed, uint64_t step, const float* __restrict__ logits,
                                                      const float* __restrict__ lse, int32_t* __restrict__ gen_out,
-                                                     int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out) {
+                                                     int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out,
+                                                     const float* __restrict__ cand_logit) {
+    // I is the GLOBAL item count (RNG index space); cand_logit (optional, aligned with cand_idx) replaces
+    // the [B, I] logits matrix when the items are sharded over ranks.
     extern __shared__ __attribute__((aligned(16))) float s_key[];
     __shared__ int s_w[NT / 64];
     __shared__ float red[NT / 64];
@@ -755,7 +814,7 @@ __global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __res
     float nnzf = 0.f;
     for (int j = tid; j < nc; j += NT) {
         const int it = cand_idx[c0 + j];
-        const float lp = row[it] - l;
+        const float lp = (cand_logit ? cand_logit[c0 + j] : row[it]) - l;
         const bool pos = expf(lp) > 0.f;  // softmax underflow == "zero probability" of sample.py:45
         float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, (uint64_t)b * (uint64_t)I + it);
         u = fmaxf(u, 2.98023223876953125e-8f);  // 2^-25
@@ -900,7 +959,7 @@ inline int dh2_kchunk(int I) {
 
 struct Workspace {
     // generator backward
-    float *negll_row, *nb, *Pb, *scal, *dlog, *part, *da2, *dmlv, *da1;
+    float *rowpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1;
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     size_t bytes;
@@ -918,12 +977,13 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     const size_t P = (size_t)max_pairs, h12 = (size_t)cfg->d_h1 + cfg->d_h2, h3 = (size_t)cfg->d_h3;
     const int kchunk = dh2_kchunk(cfg->n_items);
     const size_t nsplit = (I + kchunk - 1) / kchunk;
-    w.negll_row = take(R);
+    w.rowpart = take(R * RP);
     w.nb = take(R);
     w.Pb = take(R);
     w.scal = take(16);
     w.dlog = take(R * I);
     w.part = take(nsplit * R * H);
+    w.dh2 = take(R * H);
     w.da2 = take(R * H);
     w.dmlv = take(R * 2 * Z);
     w.da1 = take(R * H);
@@ -979,13 +1039,28 @@ bool cfg_ok(const ltg_config* c) {
            (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32);
 }
 
-int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
-                     const ltg_gen_acts* acts, float* probs_out, hipStream_t st) {
-    const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
-    if (R <= 0) return LTG_OK;
+inline int Ig_of(const ltg_config* cfg) { return cfg->n_items_global > 0 ? cfg->n_items_global : cfg->n_items; }
+
+// stage 1: enc-0 over this rank's item slab.  pre_only: leave the partial pre-activation in acts->h1.
+void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
+                   const ltg_gen_acts* acts, int pre_only, hipStream_t st) {
+    const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc;
     const Probe pr{o->probe, st};
-    LTG_PROBED(pr, LTG_K_ENC0_FWD, hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices, bt->values, o->drop_keep,
-                       o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale));
+    LTG_PROBED(pr, LTG_K_ENC0_FWD,
+               hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices,
+                                  bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
+                                  acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only));
+}
+
+// stage 2: (bias + tanh of the all-reduced pre-activation,) enc-1, reparameterisation, dec-0, dec-1 over the local slab
+void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
+                    const ltg_gen_acts* acts, int apply_bias_tanh, hipStream_t st) {
+    const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
+    const Probe pr{o->probe, st};
+    if (apply_bias_tanh) {
+        const int n = R * H;
+        hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
+    }
     LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv));
     hipLaunchKernelGGL(k_reparam, dim3(R), dim3(NT), 0, st, Z, acts->mulv, o->eps, o->is_training, cfg->seed, o->rng_step,
                        acts->z, acts->kl_rows);
@@ -999,6 +1074,14 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
         else hipLaunchKernelGGL((k_dec1_fwd<false, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         pr.after(LTG_K_DEC1_FWD);
     }
+}
+
+int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
+                     const ltg_gen_acts* acts, float* probs_out, hipStream_t st) {
+    const int R = bt->n_rows, I = cfg->n_items;
+    if (R <= 0) return LTG_OK;
+    fwd_stage_enc(cfg, gen, bt, o, acts, 0, st);
+    fwd_stage_rest(cfg, gen, bt, o, acts, 0, st);
     hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
     if (probs_out) {
         const int gx = (I + NT - 1) / NT < 64 ? (I + NT - 1) / NT : 64;
@@ -1045,7 +1128,7 @@ int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
 
 int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, const float* lse,
                      int32_t* gen_out, int32_t* pop_out, int32_t* cnt_out, ltg_stream stream) {
-    if (!cfg_ok(cfg) || !in || !logits || !lse || !gen_out || !pop_out || !cnt_out) return LTG_EINVAL;
+    if (!cfg_ok(cfg) || !in || (!logits && !in->cand_logit) || !lse || !gen_out || !pop_out || !cnt_out) return LTG_EINVAL;
     if (in->n_rows < 0 || in->max_cand < 0) return LTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(cnt_out, 0, sizeof(int32_t), st) != hipSuccess) return LTG_ELAUNCH;
@@ -1053,9 +1136,9 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
     const int max_cand = in->max_cand > 0 ? in->max_cand : 1;
     const size_t lds = (size_t)max_cand * sizeof(float);
     if (lds > 64 * 1024) return LTG_EINVAL;
-    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(NT), lds, st, cfg->n_items, in->cand_ptr, in->cand_idx, in->pop_ptr,
+    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(NT), lds, st, Ig_of(cfg), in->cand_ptr, in->cand_idx, in->pop_ptr,
                        in->pop_idx, in->n_sample, in->slot_ptr, in->valid_item, in->u_gumbel, in->u_pick, cfg->seed, in->rng_step,
-                       logits, lse, gen_out, pop_out, cnt_out);
+                       logits, lse, gen_out, pop_out, cnt_out, in->cand_logit);
     return check_launch();
 }
 
@@ -1091,32 +1174,33 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     return check_launch();
 }
 
-int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
-               const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, float* loss_out, void* ws,
-               size_t ws_bytes, ltg_stream stream) {
-    if (!cfg_ok(cfg) || !gen || !disc || !bt || !fake || !o || !acts || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
-    if (!bt->colptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
-    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim, nf = fake->n;
-    if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const Workspace w = carve(cfg, B, nf, (char*)ws);
+// ---- generator step in four stages; between them an item-sharded run exchanges (1) the encoder
+// pre-activation [B,H] (all-reduce), (2) the row partials [B,5] (all-gather), (3) dh2 [B,H] (all-reduce).
+// ltg_g_step runs the same stages back to back with one "rank".
+
+static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_pairs* fake, const ltg_gen_acts* acts,
+                          float* rowpart, hipStream_t st) {
+    hipLaunchKernelGGL(k_row_partial, dim3(bt->n_rows), dim3(NT), 0, st, cfg->n_items, cfg->item_lo, bt->indptr, bt->indices, bt->values,
+                       acts->logits, fake ? fake->n : 0, fake ? fake->row : nullptr, fake ? fake->niche : nullptr,
+                       fake ? fake->pop : nullptr, rowpart);
+}
+
+static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
+                           const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, const float* rowpart_all,
+                           int n_ranks, float* loss_out, const Workspace& w, float* dh2_out, hipStream_t st) {
+    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nf = fake->n;
     const Probe pr{o->probe, st};
-    int rc = vae_forward_impl(cfg, gen, bt, &o->fwd, acts, nullptr, st);
-    if (rc != LTG_OK) return rc;
-    // fake tower forward only (y_data is pruned from the g_trainer fetch, train.py:326)
+    // fake tower forward only (y_data is pruned from the g_trainer fetch, train.py:326); replicated on every rank
     if (nf > 0) {
         PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
         DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
     }
-    hipLaunchKernelGGL(k_g_rowstats, dim3(B), dim3(NT), 0, st, I, bt->indptr, bt->indices, bt->values, acts->logits, acts->lse, nf,
-                       fake->row, fake->niche, fake->pop, w.negll_row, w.nb, w.Pb);
-    hipLaunchKernelGGL(k_g_scalars, dim3(1), dim3(NT), 0, st, B, nf, w.negll_row, acts->kl_rows, w.Pb, w.y, o->cnt, o->anneal,
-                       o->gan_lambda, w.scal);
+    hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, st, B, n_ranks, rowpart_all, nf, acts->kl_rows, nf > 0 ? w.y : nullptr, o->cnt,
+                       o->anneal, o->gan_lambda, acts->lse, w.nb, w.Pb, w.scal);
     if (hipMemcpyAsync(loss_out, w.scal, 6 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return LTG_ELAUNCH;
     hipLaunchKernelGGL(k_dlogits, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, bt->indptr, bt->indices, bt->values,
-                       acts->logits, acts->lse, w.nb, w.Pb, w.scal, nf, fake->row, fake->niche, fake->pop, w.dlog);
-    const AdamC ad = make_adam(cfg, o->adam_t);
+                       acts->logits, acts->lse, w.nb, w.Pb, w.scal, nf, fake->row, fake->niche, fake->pop, w.dlog, cfg->item_lo);
     const int kchunk = dh2_kchunk(I);
     const int nsplit = (I + kchunk - 1) / kchunk;
     const bool bf = cfg->precision == LTG_PREC_BF16;
@@ -1130,7 +1214,22 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
-        hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, acts->h2, w.da2);
+        hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, (const float*)nullptr, dh2_out);  // slab sum only
+    }
+    return check_launch();
+}
+
+static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
+                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st) {
+    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
+    const Probe pr{o->probe, st};
+    const AdamC ad = make_adam(cfg, o->adam_t);
+    const bool bf = cfg->precision == LTG_PREC_BF16;
+    const bool big = I >= 8192;
+    {
+        const int n = B * H;
+        const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
+        hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
     }
     pr.before(LTG_K_DEC1_BWD_ADAM);
     {
@@ -1165,9 +1264,85 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         if (gx > 262144) gx = 262144;
         pr.before(LTG_K_ENC0_BWD_ADAM);
         hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, B, I, H, bt->colptr, bt->rowidx, bt->csr_pos, bt->values,
-                           o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, *gen, ad);
+                           o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, *gen, ad, cfg->item_lo,
+                           Ig_of(cfg));
         pr.after(LTG_K_ENC0_BWD_ADAM);
     }
+    return check_launch();
+}
+
+static bool g_args_ok(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_gen_acts* acts) {
+    return cfg_ok(cfg) && gen && bt && acts && bt->n_rows > 0 && bt->indptr && bt->indices;
+}
+
+int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
+               const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, float* loss_out, void* ws,
+               size_t ws_bytes, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !gen || !disc || !bt || !fake || !o || !acts || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
+    if (!bt->colptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
+    const int B = bt->n_rows, nf = fake->n;
+    if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace w = carve(cfg, B, nf, (char*)ws);
+    fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st);
+    fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
+    g_row_partial(cfg, bt, fake, acts, w.rowpart, st);
+    int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.dh2, st);
+    if (rc != LTG_OK) return rc;
+    return g_stage_bwd_rest(cfg, gen, bt, o, acts, w.dh2, w, st);
+}
+
+/* ---- the same step cut at its three exchange points (item-sharded multi-GPU; include/ltg.h) ---- */
+int ltg_g_fwd_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* opts,
+                  const ltg_gen_acts* acts, ltg_stream stream) {
+    if (!g_args_ok(cfg, gen, bt, acts) || !opts) return LTG_EINVAL;
+    fwd_stage_enc(cfg, gen, bt, opts, acts, 1, (hipStream_t)stream);
+    return check_launch();
+}
+
+int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,
+                   const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, ltg_stream stream) {
+    if (!g_args_ok(cfg, gen, bt, acts) || !opts || !rowpart_out) return LTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    fwd_stage_rest(cfg, gen, bt, opts, acts, 1, st);
+    g_row_partial(cfg, bt, (fake && fake->n > 0) ? fake : nullptr, acts, rowpart_out, st);
+    return check_launch();
+}
+
+int ltg_rowstats_combine(const ltg_config* cfg, const float* rowpart_all, int32_t n_ranks, int32_t n_rows, float* lse_out,
+                         void* ws, size_t ws_bytes, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !rowpart_all || !lse_out || n_ranks < 1 || n_rows < 1 || !ws) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, n_rows, 1) > ws_bytes) return LTG_EWORKSPACE;
+    const Workspace w = carve(cfg, n_rows, 1, (char*)ws);
+    hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, (hipStream_t)stream, n_rows, n_ranks, rowpart_all, 0, (const float*)nullptr,
+                       (const float*)nullptr, (const int32_t*)nullptr, 0.f, 0.f, lse_out, w.nb, w.Pb, (float*)nullptr);
+    return check_launch();
+}
+
+int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
+                  const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, const float* rowpart_all,
+                  int32_t n_ranks, float* loss_out, float* dh2_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    if (!g_args_ok(cfg, gen, bt, acts) || !disc || !fake || !o || !rowpart_all || n_ranks < 1 || !loss_out || !dh2_out || !ws) return LTG_EINVAL;
+    if (!o->cnt || !fake->row || fake->n < 0) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
+    const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);
+    return g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, rowpart_all, n_ranks, loss_out, w, dh2_out, (hipStream_t)stream);
+}
+
+int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,
+                   const ltg_g_opts* o, const ltg_gen_acts* acts, const float* dh2, void* ws, size_t ws_bytes, ltg_stream stream) {
+    if (!g_args_ok(cfg, gen, bt, acts) || !fake || !o || !dh2 || !ws || o->adam_t < 1) return LTG_EINVAL;
+    if (!bt->colptr || !bt->rowidx || !bt->csr_pos) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
+    const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
+    return g_stage_bwd_rest(cfg, gen, bt, o, acts, dh2, w, (hipStream_t)stream);
+}
+
+int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out, ltg_stream stream) {
+    if (!cfg_ok(cfg) || !in || !logits || !out || in->n_rows < 0) return LTG_EINVAL;
+    if (in->n_rows == 0) return LTG_OK;
+    hipLaunchKernelGGL(k_gather_cand, dim3(in->n_rows), dim3(NT), 0, (hipStream_t)stream, cfg->n_items, cfg->item_lo, in->cand_ptr,
+                       in->cand_idx, logits, out);
     return check_launch();
 }
 

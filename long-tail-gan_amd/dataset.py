@@ -133,13 +133,25 @@ def batch_csc(tr, lo, hi, n_items):
 class DeviceData:
     """IndexData uploaded to HBM + per-batch views (ctypes structs with the right offsets)."""
 
-    def __init__(self, idx: IndexData, batch_size, device):
+    def __init__(self, idx: IndexData, batch_size, device, item_lo=0, item_hi=None):
+        """item_lo/item_hi: this rank's item slab (multi-GPU item sharding).  Only the interaction matrix is
+        cut (columns [item_lo, item_hi), re-indexed from 0); pair / candidate / popular lists keep global ids
+        and are identical on every rank."""
         self.idx, self.BS, self.device = idx, int(batch_size), torch.device(device)
-        N, I = idx.N, idx.n_items
-        self.N, self.I = N, I
+        N = idx.N
+        self.item_lo, self.item_hi = int(item_lo), int(idx.n_items if item_hi is None else item_hi)
+        I = self.item_hi - self.item_lo
+        self.N, self.I, self.I_global = N, I, idx.n_items
         self.n_batches = (N + self.BS - 1) // self.BS
         up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a if dt is None else a.astype(dt))).to(self.device)
-        tr = idx.train
+        full = idx.train
+        self.row_norm2 = up(np.asarray(full.multiply(full).sum(axis=1)).reshape(-1), np.float32)   # sum x^2 over the FULL row
+        if (self.item_lo, self.item_hi) != (0, idx.n_items):
+            tr = full[:, self.item_lo:self.item_hi].tocsr()
+            tr.sort_indices()
+        else:
+            tr = full
+        self.local_csr = tr
         self.indptr = up(tr.indptr, np.int32)
         self.indices = up(tr.indices, np.int32)
         ones = np.all(tr.data == 1.0)
@@ -180,7 +192,7 @@ class DeviceData:
         lo, hi = b * self.BS, min(self.N, (b + 1) * self.BS)
         I = self.I
         batch = CsrRows(self.indptr, self.indices, lo, hi, values=self.values, colptr=self.colptr, rowidx=self.rowidx,
-                        csr_pos=self.csr_pos, col_off=b * (I + 1), ent_off=self.ent_off[b])
+                        csr_pos=self.csr_pos, col_off=b * (I + 1), ent_off=self.ent_off[b], row_norm2=self.row_norm2)
         # csr_pos holds ABSOLUTE positions and rowidx LOCAL rows: both are already relative to the arrays given
         r0, r1 = int(idx.real_ptr[lo]), int(idx.real_ptr[hi])
         real = Pairs(self.real_pop, self.real_nic, None, n=r1 - r0, off=r0)
@@ -189,7 +201,7 @@ class DeviceData:
         mc = int(cand_len[lo:hi].max()) if hi > lo else 0
         samp = cabi.ltg_sample_inputs(hi - lo, max(1, mc), _ptr(self.cand_ptr, lo), _ptr(self.cand_idx), _ptr(self.pop_ptr, lo),
                                       _ptr(self.pop_idx), _ptr(self.n_sample, lo), _ptr(self.slot_ptr, lo), _ptr(self.valid_item),
-                                      0, None, None)
+                                      0, None, None, None)
         return dict(batch=batch, real=real, fake=fake, samp=samp, n_real=r1 - r0, n_slots=s1 - s0, lo=lo, hi=hi, slot0=s0)
 
     def view(self, b):

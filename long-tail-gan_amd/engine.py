@@ -59,11 +59,11 @@ class CsrRows:
     view that the G step needs."""
 
     def __init__(self, indptr, indices, row_lo, row_hi, values=None, colptr=None, rowidx=None, csr_pos=None,
-                 col_off=0, ent_off=0):
-        self.keep = (indptr, indices, values, colptr, rowidx, csr_pos)
+                 col_off=0, ent_off=0, row_norm2=None):
+        self.keep = (indptr, indices, values, colptr, rowidx, csr_pos, row_norm2)
         self.n_rows = int(row_hi - row_lo)
         self.c = cabi.ltg_batch(self.n_rows, 0, _ptr(indptr, row_lo), _ptr(indices), _ptr(values),
-                                _ptr(colptr, col_off), _ptr(rowidx, ent_off), _ptr(csr_pos, ent_off))
+                                _ptr(colptr, col_off), _ptr(rowidx, ent_off), _ptr(csr_pos, ent_off), _ptr(row_norm2, row_lo))
 
 
 class Pairs:
@@ -75,18 +75,24 @@ class Pairs:
 
 class Engine:
     def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
-                 precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8):
+                 precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8,
+                 item_lo=0, item_hi=None):
+        """n_items = GLOBAL item count; [item_lo, item_hi) = the slab this rank owns (default: everything)."""
         self.lib = cabi.load()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
         p_dims = p_dims or [200, 600, n_items]                       # generator.py:13
         assert p_dims[-1] == n_items
-        self.I, self.H, self.Z = n_items, p_dims[1], p_dims[0]
+        self.I_global = n_items
+        self.item_lo = int(item_lo)
+        self.item_hi = int(n_items if item_hi is None else item_hi)
+        self.sharded = (self.item_lo, self.item_hi) != (0, n_items)
+        self.I, self.H, self.Z = self.item_hi - self.item_lo, p_dims[1], p_dims[0]   # self.I = LOCAL item count
         self.h0, self.h1, self.h2, self.h3 = h_sizes
         self.feature_len = feature_len or n_items
         self.precision = {"bf16": cabi.LTG_PREC_BF16, "fp32": cabi.LTG_PREC_FP32}[precision]
-        self.cfg = cabi.ltg_config(n_items, self.H, self.Z, self.feature_len, self.h0, self.h1, self.h2, self.h3,
-                                   self.precision, 0, lr, beta1, beta2, eps, seed)
+        self.cfg = cabi.ltg_config(self.I, self.H, self.Z, self.feature_len, self.h0, self.h1, self.h2, self.h3,
+                                   self.precision, 0, self.item_lo, n_items if self.sharded else 0, lr, beta1, beta2, eps, seed)
         self.lr, self.beta1, self.beta2 = lr, beta1, beta2
         self.adam_t = 0                                              # shared by D and G (Q5)
         self._init_generator(seed)
@@ -98,7 +104,7 @@ class Engine:
     # ------------------------------------------------------------------ parameters
     def _init_generator(self, seed):
         g = torch.Generator().manual_seed(seed)
-        I, H, Z = self.I, self.H, self.Z
+        I, H, Z = self.I_global, self.H, self.Z
 
         def xavier(fi, fo, shape):                                   # MultiVAE.py:199-202
             lim = math.sqrt(6.0 / (fi + fo))
@@ -112,11 +118,23 @@ class Engine:
         host = [xavier(I, H, (I, H)), xavier(H, 2 * Z, (H, 2 * Z)), xavier(Z, H, (Z, H)),
                 xavier(H, I, (I, H)),                                # W_p1 stored item-major [I][H]
                 tn((H,), 1e-3), tn((2 * Z,), 1e-3), tn((H,), 1e-3), tn((I,), 1e-3)]
-        self.set_generator([t.numpy() for t in host])
+        self.set_generator([t.numpy() for t in host])     # global tables: set_generator keeps this rank's slab
 
     def set_generator(self, arrays, m=None, v=None):
-        """arrays in engine layout: [W_q0 [I,H], W_q1 [H,2Z], W_p0 [Z,H], W_p1t [I,H], b_q0, b_q1, b_p0, b_p1]."""
+        """arrays in engine layout: [W_q0 [I,H], W_q1 [H,2Z], W_p0 [Z,H], W_p1t [I,H], b_q0, b_q1, b_p0, b_p1] with
+        I = the GLOBAL item count; an item-sharded engine keeps rows [item_lo, item_hi) of the item tables."""
         dev = self.device
+        lo, hi = self.item_lo, self.item_hi
+
+        def cut(seq):
+            seq = list(seq)
+            if seq[0].shape[0] == self.I_global and self.sharded:
+                for i in (0, 3, 7):
+                    seq[i] = seq[i][lo:hi]
+            return seq
+        arrays = cut(arrays)
+        m = cut(m) if m is not None else None
+        v = cut(v) if v is not None else None
         self.g_p = [torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev).contiguous() for a in arrays]
         self.g_m = [torch.zeros_like(t) if m is None else torch.as_tensor(np.ascontiguousarray(m[i]), dtype=torch.float32).to(dev)
                     for i, t in enumerate(self.g_p)]
@@ -217,6 +235,44 @@ class Engine:
                                  self.stream())
         cabi.check(rc, "ltg_g_step")
         return loss_out
+
+    # ------------------------------------------------------------------ the G step cut at its exchange points
+    def fwd_opts(self, keep_prob=0.75, is_training=0.0, rng_step=0, drop_keep=None, eps=None, probe=None):
+        return cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
+
+    def g_opts(self, cnt, anneal, gan_lambda=1.0, keep_prob=0.75, is_training=1.0, d_keep_prob=0.7, rng_step=0, d_rng_step=0,
+               drop_keep=None, eps=None, drop_fake=None, probe=None):
+        f = self.fwd_opts(keep_prob, is_training, rng_step, drop_keep, eps, probe)
+        df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
+        return cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe))
+
+    def g_fwd_enc(self, batch, acts, fopts):
+        cabi.check(self.lib.ltg_g_fwd_enc(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fopts), C.byref(acts.c),
+                                          self.stream()), "ltg_g_fwd_enc")
+
+    def g_fwd_rest(self, batch, fake, acts, fopts, rowpart_out):
+        cabi.check(self.lib.ltg_g_fwd_rest(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fake.c) if fake else None,
+                                           C.byref(fopts), C.byref(acts.c), _ptr(rowpart_out), self.stream()), "ltg_g_fwd_rest")
+
+    def rowstats_combine(self, rowpart_all, n_ranks, n_rows, lse_out):
+        ws = self.workspace(n_rows, 1)
+        cabi.check(self.lib.ltg_rowstats_combine(C.byref(self.cfg), _ptr(rowpart_all), n_ranks, n_rows, _ptr(lse_out), _ptr(ws), ws.numel(),
+                                                 self.stream()), "ltg_rowstats_combine")
+
+    def g_bwd_dec(self, batch, fake, acts, gopts, rowpart_all, n_ranks, loss_out, dh2_out):
+        ws = self.workspace(batch.n_rows, fake.n)
+        cabi.check(self.lib.ltg_g_bwd_dec(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
+                                          C.byref(gopts), C.byref(acts.c), _ptr(rowpart_all), n_ranks, _ptr(loss_out), _ptr(dh2_out),
+                                          _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_dec")
+
+    def g_bwd_rest(self, batch, fake, acts, gopts, dh2):
+        ws = self.workspace(batch.n_rows, fake.n)
+        cabi.check(self.lib.ltg_g_bwd_rest(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fake.c), C.byref(gopts),
+                                           C.byref(acts.c), _ptr(dh2), _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_rest")
+
+    def gather_cand_logits(self, samp_c, acts, out):
+        cabi.check(self.lib.ltg_gather_cand_logits(C.byref(self.cfg), C.byref(samp_c), _ptr(acts.logits), _ptr(out), self.stream()),
+                   "ltg_gather_cand_logits")
 
     def rank_metrics(self, acts, tr, te, out, k_ndcg=100, k_r1=20, k_r2=50):
         """pred[X.nonzero()] = -inf + NDCG@100 / Recall@20 / Recall@50  -- train.py:341-346."""

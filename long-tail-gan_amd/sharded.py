@@ -1,0 +1,108 @@
+"""Item-sharded multi-GPU training: one process per GPU, rank r owns the item slab
+[item_lo_r, item_hi_r) of W_q0 / W_p1t / b_p1 and their Adam moments plus the matching columns of the
+interaction matrix; the middle layers and the whole discriminator are replicated (identical inputs
+and identical counter-RNG streams give identical values on every rank, no broadcast needed).
+
+Exchange steps per generator step (torch.distributed over RCCL/xGMI; the C ABI never communicates):
+  1. all-reduce(sum)  encoder pre-activation   [B, H]      (240 KB at defaults)
+  2. all-gather       row partials             [B, 5]      (max, sum exp, sum x*logit, sum_S exp, sum x)
+  3. all-reduce(sum)  dh2                      [B, H]
+Phase C adds one all-reduce of the candidates' logits (~12 KB).  The discriminator step is replicated.
+Nothing else crosses ranks: the sharded tables never leave their GPU and need no gradient all-reduce.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .engine import _ptr
+from .trainer import Trainer
+
+
+def item_slab(n_items, rank, world):
+    """contiguous slab boundaries, multiples of 64 items except the last"""
+    per = -(-n_items // world)
+    per = -(-per // 64) * 64
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+class ShardedTrainer(Trainer):
+    def __init__(self, engine, data, group=None, **kw):
+        super().__init__(engine, data, **kw)
+        self.group = group
+        self.R = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        dev = engine.device
+        B = data.max_rows
+        self.rowpart = torch.zeros(B * 5, dtype=torch.float32, device=dev)
+        self.rowpart_all = torch.zeros(self.R * B * 5, dtype=torch.float32, device=dev)
+        self.dh2 = torch.zeros(B, engine.H, dtype=torch.float32, device=dev)
+        self.cand_logit = torch.zeros(max(1, int(data.idx.cand_ptr[-1])), dtype=torch.float32, device=dev)
+
+    # -- collectives -------------------------------------------------------------------------------
+    def _allreduce(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _allgather_rowpart(self, B):
+        n = B * 5
+        out = self.rowpart_all[: self.R * n]
+        src = self.rowpart[:n]
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, src, group=self.group)
+        else:
+            parts = [out[r * n:(r + 1) * n] for r in range(self.R)]
+            dist.all_gather(parts, src, group=self.group)
+        return out
+
+    # -- forward over the shards ---------------------------------------------------------------------
+    def _forward(self, v, fake, fopts):
+        eng, B = self.eng, v["batch"].n_rows
+        eng.g_fwd_enc(v["batch"], self.acts, fopts)
+        self._allreduce(self.acts.h1[:B])
+        eng.g_fwd_rest(v["batch"], fake, self.acts, fopts, self.rowpart)
+        return self._allgather_rowpart(B)
+
+    def create_phase(self):
+        d, eng = self.data, self.eng
+        d.fake_cnt.zero_()
+        for b in range(d.n_batches):
+            v = d.view(b)
+            st = self._step()
+            B = v["batch"].n_rows
+            rp_all = self._forward(v, None, eng.fwd_opts(self.vae_keep, 0.0, st))
+            eng.rowstats_combine(rp_all, self.R, B, self.acts.lse)
+            c0, c1 = int(d.idx.cand_ptr[v["lo"]]), int(d.idx.cand_ptr[v["hi"]])
+            eng.gather_cand_logits(v["samp"], self.acts, self.cand_logit)
+            if c1 > c0:
+                self._allreduce(self.cand_logit[c0:c1])
+            v["samp"].rng_step = st
+            v["samp"].cand_logit = _ptr(self.cand_logit)
+            eng.sample_pairs(v["samp"], self.acts, d.fake_gen, d.fake_pop, d.fake_cnt[b:])
+        cnt = d.fake_cnt.cpu().numpy()
+        self.active = [b for b in range(d.n_batches) if cnt[b] > 0]
+        self.order = np.arange(len(self.active))
+        self.np_rng.shuffle(self.order)          # same seed on every rank -> same order
+        return int((~d.idx.user_ok).sum())
+
+    # d_phase: inherited -- the discriminator step is replicated (identical on every rank)
+
+    def g_phase(self):
+        d, eng = self.data, self.eng
+        self.last_anneal = []
+        for j in range(self.S):
+            a = self.anneal()
+            for k in self.order:
+                b = self.active[k]
+                v = d.view(b)
+                a = self.anneal()
+                self.update_count += 1
+                B = v["batch"].n_rows
+                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step())
+                rp_all = self._forward(v, v["fake"], go.fwd)
+                eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
+                self._allreduce(self.dh2[:B])
+                eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
+            self.last_anneal.append(a)
+        return self.g_losses

@@ -48,7 +48,11 @@ def _histories(rng, n_users, I):
 
 
 def synthetic_index(name, users=None, seed=1234):
-    spec = WORKLOADS[name]
+    """name: "ml20m", "c4" or "custom:<n_items>"."""
+    if name.startswith("custom:"):
+        spec = dict(I=int(name.split(":")[1]), N=1000)
+    else:
+        spec = WORKLOADS[name]
     I = spec["I"]
     N = int(users or spec["N"])
     rng = np.random.default_rng(seed)

@@ -1,0 +1,70 @@
+"""Worker of tests/test_gpu_sharded.py: `torchrun --nproc-per-node 2` on ONE GPU (gloo backend, both
+ranks on cuda:0) -- runs the item-sharded trainer and, on every rank, the unsharded trainer with the
+same seeds, and compares the fake pairs, the loss trajectory and the rank's slab of every tensor."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from ltgan.dataset import DeviceData
+    from ltgan.engine import Engine
+    from ltgan.sharded import ShardedTrainer, item_slab
+    from ltgan.synthetic import synthetic_index
+    from ltgan.trainer import Trainer
+    workload, users, precision = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda:0"
+    idx, _ = synthetic_index(workload, users=users, seed=5)
+    I = idx.n_items
+    hs = (16, 24, 40, 32)
+    S = 2
+    # ---- unsharded reference
+    ref = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev)
+    ref_tr = Trainer(ref, DeviceData(idx, 100, dev), num_sub_epochs=S, shuffle_seed=1)
+    # ---- this rank's shard
+    lo, hi = item_slab(I, rank, world)
+    eng = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi)
+    data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
+    tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1)
+    for epoch in range(2):
+        ref_tr.create_phase()
+        tr.create_phase()
+        torch.cuda.synchronize()
+        assert torch.equal(data.fake_gen, ref_tr.data.fake_gen), "fake pairs differ (epoch %d)" % epoch
+        assert torch.equal(data.fake_pop, ref_tr.data.fake_pop)
+        assert torch.equal(data.fake_cnt, ref_tr.data.fake_cnt)
+        dl_ref = ref_tr.d_phase().cpu().numpy()[:S, 0]
+        dl = tr.d_phase().cpu().numpy()[:S, 0]
+        np.testing.assert_allclose(dl, dl_ref, rtol=1e-6)
+        gl_ref = ref_tr.g_phase().cpu().numpy()[:S, :6]
+        gl = tr.g_phase().cpu().numpy()[:S, :6]
+        tol = 2e-5 if precision == "fp32" else 2e-3
+        np.testing.assert_allclose(gl[:, :2], gl_ref[:, :2], rtol=tol)
+        np.testing.assert_allclose(gl[:, 2:], gl_ref[:, 2:], rtol=10 * tol, atol=1e-6)
+    torch.cuda.synchronize()
+    atol = 2e-6 if precision == "fp32" else 3e-4
+    for i in range(8):
+        want = ref.g_p[i]
+        if i in (0, 3, 7):
+            want = want[lo:hi]
+        err = (eng.g_p[i] - want).abs().max().item()
+        assert err < atol * 50 if i not in (0, 3, 7) else err < atol * 50, ("gen tensor", i, err)
+    for i in range(8):
+        assert (eng.d_p[i] - ref.d_p[i]).abs().max().item() < 1e-6, ("disc tensor", i)
+    assert eng.adam_t == ref.adam_t
+    dist.barrier()
+    if rank == 0:
+        print("SHARDED_OK world=%d workload=%s precision=%s" % (world, workload, precision))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -274,7 +274,7 @@ def test_sampler_matches_oracle(with_zero_probs):
     t = lambda a: torch.from_numpy(a).to(dev)
     d = [t(x) for x in (cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, slot_ptr, valid)]
     step = 77
-    samp = cabi.ltg_sample_inputs(B, int(np.diff(cand_ptr).max()), *[_ptr(x) for x in d], step, None, None)
+    samp = cabi.ltg_sample_inputs(B, int(np.diff(cand_ptr).max()), *[_ptr(x) for x in d], step, None, None, None)
     ns = int(slot_ptr[-1])
     gen = torch.full((ns,), -7, dtype=torch.int32, device=dev)
     pop = torch.full((ns,), -7, dtype=torch.int32, device=dev)
