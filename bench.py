@@ -31,7 +31,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="askubuntu")
+    ap.add_argument("--workload", default=None, help="askubuntu | ml20m | c4 | custom:<items>; default: askubuntu at 1 GPU, c4 (item-sharded) at N > 1")
+    ap.add_argument("--parallelism", default=None, choices=["item-shard", "replicas"], help="default: item-shard when N > 1")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--sub-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=100)
@@ -206,10 +207,39 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from ltgan.engine import Engine
     from ltgan.trainer import Trainer
-    idx, data, desc = load_workload(a.workload, a.batch_size, device, a.users)
-    eng = Engine(idx.n_items, precision=a.precision, device=device)
-    eng.cfg.reserved0 = a.variant
-    tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
+    workload = a.workload or ("askubuntu" if world == 1 else "c4")
+    a.workload = workload
+    mode = a.parallelism or ("item-shard" if world > 1 else "single")
+    if mode == "item-shard" and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)      # exercises the RCCL code path on one GPU
+    idx, data, desc = load_workload(workload, a.batch_size, device, a.users)
+    n1_ref = None
+    if mode == "item-shard":
+        from ltgan.dataset import DeviceData
+        from ltgan.sharded import ShardedTrainer, item_slab
+        if world > 1 and rank == 0:
+            # same workload on ONE GPU, measured in this very job (the other ranks wait): the strong-scaling reference
+            e1 = Engine(idx.n_items, precision=a.precision, device=device)
+            t1 = Trainer(e1, data, num_sub_epochs=a.sub_epochs)
+            t1.epoch()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t1.epoch()
+            torch.cuda.synchronize()
+            n1_ref = data.N / (time.perf_counter() - t0)
+            del e1, t1
+            torch.cuda.empty_cache()
+        lo, hi = item_slab(idx.n_items, rank, world)
+        data = DeviceData(idx, a.batch_size, device, item_lo=lo, item_hi=hi)
+        eng = Engine(idx.n_items, precision=a.precision, device=device, item_lo=lo, item_hi=hi)
+        eng.cfg.reserved0 = a.variant
+        tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs)
+    else:
+        eng = Engine(idx.n_items, precision=a.precision, device=device)
+        eng.cfg.reserved0 = a.variant
+        tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -221,9 +251,12 @@ def main():
         tr.epoch()
     # ---- live per-kernel timing (HIP events recorded by the library around ONE kernel per call)
     prof = KernelProfiler(eng, tr, data, a)
-    calib = prof.calibrate() if rank == 0 else None
-    dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
-    tr.probe_hook = prof.hook(dominant) if dominant else None
+    if mode == "item-shard":
+        calib, dominant = None, "dec1_bwd_adam"        # monolithic probe steps would desynchronise the shards
+    else:
+        calib = prof.calibrate() if rank == 0 else None
+        dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
+    tr.probe_hook = prof.hook(dominant) if (dominant and rank == 0) else None
     barrier()
     t0 = time.perf_counter()
     phases = []
@@ -236,26 +269,40 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    users = data.N * a.steps * world          # replicas: every rank processes the full workload
+    replicas = mode == "replicas" and world > 1
+    users = data.N * a.steps * (world if replicas else 1)   # replicas: every rank processes the full workload
     value = users / dt
     res = {
         "metric": "train users/sec at BATCH_SIZE=%d" % a.batch_size,
         "value": value, "unit": "users/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
         "dtype": a.precision, "data": desc,
         "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
-                   "sub_epochs": a.sub_epochs, "batch_size": a.batch_size, "parallelism": "replicas x%d" % world},
+                   "sub_epochs": a.sub_epochs, "batch_size": a.batch_size,
+                   "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step replicated)" % world)
+                   if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
         "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
     }
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         res["roofline"] = prof.roofline(dominant, calib)
-        res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
-        if not a.no_cpu_baseline:
+        if calib:
+            res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
+        if n1_ref:
+            res["n1_same_workload"] = {"value": n1_ref, "unit": "users/s", "note": "same workload, unsharded, on rank 0's GPU in this job"}
+            res["strong_scaling_vs_1gpu"] = value / n1_ref
+        if not a.no_cpu_baseline and world == 1:
             from oracle.cpu_port import time_cpu_baseline   # oracle/ is only ever the baseline / checker
             res["cpu_baseline"] = time_cpu_baseline(idx, budget_s=a.cpu_seconds, S=a.sub_epochs, batch_size=a.batch_size)
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # RCCL prints its banner through C stdio: get it out BEFORE the JSON line
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -1031,6 +1031,8 @@ struct Probe {
     } while (0)
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? LTG_OK : LTG_ELAUNCH; }
+// hipGetLastError is sticky across unrelated runtime calls of the host program: clear it on entry
+inline void clear_errors() { (void)hipGetLastError(); }
 
 inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return dim3((N + bn - 1) / bn, (M + bm - 1) / bm, z); }
 
@@ -1117,6 +1119,7 @@ size_t ltg_workspace_bytes(const ltg_config* cfg, int32_t max_rows, int32_t max_
 
 int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_fwd_opts* opts,
                     const ltg_gen_acts* acts, float* probs_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
     (void)ws;
     (void)ws_bytes;
     if (!cfg_ok(cfg) || !gen || !batch || !opts || !acts || batch->n_rows < 0) return LTG_EINVAL;
@@ -1128,6 +1131,7 @@ int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
 
 int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, const float* lse,
                      int32_t* gen_out, int32_t* pop_out, int32_t* cnt_out, ltg_stream stream) {
+    clear_errors();
     if (!cfg_ok(cfg) || !in || (!logits && !in->cand_logit) || !lse || !gen_out || !pop_out || !cnt_out) return LTG_EINVAL;
     if (in->n_rows < 0 || in->max_cand < 0) return LTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -1144,6 +1148,7 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
 
 int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real, const ltg_pairs* fake,
                const ltg_d_opts* o, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
     if (!cfg_ok(cfg) || !disc || !real || !fake || !o || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
     const int n = real->n + fake->n;
     if (real->n < 0 || fake->n < 0) return LTG_EINVAL;
@@ -1278,6 +1283,7 @@ static bool g_args_ok(const ltg_config* cfg, const ltg_gen_state* gen, const ltg
 int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
                const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, float* loss_out, void* ws,
                size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
     if (!cfg_ok(cfg) || !gen || !disc || !bt || !fake || !o || !acts || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
     if (!bt->colptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
     const int B = bt->n_rows, nf = fake->n;
@@ -1295,6 +1301,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
 /* ---- the same step cut at its three exchange points (item-sharded multi-GPU; include/ltg.h) ---- */
 int ltg_g_fwd_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* opts,
                   const ltg_gen_acts* acts, ltg_stream stream) {
+    clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !opts) return LTG_EINVAL;
     fwd_stage_enc(cfg, gen, bt, opts, acts, 1, (hipStream_t)stream);
     return check_launch();
@@ -1302,6 +1309,7 @@ int ltg_g_fwd_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_bat
 
 int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,
                    const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, ltg_stream stream) {
+    clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !opts || !rowpart_out) return LTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     fwd_stage_rest(cfg, gen, bt, opts, acts, 1, st);
@@ -1311,6 +1319,7 @@ int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 
 int ltg_rowstats_combine(const ltg_config* cfg, const float* rowpart_all, int32_t n_ranks, int32_t n_rows, float* lse_out,
                          void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
     if (!cfg_ok(cfg) || !rowpart_all || !lse_out || n_ranks < 1 || n_rows < 1 || !ws) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, n_rows, 1) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, n_rows, 1, (char*)ws);
@@ -1322,6 +1331,7 @@ int ltg_rowstats_combine(const ltg_config* cfg, const float* rowpart_all, int32_
 int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
                   const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, const float* rowpart_all,
                   int32_t n_ranks, float* loss_out, float* dh2_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !disc || !fake || !o || !rowpart_all || n_ranks < 1 || !loss_out || !dh2_out || !ws) return LTG_EINVAL;
     if (!o->cnt || !fake->row || fake->n < 0) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
@@ -1331,6 +1341,7 @@ int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_dis
 
 int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,
                    const ltg_g_opts* o, const ltg_gen_acts* acts, const float* dh2, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !fake || !o || !dh2 || !ws || o->adam_t < 1) return LTG_EINVAL;
     if (!bt->colptr || !bt->rowidx || !bt->csr_pos) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
@@ -1339,6 +1350,7 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 }
 
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out, ltg_stream stream) {
+    clear_errors();
     if (!cfg_ok(cfg) || !in || !logits || !out || in->n_rows < 0) return LTG_EINVAL;
     if (in->n_rows == 0) return LTG_OK;
     hipLaunchKernelGGL(k_gather_cand, dim3(in->n_rows), dim3(NT), 0, (hipStream_t)stream, cfg->n_items, cfg->item_lo, in->cand_ptr,
@@ -1348,6 +1360,7 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
 
 int ltg_rank_metrics(const ltg_config* cfg, const float* logits, const ltg_batch* tr, const ltg_batch* te, int32_t k_ndcg,
                      int32_t k_r1, int32_t k_r2, float* out, ltg_stream stream) {
+    clear_errors();
     if (!cfg_ok(cfg) || !logits || !tr || !te || !out || tr->n_rows != te->n_rows || tr->n_rows < 0) return LTG_EINVAL;
     if (tr->n_rows == 0) return LTG_OK;
     const size_t lds = (size_t)((cfg->n_items + 31) / 32) * sizeof(unsigned);

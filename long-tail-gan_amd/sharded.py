@@ -99,7 +99,8 @@ class ShardedTrainer(Trainer):
                 a = self.anneal()
                 self.update_count += 1
                 B = v["batch"].n_rows
-                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step())
+                pr = self.probe_hook("g", b) if self.probe_hook else None
+                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step(), probe=pr)
                 rp_all = self._forward(v, v["fake"], go.fwd)
                 eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
                 self._allreduce(self.dh2[:B])

@@ -4,7 +4,7 @@ path's OUTPUTS are synthesised directly with the same shape statistics as Askubu
 
   * item popularity ~ Zipf(s=1) over I items; history length max(5, round(LogNormal(2.2, 0.9)))
     clipped to min(I/2, 2000); items drawn ~ popularity without replacement;
-  * popular set = top 10 % of items by interaction count, niche = the rest; a user's popular / niche
+  * popular set = the 10 % most popular items of the generating distribution, niche = the rest; a user's popular / niche
     lists = the history split by that set (users missing either list stay invalid, Q8);
   * real pairs: each niche item of a user paired with one of the user's popular items (uniform:
     timing-only stand-in for the max-overlap partner);
@@ -59,10 +59,11 @@ def synthetic_index(name, users=None, seed=1234):
     row, item, pop = _histories(rng, N, I)
     train = sparse.csr_matrix((np.ones(len(row), np.float32), (row, item)), shape=(N, I))
     train.sort_indices()
-    counts = np.bincount(item, minlength=I)
+    # popular set = the 10 % of items with the largest generating popularity (Zipf is monotone in the id);
+    # sample counts would mark every touched item popular when users << items
     n_pop = max(1, I // 10)
     popular = np.zeros(I, bool)
-    popular[np.argsort(-counts, kind="stable")[:n_pop]] = True
+    popular[:n_pop] = True
     is_pop = popular[item]
     indptr = train.indptr
     npop_u = np.add.reduceat(is_pop.astype(np.int64), indptr[:-1]) if len(item) else np.zeros(N, np.int64)

@@ -1,0 +1,55 @@
+"""N>1 path on CPU: world_size-2 gloo run of the item-sharded exchange steps (tests/dist_cpu_worker.py),
+plus the host-side sharding of the data."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gloo_world2_exchange_algebra():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "tests", "dist_cpu_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "DIST_CPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_item_slabs_partition_and_shard_data():
+    from ltgan.dataset import DeviceData
+    from ltgan.sharded import item_slab
+    from ltgan.synthetic import synthetic_index
+    for I, R in ((1000, 8), (200000, 8), (20000, 2), (777, 4)):
+        slabs = [item_slab(I, r, R) for r in range(R)]
+        assert slabs[0][0] == 0 and slabs[-1][1] == I
+        assert all(slabs[i][1] == slabs[i + 1][0] for i in range(R - 1)) and all(hi > lo for lo, hi in slabs)
+    idx, _ = synthetic_index("custom:500", users=230, seed=3)
+    full = DeviceData(idx, 100, "cpu")
+    nnz = 0
+    for r in range(2):
+        lo, hi = item_slab(500, r, 2)
+        d = DeviceData(idx, 100, "cpu", item_lo=lo, item_hi=hi)
+        assert d.I == hi - lo and d.I_global == 500 and d.n_batches == full.n_batches
+        assert np.array_equal(d.row_norm2.numpy(), full.row_norm2.numpy())          # norms are over the FULL row
+        loc = d.local_csr
+        assert loc.shape == (idx.N, hi - lo) and (loc.indices.max() < hi - lo)
+        sub = idx.train[:, lo:hi]
+        assert (loc != sub).nnz == 0
+        nnz += loc.nnz
+        # the per-batch transposed view indexes the LOCAL arrays
+        b = 1
+        v = d.view(b)
+        cp = d.colptr[b * (d.I + 1):(b + 1) * (d.I + 1)].numpy()
+        e0, e1 = d.ent_off[b], d.ent_off[b + 1]
+        assert cp[0] == 0 and cp[-1] == e1 - e0 == loc[v["lo"]:v["hi"]].nnz
+        pos = d.csr_pos[e0:e1].numpy()
+        assert np.all(np.diff(d.indices.numpy()[pos]) >= 0)                              # sorted by local item id
+        assert torch_equal(d.fake_row, full.fake_row) and torch_equal(d.cand_idx, full.cand_idx)   # global lists
+    assert nnz == idx.train.nnz
+
+
+def torch_equal(a, b):
+    import torch
+    return torch.equal(a, b)
