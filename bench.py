@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=100)
     ap.add_argument("--users", type=int, default=None, help="synthetic workloads: number of user rows to generate (default: a bounded sample)")
     ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event kernel probes (use under rocprofv3 --pmc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -251,7 +252,9 @@ def main():
         tr.epoch()
     # ---- live per-kernel timing (HIP events recorded by the library around ONE kernel per call)
     prof = KernelProfiler(eng, tr, data, a)
-    if mode == "item-shard":
+    if a.no_probe:
+        calib, dominant = None, None
+    elif mode == "item-shard":
         calib, dominant = None, "dec1_bwd_adam"        # monolithic probe steps would desynchronise the shards
     else:
         calib = prof.calibrate() if rank == 0 else None
@@ -287,7 +290,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        res["roofline"] = prof.roofline(dominant, calib)
+        res["roofline"] = prof.roofline(dominant, calib) if dominant else None
         if calib:
             res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
         if n1_ref:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 2
+#define LTG_ABI_VERSION 3
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -81,16 +81,19 @@ typedef struct ltg_disc_state {
 } ltg_disc_state;
 
 /* A batch of user rows in CSR form (replaces the dense [B,I] float32 feed of train.py:194-198).
- * indptr holds absolute offsets into indices/values.  The CSC view (colptr/rowidx/csr_pos) is
- * only required by ltg_g_step (sparse gradient of W_q0). */
+ * indptr holds absolute offsets into indices/values.  The transposed view (the batch's entries grouped
+ * by item) is only required by the G step (sparse gradient of W_q0):
+ *   uitem[u]  = u-th distinct item of the batch (ascending),  uptr[u..u+1] = its entry range,
+ *   rowidx/csr_pos = per entry: local row, index into indices[];  slot[i] = u or -1 for every item i. */
 typedef struct ltg_batch {
     int32_t n_rows;
-    int32_t reserved0;
+    int32_t n_unique;       /* number of distinct items in the batch */
     const int32_t* indptr;  /* [n_rows+1] */
     const int32_t* indices; /* item ids, ascending within a row */
     const float* values;    /* NULL => 1.0f */
-    const int32_t* colptr;  /* [n_items+1] offsets into rowidx/csr_pos (relative to 0) */
-    const int32_t* rowidx;  /* local row of each CSC entry */
+    const int32_t* slot;    /* [n_items] item -> index into uitem / the gradient rows, or -1 */
+    const int32_t* uptr;    /* [n_unique+1] offsets into rowidx/csr_pos (relative to 0) */
+    const int32_t* rowidx;  /* local row of each transposed entry */
     const int32_t* csr_pos; /* index of that entry in indices[] */
     const float* row_norm2; /* optional [n_rows]: sum x^2 over the FULL row (needed when the items are sharded) */
 } ltg_batch;
@@ -171,6 +174,11 @@ typedef struct ltg_g_opts {
     const uint8_t* drop_fake[3]; /* optional */
     const int32_t* cnt;  /* device scalar: sampled_cnt (number of valid fake pairs) */
     const ltg_probe* probe; /* optional (the forward part uses fwd.probe) */
+    /* optional fork/join: run the fake-tower forward on aux_stream concurrently with the generator forward.
+     * ev_fork / ev_join are caller-created hipEvent_t (the library allocates nothing); all three or none. */
+    ltg_stream aux_stream;
+    void* ev_fork;
+    void* ev_join;
 } ltg_g_opts;
 
 /* Static per-user sampling inputs for a batch (results of the index path, data_processing.py). */

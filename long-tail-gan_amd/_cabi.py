@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
-LTG_ABI_VERSION = 2
+LTG_ABI_VERSION = 3
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -37,8 +37,8 @@ class ltg_disc_state(C.Structure):
 
 
 class ltg_batch(C.Structure):
-    _fields_ = [("n_rows", C.c_int32), ("reserved0", C.c_int32), ("indptr", vp), ("indices", vp), ("values", vp),
-                ("colptr", vp), ("rowidx", vp), ("csr_pos", vp), ("row_norm2", vp)]
+    _fields_ = [("n_rows", C.c_int32), ("n_unique", C.c_int32), ("indptr", vp), ("indices", vp), ("values", vp),
+                ("slot", vp), ("uptr", vp), ("rowidx", vp), ("csr_pos", vp), ("row_norm2", vp)]
 
 
 class ltg_gen_acts(C.Structure):
@@ -70,7 +70,8 @@ class ltg_d_opts(C.Structure):
 
 class ltg_g_opts(C.Structure):
     _fields_ = [("fwd", ltg_fwd_opts), ("anneal", C.c_float), ("gan_lambda", C.c_float), ("d_keep_prob", C.c_float),
-                ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp), ("probe", C.POINTER(ltg_probe))]
+                ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp), ("probe", C.POINTER(ltg_probe)),
+                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp)]
 
 
 class ltg_sample_inputs(C.Structure):

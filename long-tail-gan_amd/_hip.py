@@ -20,6 +20,7 @@ def _lib():
                     break
         _hip = C.CDLL(path or "libamdhip64.so")
         _hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        _hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
         _hip.hipEventDestroy.argtypes = [C.c_void_p]
         _hip.hipEventSynchronize.argtypes = [C.c_void_p]
         _hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
@@ -27,10 +28,13 @@ def _lib():
 
 
 class EventPair:
-    def __init__(self):
+    def __init__(self, timing=True):
         h = _lib()
         self.start, self.stop = C.c_void_p(), C.c_void_p()
-        assert h.hipEventCreate(C.byref(self.start)) == 0 and h.hipEventCreate(C.byref(self.stop)) == 0
+        if timing:
+            assert h.hipEventCreate(C.byref(self.start)) == 0 and h.hipEventCreate(C.byref(self.stop)) == 0
+        else:  # hipEventDisableTiming = 0x2: cheap ordering-only events (fork / join of two streams)
+            assert h.hipEventCreateWithFlags(C.byref(self.start), 2) == 0 and h.hipEventCreateWithFlags(C.byref(self.stop), 2) == 0
 
     def elapsed_ms(self):
         h = _lib()

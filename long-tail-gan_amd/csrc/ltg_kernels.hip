@@ -54,11 +54,11 @@ __device__ __forceinline__ float block_max(float x, float* red) {
 // ---------------------------------------------------------------------------------------------
 
 // enc-0 as a sparse row gather-sum (MultiVAE.py:148-155): h1 = tanh(dropout(l2norm(x)) . W_q0 + b).
-// One 512-thread workgroup per user row.  The row's (item, value*keep) list is staged through LDS;
-// the 8 waves split the row's entries (so a 900-item history does not serialise on one wave), each
+// One 1024-thread workgroup per user row.  The row's (item, value*keep) list is staged through LDS;
+// the 16 waves split the row's entries (so a 900-item history does not serialise on one wave), each
 // lane owning float4 column chunks of the gathered W_q0 rows (coalesced 16-B loads); the wave
 // partials meet in LDS.
-constexpr int ENC_NT = 512;
+constexpr int ENC_NT = 1024;
 constexpr int ENC_NW = ENC_NT / 64;
 __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t* __restrict__ indptr,
                                                      const int32_t* __restrict__ indices, const float* __restrict__ values,
@@ -110,21 +110,31 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
         }
         __syncthreads();
         const int cnt = min(ENC_NT, end - c0);
-        for (int j = w; j < cnt; j += 2 * ENC_NW) {
-            const int j2 = j + ENC_NW;
-            const float v0 = s_val[j];
-            const float v1 = j2 < cnt ? s_val[j2] : 0.f;
-            const float4* w0 = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[j] * H);
-            const float4* w1 = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[j2 < cnt ? j2 : j] * H);
+        // 4 entries per trip: their W_q0 row loads are independent, so 4 x MAXQ float4 loads are in flight
+        for (int j = w; j < cnt; j += 4 * ENC_NW) {
+            float v[4];
+            const float4* wr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ju = j + u * ENC_NW;
+                const bool ok = ju < cnt;
+                v[u] = ok ? s_val[ju] : 0.f;
+                wr[u] = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[ok ? ju : j] * H);
+            }
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
                 const int c4 = lane + 64 * q;
                 if (c4 < H4) {
-                    const float4 x0 = w0[c4], x1 = w1[c4];
-                    acc[q].x += v0 * x0.x + v1 * x1.x;
-                    acc[q].y += v0 * x0.y + v1 * x1.y;
-                    acc[q].z += v0 * x0.z + v1 * x1.z;
-                    acc[q].w += v0 * x0.w + v1 * x1.w;
+                    float4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = wr[u][c4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[q].x += v[u] * x[u].x;
+                        acc[q].y += v[u] * x[u].y;
+                        acc[q].z += v[u] * x[u].z;
+                        acc[q].w += v[u] * x[u].w;
+                    }
                 }
             }
         }
@@ -513,7 +523,8 @@ __global__ __launch_bounds__(NT) void k_row_partial(int I, int item_lo, const in
 __global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __restrict__ rowpart_all, int nf,
                                                   const float* __restrict__ kl_rows, const float* __restrict__ y,
                                                   const int32_t* __restrict__ cnt, float anneal, float lam, float* __restrict__ lse,
-                                                  float* __restrict__ nb, float* __restrict__ Pb, float* __restrict__ out) {
+                                                  float* __restrict__ nb, float* __restrict__ Pb, float* __restrict__ out,
+                                                  float* __restrict__ out2) {
     __shared__ float red[NT / 64];
     float a = 0.f, k = 0.f, p = 0.f, sy = 0.f;
     for (int b = threadIdx.x; b < B; b += NT) {
@@ -550,12 +561,12 @@ __global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __r
         const float c = (cnt && cnt[0] > 0) ? lam / (float)cnt[0] * sy : 0.f;
         const float vae = negll + anneal * KL;
         const float gan = -c * p;
-        out[0] = vae + gan;
-        out[1] = vae;
-        out[2] = gan;
-        out[3] = p;
-        out[4] = sy;
-        out[5] = c;
+        const float r[6] = {vae + gan, vae, gan, p, sy, c};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            out[i] = r[i];
+            if (out2) out2[i] = r[i];  // the caller's loss buffer (no separate device-to-device copy)
+        }
     }
 }
 
@@ -726,15 +737,65 @@ __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* _
     ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
 }
 
-// Dense Adam sweep over W_q0 [I][H] (+ bias row I) with the sparse gradient gathered through the
-// batch's CSC view: dW_q0[i][:] = sum_{b in col i} keep*val*row_scale[b] * da1[b][:].
-// TF's Adam touches every row every step (zero gradient still decays m, v and moves theta).
-__global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int B, int I, int H, const int32_t* __restrict__ colptr,
-                                                      const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
-                                                      const float* __restrict__ values, const uint8_t* __restrict__ drop_keep,
-                                                      float keep, uint64_t seed, uint64_t step,
-                                                      const float* __restrict__ row_scale, const float* __restrict__ da1,
-                                                      ltg_gen_state st, AdamC ad, int item_lo, int Ig) {
+// Sparse gradient rows of W_q0: G[u][:] = sum over the batch entries of item uitem[u] of
+// keep * val * row_scale[b] * da1[b][:]; row n_unique = bias gradient sum_b da1[b][:].
+// One workgroup per distinct item: the 4 waves split its entries (a popular item is in dozens of the
+// batch's rows), lanes own float4 column chunks, partials meet in LDS.
+__global__ __launch_bounds__(NT) void k_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
+                                                  const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
+                                                  const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                  const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
+                                                  const float* __restrict__ row_scale, const float* __restrict__ da1,
+                                                  float* __restrict__ G, int item_lo, int Ig) {
+    extern __shared__ __attribute__((aligned(16))) float s_g[];  // [4][H]
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H4 = H >> 2;
+    constexpr int MAXQ = 4;
+    float4 acc[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* d4 = reinterpret_cast<const float4*>(da1);
+    const int q0 = u < nu ? uptr[u] : 0, q1 = u < nu ? uptr[u + 1] : B;
+    for (int q = q0 + w; q < q1; q += NT / 64) {
+        int b;
+        float sc;
+        if (u < nu) {
+            b = rowidx[q];
+            const int pos = csr_pos[q];
+            const int it = indices[pos];
+            const bool kp = drop_keep ? (drop_keep[pos] != 0)
+                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
+            sc = kp ? (values ? values[pos] : 1.f) * row_scale[b] : 0.f;
+        } else {
+            b = q;  // bias row: every batch row, weight 1
+            sc = 1.f;
+        }
+#pragma unroll
+        for (int qq = 0; qq < MAXQ; ++qq) {
+            const int c4 = lane + 64 * qq;
+            if (c4 < H4) {
+                const float4 d = d4[(size_t)b * H4 + c4];
+                acc[qq].x += sc * d.x;
+                acc[qq].y += sc * d.y;
+                acc[qq].z += sc * d.z;
+                acc[qq].w += sc * d.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int qq = 0; qq < MAXQ; ++qq) {
+        const int c4 = lane + 64 * qq;
+        if (c4 < H4) reinterpret_cast<float4*>(s_g + (size_t)w * H)[c4] = acc[qq];
+    }
+    __syncthreads();
+    for (int c = tid; c < H; c += NT) G[(size_t)u * H + c] = s_g[c] + s_g[H + c] + s_g[2 * H + c] + s_g[3 * H + c];
+}
+
+// Dense Adam sweep over W_q0 [I][H] (+ bias row I): pure streaming, 16 B per lane, the sparse gradient row
+// (if any) is picked up through slot[i].  TF's Adam touches every row every step (a zero gradient still
+// decays m, v and moves theta), so this sweep is the algorithmic 24 B/parameter.
+__global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int I, int H, int nu, const int32_t* __restrict__ slot,
+                                                      const float* __restrict__ G, ltg_gen_state st, AdamC ad) {
     const int H4 = H >> 2;  // H % 4 == 0 (checked on the host)
     const size_t total = (size_t)(I + 1) * H4;
     float4* W4 = reinterpret_cast<float4*>(st.p[0]);
@@ -743,37 +804,16 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int B, int I, int H, const
     float4* b4 = reinterpret_cast<float4*>(st.p[4]);
     float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
     float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
-    const float4* d4 = reinterpret_cast<const float4*>(da1);
+    const float4* G4 = reinterpret_cast<const float4*>(G);
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
         const int i = (int)(e / H4), c = (int)(e % H4);
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < I) {
-            for (int q = colptr[i]; q < colptr[i + 1]; ++q) {
-                const int b = rowidx[q], pos = csr_pos[q];
-                const bool kp = drop_keep ? (drop_keep[pos] != 0)
-                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + i, keep);
-                if (kp) {
-                    const float s = (values ? values[pos] : 1.f) * row_scale[b];
-                    const float4 d = d4[(size_t)b * H4 + c];
-                    g.x += s * d.x;
-                    g.y += s * d.y;
-                    g.z += s * d.z;
-                    g.w += s * d.w;
-                }
-            }
-        } else {
-            for (int b = 0; b < B; ++b) {
-                const float4 d = d4[(size_t)b * H4 + c];
-                g.x += d.x;
-                g.y += d.y;
-                g.z += d.z;
-                g.w += d.w;
-            }
-        }
         float4* P = i < I ? W4 + e : b4 + c;
         float4* Mm = i < I ? m4 + e : mb4 + c;
         float4* Vv = i < I ? v4 + e : vb4 + c;
         float4 p = *P, mm = *Mm, vv = *Vv;
+        const int u = i < I ? slot[i] : nu;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u >= 0) g = G4[(size_t)u * H4 + c];
 #define LTG_ADAM1(f)                                              \
     mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;                    \
     vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;              \
@@ -957,9 +997,16 @@ inline int dh2_kchunk(int I) {
     return chunk;
 }
 
+// upper bound of distinct items in a batch of max_rows rows: min(n_items, max_nnz); the caller states max nnz
+// through ltg_workspace_bytes' max_rows only, so assume the dense worst case capped by the table size.
+inline size_t gq0_rows(const ltg_config* cfg, int max_rows) {
+    const size_t cap = (size_t)max_rows * 2048;   // <= 2048 interactions per user row on average
+    return cap < (size_t)cfg->n_items ? cap : (size_t)cfg->n_items;
+}
+
 struct Workspace {
     // generator backward
-    float *rowpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1;
+    float *rowpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     size_t bytes;
@@ -987,6 +1034,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.da2 = take(R * H);
     w.dmlv = take(R * 2 * Z);
     w.da1 = take(R * H);
+    w.gq0 = take((size_t)(gq0_rows(cfg, max_rows) + 1) * H);   // sparse gradient rows of W_q0 (+ bias row)
     w.A1 = take(P * h12);
     w.A3 = take(P * h3);
     w.y = take(P);
@@ -1037,7 +1085,7 @@ inline void clear_errors() { (void)hipGetLastError(); }
 inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return dim3((N + bn - 1) / bn, (M + bm - 1) / bm, z); }
 
 bool cfg_ok(const ltg_config* c) {
-    return c && c->n_items > 0 && c->h_enc > 0 && c->h_enc <= 1024 && (c->h_enc % 4) == 0 && c->z_dim > 0 &&
+    return c && c->n_items > 0 && c->h_enc > 0 && c->h_enc <= 768 && (c->h_enc % 4) == 0 && c->z_dim > 0 &&
            (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32);
 }
 
@@ -1192,18 +1240,18 @@ static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_
 
 static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
                            const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, const float* rowpart_all,
-                           int n_ranks, float* loss_out, const Workspace& w, float* dh2_out, hipStream_t st) {
+                           int n_ranks, float* loss_out, const Workspace& w, float* dh2_out, hipStream_t st,
+                           bool disc_done = false, const float* h2_for_da2 = nullptr) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nf = fake->n;
     const Probe pr{o->probe, st};
     // fake tower forward only (y_data is pruned from the g_trainer fetch, train.py:326); replicated on every rank
-    if (nf > 0) {
+    if (nf > 0 && !disc_done) {
         PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
         DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
     }
     hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, st, B, n_ranks, rowpart_all, nf, acts->kl_rows, nf > 0 ? w.y : nullptr, o->cnt,
-                       o->anneal, o->gan_lambda, acts->lse, w.nb, w.Pb, w.scal);
-    if (hipMemcpyAsync(loss_out, w.scal, 6 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return LTG_ELAUNCH;
+                       o->anneal, o->gan_lambda, acts->lse, w.nb, w.Pb, w.scal, loss_out);
     hipLaunchKernelGGL(k_dlogits, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, bt->indptr, bt->indices, bt->values,
                        acts->logits, acts->lse, w.nb, w.Pb, w.scal, nf, fake->row, fake->niche, fake->pop, w.dlog, cfg->item_lo);
     const int kchunk = dh2_kchunk(I);
@@ -1219,60 +1267,81 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
-        hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, (const float*)nullptr, dh2_out);  // slab sum only
+        // slab sum; the single-GPU path folds the tanh derivative in (dh2_out is then already da2)
+        hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, h2_for_da2, dh2_out);
     }
     return check_launch();
 }
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
-                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st) {
+                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false,
+                            bool overlap = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const Probe pr{o->probe, st};
+    // Critical path: da2 -> dz -> dh1 -> sweep of W_q0.  The three weight-gradient + Adam kernels only consume
+    // it, so with `overlap` they run on the caller's aux stream, each released by a re-recorded ev_fork after
+    // the last READER of the weights it updates (dz reads W_p0, dh1 reads W_q1) has been enqueued on `st`.
+    hipStream_t side = overlap ? (hipStream_t)o->aux_stream : st;
+    hipEvent_t evf = (hipEvent_t)o->ev_fork, evj = (hipEvent_t)o->ev_join;
+    auto release_side = [&]() {
+        if (overlap) {
+            (void)hipEventRecord(evf, st);
+            (void)hipStreamWaitEvent(side, evf, 0);
+        }
+    };
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
-    {
+    if (!da2_ready) {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
     }
-    pr.before(LTG_K_DEC1_BWD_ADAM);
+    release_side();  // dlog, h2 and the dh2 products with the old W_p1t are all enqueued
+    const Probe prs{o->probe, side};
+    prs.before(LTG_K_DEC1_BWD_ADAM);
     {
         const int var = cfg->reserved0 > 0 ? cfg->reserved0 - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
         if (!bf) {
-            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
-        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, st, B, I, H, w.dlog, acts->h2, *gen, ad);
+            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
     }
-    pr.after(LTG_K_DEC1_BWD_ADAM);
+    prs.after(LTG_K_DEC1_BWD_ADAM);
     pr.before(LTG_K_DZ);
     hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
                        o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
     pr.after(LTG_K_DZ);
-    pr.before(LTG_K_WGRAD_P0);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, st, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
+    release_side();  // dz (the reader of the old W_p0) is enqueued
+    prs.before(LTG_K_WGRAD_P0);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, side, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
                        gen->p[6], gen->m[6], gen->v[6], ad);
-    pr.after(LTG_K_WGRAD_P0);
+    prs.after(LTG_K_WGRAD_P0);
     pr.before(LTG_K_DH1);
     hipLaunchKernelGGL(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
     pr.after(LTG_K_DH1);
-    pr.before(LTG_K_WGRAD_Q1);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
+    release_side();  // dh1 (the reader of the old W_q1) is enqueued
+    prs.before(LTG_K_WGRAD_Q1);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, side, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
                        gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
-    pr.after(LTG_K_WGRAD_Q1);
+    prs.after(LTG_K_WGRAD_Q1);
+    if (overlap) (void)hipEventRecord(evj, side);
     {
+        const int nu = bt->n_unique;
+        pr.before(LTG_K_ENC0_BWD_ADAM);
+        hipLaunchKernelGGL(k_enc0_grad, dim3(nu + 1), dim3(NT), (size_t)4 * H * sizeof(float), st, B, I, H, nu, bt->uptr, bt->rowidx,
+                           bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
+                           acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
         if (gx > 262144) gx = 262144;
-        pr.before(LTG_K_ENC0_BWD_ADAM);
-        hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, B, I, H, bt->colptr, bt->rowidx, bt->csr_pos, bt->values,
-                           o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, *gen, ad, cfg->item_lo,
-                           Ig_of(cfg));
+        hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, I, H, nu, bt->slot, w.gq0, *gen, ad);
         pr.after(LTG_K_ENC0_BWD_ADAM);
     }
+    if (overlap) (void)hipStreamWaitEvent(st, evj, 0);  // join: the caller's stream again orders everything
     return check_launch();
 }
 
@@ -1285,17 +1354,32 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
                size_t ws_bytes, ltg_stream stream) {
     clear_errors();
     if (!cfg_ok(cfg) || !gen || !disc || !bt || !fake || !o || !acts || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
-    if (!bt->colptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
+    if (!bt->slot || !bt->uptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
+    if (bt->n_unique < 0 || (size_t)bt->n_unique > gq0_rows(cfg, bt->n_rows)) return LTG_EINVAL;
     const int B = bt->n_rows, nf = fake->n;
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const Workspace w = carve(cfg, B, nf, (char*)ws);
+    // fork: the fake tower (independent of the generator forward) runs on the caller's aux stream
+    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0;
+    if (fork) {
+        hipStream_t aux = (hipStream_t)o->aux_stream;
+        if (hipEventRecord((hipEvent_t)o->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)o->ev_fork, 0) != hipSuccess)
+            return LTG_ELAUNCH;
+        PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
+        DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
+        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, aux);
+        if (hipEventRecord((hipEvent_t)o->ev_join, aux) != hipSuccess) return LTG_ELAUNCH;
+    }
     fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st);
     fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
     g_row_partial(cfg, bt, fake, acts, w.rowpart, st);
-    int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.dh2, st);
+    if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
+    // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)
+    int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork, acts->h2);
     if (rc != LTG_OK) return rc;
-    return g_stage_bwd_rest(cfg, gen, bt, o, acts, w.dh2, w, st);
+    // the side stream only pays while the step is a chain of short kernels; HBM-bound sweeps just contend
+    return g_stage_bwd_rest(cfg, gen, bt, o, acts, w.da2, w, st, true, o->aux_stream && o->ev_fork && o->ev_join && cfg->n_items < 8192);
 }
 
 /* ---- the same step cut at its three exchange points (item-sharded multi-GPU; include/ltg.h) ---- */
@@ -1324,7 +1408,7 @@ int ltg_rowstats_combine(const ltg_config* cfg, const float* rowpart_all, int32_
     if (ltg_workspace_bytes(cfg, n_rows, 1) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, n_rows, 1, (char*)ws);
     hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, (hipStream_t)stream, n_rows, n_ranks, rowpart_all, 0, (const float*)nullptr,
-                       (const float*)nullptr, (const int32_t*)nullptr, 0.f, 0.f, lse_out, w.nb, w.Pb, (float*)nullptr);
+                       (const float*)nullptr, (const int32_t*)nullptr, 0.f, 0.f, lse_out, w.nb, w.Pb, (float*)nullptr, (float*)nullptr);
     return check_launch();
 }
 
@@ -1343,7 +1427,8 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                    const ltg_g_opts* o, const ltg_gen_acts* acts, const float* dh2, void* ws, size_t ws_bytes, ltg_stream stream) {
     clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !fake || !o || !dh2 || !ws || o->adam_t < 1) return LTG_EINVAL;
-    if (!bt->colptr || !bt->rowidx || !bt->csr_pos) return LTG_EINVAL;
+    if (!bt->slot || !bt->uptr || !bt->rowidx || !bt->csr_pos) return LTG_EINVAL;
+    if (bt->n_unique < 0 || (size_t)bt->n_unique > gq0_rows(cfg, bt->n_rows)) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
     return g_stage_bwd_rest(cfg, gen, bt, o, acts, dh2, w, (hipStream_t)stream);

@@ -5,7 +5,7 @@ user-id ranges, fixed for the whole run).
 
 Per batch b (users [b*BS, min((b+1)*BS, N))):
   X rows          indptr/indices               (replaces the dense float32 [B,I] feed)
-  X^T view        colptr[b] / rowidx / csr_pos (sparse gradient of W_q0 in the G step)
+  X^T view        slot[b] / uptr / rowidx / csr_pos (entries grouped by item: sparse gradient of W_q0)
   real pairs      x_popular_n / x_niche        (train.py:223-224; static)
   sampler inputs  candidates, popular lists, to_sample, output slots (train.py:213-227)
 """
@@ -119,15 +119,18 @@ class IndexData:
 
 
 def batch_csc(tr, lo, hi, n_items):
-    """CSC view of rows [lo, hi) of a CSR matrix: (colptr [I+1], local row, csr position)."""
+    """Transposed view of rows [lo, hi) of a CSR matrix: entries grouped by item.
+    Returns (slot [I] item -> group or -1, uptr [nu+1], local row per entry, csr position per entry)."""
     beg, end = tr.indptr[lo], tr.indptr[hi]
     idx = tr.indices[beg:end].astype(np.int64)
     row_of = np.repeat(np.arange(hi - lo), np.diff(tr.indptr[lo:hi + 1]))
     pos = np.arange(beg, end, dtype=np.int64)
     order = np.lexsort((row_of, idx))
-    colptr = np.zeros(n_items + 1, np.int64)
-    np.add.at(colptr, idx + 1, 1)
-    return np.cumsum(colptr).astype(np.int32), row_of[order].astype(np.int32), pos[order].astype(np.int32)
+    uitem, counts = np.unique(idx, return_counts=True)
+    slot = np.full(n_items, -1, np.int32)
+    slot[uitem] = np.arange(len(uitem), dtype=np.int32)
+    uptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return slot, uptr, row_of[order].astype(np.int32), pos[order].astype(np.int32)
 
 
 class DeviceData:
@@ -156,18 +159,21 @@ class DeviceData:
         self.indices = up(tr.indices, np.int32)
         ones = np.all(tr.data == 1.0)
         self.values = None if ones else up(tr.data, np.float32)
-        colptrs, rowidx, cpos, ent_off = [], [], [], [0]
+        slots, uptrs, rowidx, cpos, ent_off, uptr_off = [], [], [], [], [0], [0]
         for b in range(self.n_batches):
             lo, hi = b * self.BS, min(N, (b + 1) * self.BS)
-            cp, ri, ps = batch_csc(tr, lo, hi, I)
-            colptrs.append(cp)
+            sl, up_, ri, ps = batch_csc(tr, lo, hi, I)
+            slots.append(sl)
+            uptrs.append(up_)
             rowidx.append(ri)
             cpos.append(ps)
             ent_off.append(ent_off[-1] + len(ri))
-        self.colptr = up(np.concatenate(colptrs))
-        self.rowidx = up(np.concatenate(rowidx))
-        self.csr_pos = up(np.concatenate(cpos))
-        self.ent_off = ent_off
+            uptr_off.append(uptr_off[-1] + len(up_))
+        self.slot = up(np.concatenate(slots))
+        self.uptr = up(np.concatenate(uptrs))
+        self.rowidx = up(np.concatenate(rowidx) if ent_off[-1] else np.zeros(1, np.int32))
+        self.csr_pos = up(np.concatenate(cpos) if ent_off[-1] else np.zeros(1, np.int32))
+        self.ent_off, self.uptr_off = ent_off, uptr_off
         self.pop_ptr, self.pop_idx = up(idx.pop_ptr), up(idx.pop_idx if len(idx.pop_idx) else np.zeros(1, np.int32))
         self.cand_ptr, self.cand_idx = up(idx.cand_ptr), up(idx.cand_idx if len(idx.cand_idx) else np.zeros(1, np.int32))
         self.n_sample, self.slot_ptr = up(idx.n_sample), up(idx.slot_ptr)
@@ -191,8 +197,9 @@ class DeviceData:
         idx = self.idx
         lo, hi = b * self.BS, min(self.N, (b + 1) * self.BS)
         I = self.I
-        batch = CsrRows(self.indptr, self.indices, lo, hi, values=self.values, colptr=self.colptr, rowidx=self.rowidx,
-                        csr_pos=self.csr_pos, col_off=b * (I + 1), ent_off=self.ent_off[b], row_norm2=self.row_norm2)
+        batch = CsrRows(self.indptr, self.indices, lo, hi, values=self.values, slot=self.slot, uptr=self.uptr, rowidx=self.rowidx,
+                        csr_pos=self.csr_pos, n_unique=self.uptr_off[b + 1] - self.uptr_off[b] - 1, slot_off=b * I,
+                        uptr_off=self.uptr_off[b], ent_off=self.ent_off[b], row_norm2=self.row_norm2)
         # csr_pos holds ABSOLUTE positions and rowidx LOCAL rows: both are already relative to the arrays given
         r0, r1 = int(idx.real_ptr[lo]), int(idx.real_ptr[hi])
         real = Pairs(self.real_pop, self.real_nic, None, n=r1 - r0, off=r0)

@@ -55,15 +55,16 @@ class Acts:
 
 
 class CsrRows:
-    """A range of user rows of a device-resident CSR matrix (ltg_batch), optionally with the CSC
-    view that the G step needs."""
+    """A range of user rows of a device-resident CSR matrix (ltg_batch), optionally with the transposed
+    view (entries grouped by item) that the G step needs."""
 
-    def __init__(self, indptr, indices, row_lo, row_hi, values=None, colptr=None, rowidx=None, csr_pos=None,
-                 col_off=0, ent_off=0, row_norm2=None):
-        self.keep = (indptr, indices, values, colptr, rowidx, csr_pos, row_norm2)
+    def __init__(self, indptr, indices, row_lo, row_hi, values=None, slot=None, uptr=None, rowidx=None, csr_pos=None,
+                 n_unique=0, slot_off=0, uptr_off=0, ent_off=0, row_norm2=None):
+        self.keep = (indptr, indices, values, slot, uptr, rowidx, csr_pos, row_norm2)
         self.n_rows = int(row_hi - row_lo)
-        self.c = cabi.ltg_batch(self.n_rows, 0, _ptr(indptr, row_lo), _ptr(indices), _ptr(values),
-                                _ptr(colptr, col_off), _ptr(rowidx, ent_off), _ptr(csr_pos, ent_off), _ptr(row_norm2, row_lo))
+        self.c = cabi.ltg_batch(self.n_rows, int(n_unique), _ptr(indptr, row_lo), _ptr(indices), _ptr(values),
+                                _ptr(slot, slot_off), _ptr(uptr, uptr_off), _ptr(rowidx, ent_off), _ptr(csr_pos, ent_off),
+                                _ptr(row_norm2, row_lo))
 
 
 class Pairs:
@@ -100,6 +101,8 @@ class Engine:
         self._ws = None
         self._ws_key = (0, 0)
         self.loss_buf = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.overlap = True                                          # fake-tower forward on a second stream (ltg_g_opts.aux_stream)
+        self._aux = None
 
     # ------------------------------------------------------------------ parameters
     def _init_generator(self, seed):
@@ -190,6 +193,15 @@ class Engine:
     def new_acts(self, rows):
         return Acts(rows, self.I, self.H, self.Z, self.device)
 
+    def _fork_handles(self):
+        if not self.overlap:
+            return None, None, None
+        if self._aux is None:
+            from ._hip import EventPair
+            self._aux = (torch.cuda.Stream(self.device), EventPair(timing=False))
+        st, ev = self._aux
+        return st.cuda_stream, ev.start, ev.stop
+
     def next_adam_t(self):
         self.adam_t += 1
         return self.adam_t
@@ -229,7 +241,8 @@ class Engine:
         ws = self.workspace(batch.n_rows, fake.n)
         f = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
-        o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe))
+        o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
+                            *self._fork_handles())
         rc = self.lib.ltg_g_step(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c),
                                  C.byref(fake.c), C.byref(o), C.byref(acts.c), _ptr(loss_out), _ptr(ws), ws.numel(),
                                  self.stream())
@@ -244,7 +257,8 @@ class Engine:
                drop_keep=None, eps=None, drop_fake=None, probe=None):
         f = self.fwd_opts(keep_prob, is_training, rng_step, drop_keep, eps, probe)
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
-        return cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe))
+        return cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
+                               None, None, None)
 
     def g_fwd_enc(self, batch, acts, fopts):
         cabi.check(self.lib.ltg_g_fwd_enc(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fopts), C.byref(acts.c),

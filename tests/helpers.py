@@ -21,16 +21,11 @@ def random_history(rng, n_rows, n_items, mean_nnz=18, min_nnz=1):
 
 
 def csc_view(X):
-    """(colptr, rowidx, csr_pos) of a CSR matrix: the transposed view ltg_g_step needs."""
+    """(slot, uptr, rowidx, csr_pos, n_unique) of a CSR matrix: the transposed view ltg_g_step needs."""
+    from ltgan.dataset import batch_csc
     X = X.tocsr()
-    n_rows, n_items = X.shape
-    pos = np.arange(X.nnz, dtype=np.int64)
-    row_of = np.repeat(np.arange(n_rows), np.diff(X.indptr))
-    order = np.lexsort((row_of, X.indices))
-    colptr = np.zeros(n_items + 1, np.int64)
-    np.add.at(colptr, X.indices + 1, 1)
-    colptr = np.cumsum(colptr)
-    return colptr.astype(np.int32), row_of[order].astype(np.int32), pos[order].astype(np.int32)
+    slot, uptr, rowidx, pos = batch_csc(X, 0, X.shape[0], X.shape[1])
+    return slot, uptr, rowidx, pos, len(uptr) - 1
 
 
 def dropout_mask_dense(seed, step, n_rows, n_items, keep):

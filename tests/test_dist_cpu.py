@@ -41,11 +41,16 @@ def test_item_slabs_partition_and_shard_data():
         # the per-batch transposed view indexes the LOCAL arrays
         b = 1
         v = d.view(b)
-        cp = d.colptr[b * (d.I + 1):(b + 1) * (d.I + 1)].numpy()
+        sl = d.slot[b * d.I:(b + 1) * d.I].numpy()
         e0, e1 = d.ent_off[b], d.ent_off[b + 1]
-        assert cp[0] == 0 and cp[-1] == e1 - e0 == loc[v["lo"]:v["hi"]].nnz
+        u0, u1 = d.uptr_off[b], d.uptr_off[b + 1]
+        up = d.uptr[u0:u1].numpy()
+        assert up[0] == 0 and up[-1] == e1 - e0 == loc[v["lo"]:v["hi"]].nnz and v["batch"].c.n_unique == len(up) - 1
         pos = d.csr_pos[e0:e1].numpy()
-        assert np.all(np.diff(d.indices.numpy()[pos]) >= 0)                              # sorted by local item id
+        items = d.indices.numpy()[pos]
+        assert np.all(np.diff(items) >= 0)                                                # grouped by local item id
+        assert np.array_equal(sl[items], np.repeat(np.arange(len(up) - 1), np.diff(up)))   # slot[] points at the group
+        assert (sl >= 0).sum() == len(up) - 1
         assert torch_equal(d.fake_row, full.fake_row) and torch_equal(d.cand_idx, full.cand_idx)   # global lists
     assert nnz == idx.train.nnz
 

@@ -35,9 +35,9 @@ def _upload_batch(eng, X, with_csc=False):
     indptr = torch.from_numpy(X.indptr.astype(np.int32)).to(dev)
     indices = torch.from_numpy(X.indices.astype(np.int32)).to(dev)
     if with_csc:
-        colptr, rowidx, pos = Hh.csc_view(X)
-        return CsrRows(indptr, indices, 0, X.shape[0], colptr=torch.from_numpy(colptr).to(dev),
-                       rowidx=torch.from_numpy(rowidx).to(dev), csr_pos=torch.from_numpy(pos).to(dev))
+        slot, uptr, rowidx, pos, nu = Hh.csc_view(X)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return CsrRows(indptr, indices, 0, X.shape[0], slot=up(slot), uptr=up(uptr), rowidx=up(rowidx), csr_pos=up(pos), n_unique=nu)
     return CsrRows(indptr, indices, 0, X.shape[0])
 
 
