@@ -187,7 +187,13 @@ class KernelProfiler:
             ach, peak, unit, bound = by / (avg * 1e-3) / 1e9, PEAK["hbm"] / 1e9, "GB/s", "hbm"
         else:
             ach, peak, unit, bound = fl / (avg * 1e-3) / 1e12, peak_f / 1e12, "TFLOP/s", "mfma"
-        return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+        traffic = None
+        try:   # PMC-derived HBM bytes per launch of this kernel on this workload, measured offline (profiles/README.md)
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                traffic = json.load(f)["workloads"][self.a.workload][name]["traffic_bytes"]
+        except Exception:
+            pass
+        return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                 "avg_us": avg * 1e3, "launches_timed": len(ms), "algorithmic_flops": fl, "algorithmic_bytes": by,
                 "note": "dominant kernel = largest (avg duration x launches per step) among the probed kernels"}
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 3
+#define LTG_ABI_VERSION 4
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -69,6 +69,11 @@ typedef struct ltg_gen_state {
     float* p[8];
     float* m[8];
     float* v[8];
+    /* optional bf16 shadow of W_p1t: [n_items][608] bf16 (row = item, K zero-padded to 608), rebuilt by
+     * ltg_refresh_shadow and kept in step by the Adam epilogue of the G step.  When present (and n_items >=
+     * 8192, n_items % 8 == 0, bf16 precision, <= 128 rows) the decoder forward and the dh2 product stream it
+     * (1216 B/item instead of 2400 B/item).  NULL: the fp32 rows are converted on the fly. */
+    uint16_t* wp1t_bf16;
 } ltg_gen_state;
 
 /* Discriminator: emb is read-only (discriminator.py:14 is not in d_params, :47).
@@ -257,6 +262,8 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                    ltg_stream stream);
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out,
                            ltg_stream stream);
+/* (re)build gen->wp1t_bf16 from gen->p[3] (after initialisation or after loading weights). */
+int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream);
 
 /* Ranking metrics on device: replaces pred[X.nonzero()] = -inf (Codes/train.py:341) +
  * NDCG_binary_at_k_batch / Recall_at_k_batch (Codes/eval_functions.py:11-62).

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
-LTG_ABI_VERSION = 3
+LTG_ABI_VERSION = 4
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -29,7 +29,7 @@ class ltg_config(C.Structure):
 
 
 class ltg_gen_state(C.Structure):
-    _fields_ = [("p", vp * 8), ("m", vp * 8), ("v", vp * 8)]
+    _fields_ = [("p", vp * 8), ("m", vp * 8), ("v", vp * 8), ("wp1t_bf16", vp)]
 
 
 class ltg_disc_state(C.Structure):
@@ -103,6 +103,7 @@ SYMBOLS = {
     "ltg_g_bwd_rest": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pairs),
                                  C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
     "ltg_gather_cand_logits": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp]),
+    "ltg_refresh_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,
                                    C.c_int32, C.c_int32, vp, vp]),
 }

@@ -209,6 +209,211 @@ __global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const floa
     ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Streaming decoder kernels for large item counts (training batch <= 128 rows, H <= 608, bf16 MFMA).
+// Both read W_p1t exactly once from HBM with 16-B loads, convert to bf16 on the fly into a double-
+// buffered LDS tile of 32 items, and keep the small operand stationary in registers:
+//   k_dec1_fwd_stream : h2 fragments stationary (each of the 8 waves owns 16 batch rows),
+//                       logits[b][i] = h2[b][:] . W_p1t[i][:] + b_p1[i]
+//   k_dh2_stream      : the [16 rows x 608] accumulator of each wave stationary over its item chunk,
+//                       dh2[b][:] += dlog[b][i] * W_p1t[i][:]; W is consumed TRANSPOSED straight from its
+//                       row-major LDS image by ds_read_b64_tr_b16 (no transposing stores)
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short ltg_s16x4;
+constexpr int ST_NT = 512;      // 8 waves
+constexpr int ST_BN = 32;       // items per LDS tile
+constexpr int ST_KP = 608;      // K padded to 19 x 32
+constexpr int ST_LDW = 616;     // LDS row stride in bf16 (1232 B: 16-B aligned rows, conflict-free fragment reads)
+constexpr int ST_KS = ST_KP / 32;
+
+__device__ __forceinline__ uint2 ltg_pack4(float4 v) {
+    return make_uint2((unsigned)ltg_f2bf(v.x) | ((unsigned)ltg_f2bf(v.y) << 16), (unsigned)ltg_f2bf(v.z) | ((unsigned)ltg_f2bf(v.w) << 16));
+}
+
+// The streaming kernels read the bf16 SHADOW of W_p1t ([I][ST_KP] bf16, K padded with zeros, maintained by the
+// Adam epilogue of k_dec1_bwd_adam): 1216 B per item instead of 2400, no conversion on the hot path.
+// global -> registers for one 32-item tile: 16 threads walk one item row in 256-B steps, 5 x 16 B per thread.
+constexpr int ST_C16 = ST_KP * 2 / 16;  // 76 16-byte chunks per shadow row
+// (five named members, not an array: a conditionally written register array is demoted to scratch)
+typedef __attribute__((ext_vector_type(4))) unsigned int ltg_u32x4;  // native vector: stays in VGPRs (HIP's uint4 is a union struct)
+struct StW {
+    ltg_u32x4 a, b, c, d, e;
+};
+__device__ __forceinline__ void st_fetch_w(const unsigned short* __restrict__ Wb, int I, int i0, StW& r) {
+    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    const ltg_u32x4* row = reinterpret_cast<const ltg_u32x4*>(Wb + (size_t)min(i0 + it, I - 1) * ST_KP);
+    r.a = row[c0];
+    r.b = row[c0 + 16];
+    r.c = row[c0 + 32];
+    r.d = row[c0 + 48];
+    r.e = row[min(c0 + 64, ST_C16 - 1)];
+}
+__device__ __forceinline__ void st_stash_w(unsigned short* __restrict__ Wl, const StW& r) {
+    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    ltg_u32x4* row = reinterpret_cast<ltg_u32x4*>(Wl + it * ST_LDW);
+    row[c0] = r.a;
+    row[c0 + 16] = r.b;
+    row[c0 + 32] = r.c;
+    row[c0 + 48] = r.d;
+    if (c0 + 64 < ST_C16) row[c0 + 64] = r.e;
+}
+
+__global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, const float* __restrict__ h2,
+                                                           const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
+                                                           float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup)
+    ltg_bf16x8 af[ST_KS];
+    {
+        const int row = 16 * w + lr;
+        const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)min(row, M - 1) * H);
+        const int H4 = H >> 2;
+#pragma unroll
+        for (int ks = 0; ks < ST_KS; ++ks) {
+            const int c4 = ks * 8 + 2 * lq;
+            const float4 x0 = hr[min(c4, H4 - 1)], x1 = hr[min(c4 + 1, H4 - 1)];
+            const bool ok0 = row < M && c4 < H4, ok1 = row < M && c4 + 1 < H4;
+            ltg_u16x8 t;
+            t[0] = ok0 ? ltg_f2bf(x0.x) : 0; t[1] = ok0 ? ltg_f2bf(x0.y) : 0; t[2] = ok0 ? ltg_f2bf(x0.z) : 0; t[3] = ok0 ? ltg_f2bf(x0.w) : 0;
+            t[4] = ok1 ? ltg_f2bf(x1.x) : 0; t[5] = ok1 ? ltg_f2bf(x1.y) : 0; t[6] = ok1 ? ltg_f2bf(x1.z) : 0; t[7] = ok1 ? ltg_f2bf(x1.w) : 0;
+            af[ks] = __builtin_bit_cast(ltg_bf16x8, t);
+        }
+    }
+    const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x;
+    StW r0, r1;
+    int t = blockIdx.x, cur = 0;
+    if (t < ntiles) {
+        st_fetch_w(Wb, I, t * ST_BN, r0);
+        st_stash_w(st_lds, r0);
+    }
+    if (t + G < ntiles) st_fetch_w(Wb, I, (t + G) * ST_BN, r1);
+    __syncthreads();
+    // ST_STEP(RL, RS): LDS[cur] holds tile t, RS holds tile t+G (in flight since the previous step); tile t+2G
+    // is requested into RL, so two tiles of HBM loads are always outstanding per workgroup.  (A macro, not a
+    // lambda: register arrays captured by reference end up in scratch.)
+#define ST_STEP(RL, RS)                                                                                                         \
+    {                                                                                                                           \
+        if (t + 2 * G < ntiles) st_fetch_w(Wb, I, (t + 2 * G) * ST_BN, RL);                                                     \
+        const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
+        ltg_f32x4 acc0 = ltg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = ltg_f32x4{0.f, 0.f, 0.f, 0.f};                                   \
+        _Pragma("unroll") for (int ks = 0; ks < ST_KS; ++ks) {                                                                  \
+            const ltg_u16x8 b0 = *reinterpret_cast<const ltg_u16x8*>(Wl + lr * ST_LDW + ks * 32 + 8 * lq);                      \
+            const ltg_u16x8 b1 = *reinterpret_cast<const ltg_u16x8*>(Wl + (16 + lr) * ST_LDW + ks * 32 + 8 * lq);               \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], __builtin_bit_cast(ltg_bf16x8, b0), acc0, 0, 0, 0);          \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], __builtin_bit_cast(ltg_bf16x8, b1), acc1, 0, 0, 0);          \
+        }                                                                                                                       \
+        {                                                                                                                       \
+            const int ia = t * ST_BN + lr, ib = ia + 16;                                                                        \
+            const float biasa = bp1[min(ia, I - 1)], biasb = bp1[min(ib, I - 1)];                                               \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                     \
+                const int row = 16 * w + 4 * lq + q;                                                                            \
+                if (row < M && ia < I) logits[(size_t)row * I + ia] = acc0[q] + biasa;                                          \
+                if (row < M && ib < I) logits[(size_t)row * I + ib] = acc1[q] + biasb;                                          \
+            }                                                                                                                   \
+        }                                                                                                                       \
+        if (t + G < ntiles) st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                \
+        __syncthreads();                                                                                                        \
+        cur ^= 1;                                                                                                               \
+    }
+    while (t < ntiles) {
+        ST_STEP(r0, r1)
+        t += G;
+        if (t >= ntiles) break;
+        ST_STEP(r1, r0)
+        t += G;
+    }
+#undef ST_STEP
+}
+
+// part[blockIdx.x][b][h]: this workgroup's share of dh2 (k_da2 sums the slabs)
+__global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int chunk, const float* __restrict__ dlog,
+                                                      const unsigned short* __restrict__ Wb, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    constexpr int NTL = ST_KP / 16;  // 38 column tiles of the accumulator
+    ltg_f32x4 acc[NTL];
+#pragma unroll
+    for (int n = 0; n < NTL; ++n) acc[n] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ibeg = blockIdx.x * chunk, iend = min(I, ibeg + chunk);
+    const int row = 16 * w + lr;
+    const float* drow = dlog + (size_t)min(row, B - 1) * I;
+    // A fragment of a 32-item step: dlog[row][i0 + 8*lq .. +7] (I % 8 == 0: whole 32-B groups, 16-B aligned)
+    auto load_a = [&](int i0, float4& x0, float4& x1) {
+        const int ib = min(i0 + 8 * lq, I - 8);
+        x0 = *reinterpret_cast<const float4*>(drow + ib);
+        x1 = *reinterpret_cast<const float4*>(drow + ib + 4);
+    };
+    StW r;
+    float4 a0, a1, n0, n1;
+    if (ibeg < iend) {
+        st_fetch_w(Wb, I, ibeg, r);
+        st_stash_w(st_lds, r);
+        load_a(ibeg, a0, a1);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int i0 = ibeg; i0 < iend; i0 += ST_BN) {
+        const int inext = i0 + ST_BN;
+        if (inext < iend) {
+            st_fetch_w(Wb, I, inext, r);
+            load_a(inext, n0, n1);
+        }
+        ltg_u16x8 au;
+        {
+            const bool ok = row < B && i0 + 8 * lq < iend;  // chunk is a multiple of 32 and I % 8 == 0: groups are whole
+            au[0] = ok ? ltg_f2bf(a0.x) : 0; au[1] = ok ? ltg_f2bf(a0.y) : 0; au[2] = ok ? ltg_f2bf(a0.z) : 0; au[3] = ok ? ltg_f2bf(a0.w) : 0;
+            au[4] = ok ? ltg_f2bf(a1.x) : 0; au[5] = ok ? ltg_f2bf(a1.y) : 0; au[6] = ok ? ltg_f2bf(a1.z) : 0; au[7] = ok ? ltg_f2bf(a1.w) : 0;
+        }
+        const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);
+        const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;
+        // transposed fragment reads: lane 4q+p of each 16-lane group addresses row (8*lq + q), columns 4p..4p+3;
+        // it receives column (lane & 15) of the four rows -> k = 8*lq + q (first read), 8*lq + 4 + q (second)
+        const int tq = lr >> 2, tp = lr & 3;
+        const unsigned short* tbase = Wl + (8 * lq + tq) * ST_LDW + 4 * tp;
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) {
+            typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;
+            const ltg_s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + n * 16));
+            const ltg_s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + 4 * ST_LDW + n * 16));
+            ltg_u16x8 bu;
+            bu[0] = b0[0]; bu[1] = b0[1]; bu[2] = b0[2]; bu[3] = b0[3];
+            bu[4] = b1[0]; bu[5] = b1[1]; bu[6] = b1[2]; bu[7] = b1[3];
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(ltg_bf16x8, bu), acc[n], 0, 0, 0);
+        }
+        if (inext < iend) {
+            st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, r);
+            a0 = n0;
+            a1 = n1;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* out = part + (size_t)blockIdx.x * B * H;
+#pragma unroll
+    for (int n = 0; n < NTL; ++n) {
+        const int h = n * 16 + lr;
+        if (h < H) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = 16 * w + 4 * lq + q;
+                if (rr < B) out[(size_t)rr * H + h] = acc[n][q];
+            }
+        }
+    }
+}
+
+// (re)build the bf16 shadow of W_p1t from the fp32 master rows (set-up / after loading weights)
+__global__ __launch_bounds__(NT) void k_refresh_shadow(int I, int H, const float* __restrict__ W, unsigned short* __restrict__ Wb) {
+    const size_t total = (size_t)I * ST_KP;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const size_t i = e / ST_KP;
+        const int k = (int)(e % ST_KP);
+        Wb[e] = k < H ? ltg_f2bf(W[i * H + k]) : (unsigned short)0;
+    }
+}
+
 // row log-sum-exp of the logits (log_softmax / softmax, MultiVAE.py:108,143)
 __global__ __launch_bounds__(NT) void k_row_lse(int I, const float* __restrict__ logits, float* __restrict__ lse) {
     __shared__ float red[NT / 64];
@@ -652,6 +857,7 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
     constexpr int BM = VAR == 0 ? 32 : (VAR == 3 ? 32 : 64), BN = VAR == 0 ? 32 : (VAR == 2 ? 64 : 128);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
+    unsigned short* Wb = st.wp1t_bf16;  // optional bf16 shadow [I][ST_KP], kept in step with the master weights
     auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)k * I + m]; };
     auto b = [=] __device__(int k, int n) -> float {
         const float v = h2[(size_t)k * H + min(n, H - 1)];
@@ -672,6 +878,7 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
                 reinterpret_cast<float4*>(W)[o] = p;
                 reinterpret_cast<float4*>(mW)[o] = mm;
                 reinterpret_cast<float4*>(vW)[o] = vv;
+                if (Wb) *reinterpret_cast<uint2*>(Wb + (size_t)m * ST_KP + n) = ltg_pack4(p);
             } else {
                 adam_update(bb, mb, vb, m, g.x, ad);  // n == H: the ones column = bias gradient
             }
@@ -679,8 +886,10 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
         ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
     } else {
         auto epi = [=] __device__(int m, int n, float g) {
-            if (n < H) adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
-            else adam_update(bb, mb, vb, m, g, ad);
+            if (n < H) {
+                adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
+                if (Wb) Wb[(size_t)m * ST_KP + n] = ltg_f2bf(W[(size_t)m * H + n]);
+            } else adam_update(bb, mb, vb, m, g, ad);
         };
         ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
     }
@@ -989,6 +1198,16 @@ __global__ __launch_bounds__(NT) void k_rank_metrics(int I, const float* __restr
 // ---------------------------------------------------------------------------------------------
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// the streaming decoder kernels: bf16, large item slab, a training batch (<= 128 rows), H <= 608, 16-B aligned rows
+inline bool stream_ok(const ltg_config* cfg, const ltg_gen_state* gen, int rows) {
+    return gen->wp1t_bf16 && cfg->precision == LTG_PREC_BF16 && cfg->n_items >= 8192 && (cfg->n_items % 8) == 0 && rows <= 128 && cfg->h_enc <= ST_KP &&
+           (cfg->h_enc % 4) == 0 && (cfg->reserved0 & 15) != 9;
+}
+inline int dh2_stream_chunk(int I) {
+    int c = (I + 255) / 256;
+    return (c + ST_BN - 1) / ST_BN * ST_BN;
+}
+
 inline int dh2_kchunk(int I) {
     // split the item dimension so that ~128 workgroups x (H/64) share the reduction
     int chunk = (I + 63) / 64;
@@ -1023,7 +1242,11 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     const size_t R = (size_t)max_rows, I = (size_t)cfg->n_items, H = (size_t)cfg->h_enc, Z = (size_t)cfg->z_dim;
     const size_t P = (size_t)max_pairs, h12 = (size_t)cfg->d_h1 + cfg->d_h2, h3 = (size_t)cfg->d_h3;
     const int kchunk = dh2_kchunk(cfg->n_items);
-    const size_t nsplit = (I + kchunk - 1) / kchunk;
+    size_t nsplit = (I + kchunk - 1) / kchunk;
+    {
+        const size_t ns2 = (I + dh2_stream_chunk(cfg->n_items) - 1) / dh2_stream_chunk(cfg->n_items);
+        if (ns2 > nsplit) nsplit = ns2;
+    }
     w.rowpart = take(R * RP);
     w.nb = take(R);
     w.Pb = take(R);
@@ -1118,7 +1341,11 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     {
         const bool bf = cfg->precision == LTG_PREC_BF16, big = I >= 8192;
         pr.before(LTG_K_DEC1_FWD);
-        if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        if (stream_ok(cfg, gen, R)) {
+            const int ntiles = (I + ST_BN - 1) / ST_BN;
+            hipLaunchKernelGGL(k_dec1_fwd_stream, dim3(ntiles < 256 ? ntiles : 256), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H,
+                               acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits);
+        } else if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf) hipLaunchKernelGGL((k_dec1_fwd<true, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (big) hipLaunchKernelGGL((k_dec1_fwd<false, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else hipLaunchKernelGGL((k_dec1_fwd<false, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
@@ -1254,12 +1481,14 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
                        o->anneal, o->gan_lambda, acts->lse, w.nb, w.Pb, w.scal, loss_out);
     hipLaunchKernelGGL(k_dlogits, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, bt->indptr, bt->indices, bt->values,
                        acts->logits, acts->lse, w.nb, w.Pb, w.scal, nf, fake->row, fake->niche, fake->pop, w.dlog, cfg->item_lo);
-    const int kchunk = dh2_kchunk(I);
+    const bool stream = stream_ok(cfg, gen, B);
+    const int kchunk = stream ? dh2_stream_chunk(I) : dh2_kchunk(I);
     const int nsplit = (I + kchunk - 1) / kchunk;
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
     pr.before(LTG_K_DH2);
-    if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    if (stream) hipLaunchKernelGGL(k_dh2_stream, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
+    else if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf) hipLaunchKernelGGL((k_dh2_partial<true, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (big) hipLaunchKernelGGL((k_dh2_partial<false, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else hipLaunchKernelGGL((k_dh2_partial<false, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
@@ -1301,7 +1530,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     const Probe prs{o->probe, side};
     prs.before(LTG_K_DEC1_BWD_ADAM);
     {
-        const int var = cfg->reserved0 > 0 ? cfg->reserved0 - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
+        const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
         if (!bf) {
             if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
             else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
@@ -1432,6 +1661,16 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
     return g_stage_bwd_rest(cfg, gen, bt, o, acts, dh2, w, (hipStream_t)stream);
+}
+
+int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !gen || !gen->wp1t_bf16 || cfg->h_enc > ST_KP) return LTG_EINVAL;
+    const size_t total = (size_t)cfg->n_items * ST_KP;
+    size_t gx = (total + NT - 1) / NT;
+    if (gx > 65536) gx = 65536;
+    hipLaunchKernelGGL(k_refresh_shadow, dim3((unsigned)gx), dim3(NT), 0, (hipStream_t)stream, cfg->n_items, cfg->h_enc, gen->p[3], gen->wp1t_bf16);
+    return check_launch();
 }
 
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out, ltg_stream stream) {

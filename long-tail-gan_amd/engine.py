@@ -144,7 +144,13 @@ class Engine:
         self.g_v = [torch.zeros_like(t) if v is None else torch.as_tensor(np.ascontiguousarray(v[i]), dtype=torch.float32).to(dev)
                     for i, t in enumerate(self.g_p)]
         arr = lambda ts: (cabi.vp * 8)(*[_ptr(t) for t in ts])
-        self.gen_c = cabi.ltg_gen_state(arr(self.g_p), arr(self.g_m), arr(self.g_v))
+        # bf16 shadow of W_p1t for the streaming decoder kernels (large item slabs only)
+        self.g_shadow = None
+        if self.precision == cabi.LTG_PREC_BF16 and self.I >= 8192 and self.I % 8 == 0 and self.H <= 608:
+            self.g_shadow = torch.zeros(self.I, 608, dtype=torch.int16, device=dev)
+        self.gen_c = cabi.ltg_gen_state(arr(self.g_p), arr(self.g_m), arr(self.g_v), _ptr(self.g_shadow))
+        if self.g_shadow is not None:
+            cabi.check(self.lib.ltg_refresh_shadow(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_refresh_shadow")
 
     def _init_discriminator(self, seed):
         g = torch.Generator().manual_seed(seed)

@@ -23,13 +23,13 @@ def test_header_symbols_are_exported_and_bound():
     lib = cabi.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 3
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 4
 
 
 def test_struct_layouts_match_header():
     from ltgan import _cabi as cabi
     assert C.sizeof(cabi.ltg_config) == 72 and cabi.ltg_config.seed.offset == 64
-    assert C.sizeof(cabi.ltg_gen_state) == 24 * 8 and C.sizeof(cabi.ltg_disc_state) == 25 * 8
+    assert C.sizeof(cabi.ltg_gen_state) == 25 * 8 and C.sizeof(cabi.ltg_disc_state) == 25 * 8
     assert C.sizeof(cabi.ltg_batch) == 8 + 8 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
     assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8
     assert C.sizeof(cabi.ltg_pairs) == 8 + 3 * 8
