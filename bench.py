@@ -95,21 +95,27 @@ class KernelProfiler:
         n = sh["n"]
         P = h0 * h1 + h1 + h0 * h2 + h2 + h12 * h3 + h3 + h3 + 1
         ks = (n + 255) // 256
-        kchunk = max(256, -(-(-(-I // 64)) // 32) * 32)      # dh2_kchunk() of csrc/ltg_kernels.hip
+        stream = self.a.precision == "bf16" and I >= 8192 and I % 8 == 0 and B <= 128     # stream_ok() of csrc/ltg_kernels.hip
+        if stream:
+            kchunk = -(-(-(-I // 256)) // 32) * 32           # dh2_stream_chunk()
+        else:
+            kchunk = max(256, -(-(-(-I // 64)) // 32) * 32)  # dh2_kchunk()
         nsplit = -(-I // kchunk)
+        wread = 2 * 608 * I if stream else 4 * I * H        # bf16 shadow of W_p1t vs fp32 rows converted on the fly
+        shadow_w = 2 * 608 * I if stream else 0             # the Adam epilogue refreshes the shadow
         w = {
             "enc0_fwd": (2 * sh["nnz"] * H, 4 * (sh["nnz"] * H + B * H)),
             "enc1": (2 * B * H * 2 * Z, 4 * (B * H + H * 2 * Z + B * 2 * Z)),
             "dec0": (2 * B * Z * H, 4 * (B * Z + Z * H + B * H)),
-            "dec1_fwd": (2 * B * H * I, 4 * (I * H + I + B * H + B * I)),
+            "dec1_fwd": (2 * B * H * I, wread + 4 * (I + B * H + B * I)),
             "d_l1": (2 * n * h0 * h12, 4 * (2 * n * h0 + h0 * h12 + n * h12)),
             "d_l2": (2 * n * h12 * h3, 4 * (n * h12 + h12 * h3 + n * h3)),
             "d_bwd1": (2 * n * h3 * h12 + 2 * n * (h12 + 1) * h3 + 2 * n * h3,
                        4 * (n * h3 + h12 * h3 + 2 * n * h12 + n * h3 + ks * (h12 * h3 + 2 * h3 + 1))),
             "d_bwd2": (2 * n * (h0 + 1) * h12, 4 * (2 * n * h0 + n * h12 + ks * ((h0 + 1) * h12))),
             "d_adam": (0, P * (4 * ks + 24)),
-            "dh2": (2 * B * I * H, 4 * (B * I + I * H + nsplit * B * H)),
-            "dec1_bwd_adam": (2 * I * (H + 1) * B, 24 * (I * H + I) + 4 * (B * I + B * H)),
+            "dh2": (2 * B * I * H, wread + 4 * (B * I + nsplit * B * H)),
+            "dec1_bwd_adam": (2 * I * (H + 1) * B, 24 * (I * H + I) + shadow_w + 4 * (B * I + B * H)),
             "dz": (2 * B * H * Z, 4 * (B * H + Z * H + 2 * B * 2 * Z)),
             "wgrad_p0": (2 * B * (Z + 1) * H, 24 * (Z + 1) * H + 4 * (B * Z + B * H)),
             "dh1": (2 * B * 2 * Z * H, 4 * (B * 2 * Z + H * 2 * Z + 2 * B * H)),

@@ -404,6 +404,139 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     }
 }
 
+// dW_p1t[i][h] = sum_b dlog[b][i] * h2[b][h] (+ ones column h == H -> db_p1[i]) fused with the Adam update of
+// W_p1t / b_p1 and the refresh of the bf16 shadow, streaming: persistent 8-wave workgroups, h2 fragments
+// stationary in registers (wave w owns columns [80w, 80w+80)), dlog read ONCE in [128 rows][32 items] tiles
+// (row-major bf16 LDS image, consumed transposed by ds_read_b64_tr_b16), theta/m/v touched exactly once.
+constexpr int DW_LDD = 40;  // LDS row stride of the dlog tile in bf16 (80 B: 16-B aligned)
+constexpr int DW_LDC = 84;  // row stride of a wave's fp32 gradient block (80 columns + 4)
+__global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, int H, const float* __restrict__ dlog,
+                                                                const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
+    __shared__ __attribute__((aligned(16))) unsigned short Dl[2][128 * DW_LDD];
+    __shared__ __attribute__((aligned(16))) float Cs[8 * 32 * DW_LDC];   // per-wave [32][80] gradient blocks
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
+    unsigned short* Wb = st.wp1t_bf16;
+    // stationary B fragments: B[k = b][n] = h2[b][n] (n < H), 1 (n == H), 0 beyond
+    ltg_bf16x8 bf[5][4];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+        const int n = 80 * w + 16 * nt + lr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            ltg_u16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = ks * 32 + 8 * lq + j;
+                const float v = h2[(size_t)min(b, B - 1) * H + min(n, H - 1)];
+                t[j] = b < B ? (n < H ? ltg_f2bf(v) : (n == H ? (unsigned short)0x3F80 : (unsigned short)0)) : (unsigned short)0;
+            }
+            bf[nt][ks] = __builtin_bit_cast(ltg_bf16x8, t);
+        }
+    }
+    const int ntiles = (I + 31) / 32, G = gridDim.x;
+    // dlog tile loader: thread -> (row b = tid / 4, 8 items at 8 * (tid % 4))
+    const int lb = tid >> 2, lseg = tid & 3;
+    const float* lrow = dlog + (size_t)min(lb, B - 1) * I;
+    auto fetch = [&](int t, float4& x0, float4& x1) {
+        const int ib = min(t * 32 + 8 * lseg, I - 8);
+        x0 = *reinterpret_cast<const float4*>(lrow + ib);
+        x1 = *reinterpret_cast<const float4*>(lrow + ib + 4);
+    };
+    auto stash = [&](unsigned short* D, int t, const float4& x0, const float4& x1) {
+        const bool ok = lb < B && t * 32 + 8 * lseg < I;
+        ltg_u32x4 p;
+        const uint2 a = ltg_pack4(x0), c = ltg_pack4(x1);
+        p[0] = ok ? a.x : 0u; p[1] = ok ? a.y : 0u; p[2] = ok ? c.x : 0u; p[3] = ok ? c.y : 0u;
+        *reinterpret_cast<ltg_u32x4*>(D + lb * DW_LDD + 8 * lseg) = p;
+    };
+    int t = blockIdx.x, cur = 0;
+    float4 x0, x1;
+    if (t < ntiles) {
+        fetch(t, x0, x1);
+        stash(Dl[0], t, x0, x1);
+    }
+    __syncthreads();
+    const int tq = lr >> 2, tp = lr & 3;
+    for (; t < ntiles; t += G) {
+        const bool more = t + G < ntiles;
+        if (more) fetch(t + G, x0, x1);
+        ltg_f32x4 acc[2][5];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned short* D = Dl[cur];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;
+                const unsigned short* base = D + (ks * 32 + 8 * lq + tq) * DW_LDD + mt * 16 + 4 * tp;
+                const ltg_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)base);
+                const ltg_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * DW_LDD));
+                ltg_u16x8 au;
+                au[0] = a0[0]; au[1] = a0[1]; au[2] = a0[2]; au[3] = a0[3];
+                au[4] = a1[0]; au[5] = a1[1]; au[6] = a1[2]; au[7] = a1[3];
+                const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt][ks], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        // Adam epilogue: the wave's [32 items][80 columns] gradient block takes a round trip through its private
+        // LDS slab so that theta / m / v are walked in float4 over 320-B row segments (16 B per lane).
+        float* Cw = Cs + w * (32 * DW_LDC);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Cw[(mt * 16 + 4 * lq + q) * DW_LDC + 16 * nt + lr] = acc[mt][nt][q];
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 pv[5], mv[5], vv[5], gv[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int e = lane + 64 * (5 * half + j);          // 640 float4 per wave: row = e / 20, chunk = e % 20
+                const int rr = e / 20, c4 = e % 20;
+                const int i = t * 32 + rr, n = 80 * w + 4 * c4;
+                const size_t o = ((size_t)min(i, I - 1) * H + min(n, H - 4)) >> 2;
+                pv[j] = reinterpret_cast<const float4*>(W)[o];
+                mv[j] = reinterpret_cast<const float4*>(mW)[o];
+                vv[j] = reinterpret_cast<const float4*>(vW)[o];
+                gv[j] = *reinterpret_cast<const float4*>(Cw + rr * DW_LDC + 4 * c4);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int e = lane + 64 * (5 * half + j);
+                const int rr = e / 20, c4 = e % 20;
+                const int i = t * 32 + rr, n = 80 * w + 4 * c4;
+                if (i < I && n < H) {
+                    float4 p = pv[j], mm = mv[j], v2 = vv[j];
+                    const float4 g = gv[j];
+#define LTG_ADAM4(f)                                  \
+    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;        \
+    v2.f = ad.b2 * v2.f + (1.f - ad.b2) * g.f * g.f;  \
+    p.f = p.f - ad.lr_t * mm.f / (sqrtf(v2.f) + ad.eps);
+                    LTG_ADAM4(x) LTG_ADAM4(y) LTG_ADAM4(z) LTG_ADAM4(w)
+#undef LTG_ADAM4
+                    const size_t o = ((size_t)i * H + n) >> 2;
+                    reinterpret_cast<float4*>(W)[o] = p;
+                    reinterpret_cast<float4*>(mW)[o] = mm;
+                    reinterpret_cast<float4*>(vW)[o] = v2;
+                    if (Wb) *reinterpret_cast<uint2*>(Wb + (size_t)i * ST_KP + n) = ltg_pack4(p);
+                } else if (i < I && n == H) {
+                    adam_update(bb, mb, vb, i, gv[j].x, ad);   // the ones column: bias gradient
+                }
+            }
+        }
+        if (more) stash(Dl[cur ^ 1], t + G, x0, x1);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // (re)build the bf16 shadow of W_p1t from the fp32 master rows (set-up / after loading weights)
 __global__ __launch_bounds__(NT) void k_refresh_shadow(int I, int H, const float* __restrict__ W, unsigned short* __restrict__ Wb) {
     const size_t total = (size_t)I * ST_KP;
@@ -1531,7 +1664,10 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     prs.before(LTG_K_DEC1_BWD_ADAM);
     {
         const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
-        if (!bf) {
+        if (stream_ok(cfg, gen, B) && (cfg->reserved0 & 15) == 0) {
+            const int ntl = (I + 31) / 32;
+            hipLaunchKernelGGL(k_dec1_bwd_adam_stream, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+        } else if (!bf) {
             if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
             else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
         } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
