@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 4
+#define LTG_ABI_VERSION 5
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -251,7 +251,8 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
 int ltg_g_fwd_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_fwd_opts* opts,
                   const ltg_gen_acts* acts, ltg_stream stream);
 int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
-                   const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, ltg_stream stream);
+                   const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, void* ws, size_t ws_bytes,
+                   ltg_stream stream);
 int ltg_rowstats_combine(const ltg_config* cfg, const float* rowpart_all, int32_t n_ranks, int32_t n_rows, float* lse_out,
                          void* ws, size_t ws_bytes, ltg_stream stream);
 int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
-LTG_ABI_VERSION = 4
+LTG_ABI_VERSION = 5
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -95,7 +95,7 @@ SYMBOLS = {
     "ltg_g_fwd_enc": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_fwd_opts),
                                 C.POINTER(ltg_gen_acts), vp]),
     "ltg_g_fwd_rest": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pairs),
-                                 C.POINTER(ltg_fwd_opts), C.POINTER(ltg_gen_acts), vp, vp]),
+                                 C.POINTER(ltg_fwd_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
     "ltg_rowstats_combine": (C.c_int, [C.POINTER(ltg_config), vp, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
     "ltg_g_bwd_dec": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state), C.POINTER(ltg_batch),
                                 C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, C.c_int32, vp, vp, vp,

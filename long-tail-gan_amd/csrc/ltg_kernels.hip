@@ -856,6 +856,83 @@ __global__ __launch_bounds__(NT) void k_row_partial(int I, int item_lo, const in
     }
 }
 
+// Large item slabs: the same statistics per (4096-item segment, row) in one pass over the logits (the segment
+// lives in registers between the max and the exp-sum), merged per row by k_row_partial_merge.
+constexpr int RS_SEG = 4096;
+__global__ __launch_bounds__(NT) void k_row_partial_seg(int I, int item_lo, const int32_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                        const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
+                                                        const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
+                                                        float* __restrict__ segpart) {
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.y, sg = blockIdx.x, B = gridDim.y;
+    const int i0 = sg * RS_SEG, i1 = min(I, i0 + RS_SEG);
+    const float* row = logits + (size_t)b * I;
+    float v[RS_SEG / NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < RS_SEG / NT; ++j) {
+        const int i = i0 + threadIdx.x + NT * j;
+        v[j] = i < i1 ? row[i] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = block_max(mx, red);
+    float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < RS_SEG / NT; ++j) s += expf(v[j] - mx);  // exp(-inf) = 0 for the tail
+    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+        const int it = indices[e];
+        if (it >= i0 && it < i1) {
+            const float x = values ? values[e] : 1.f;
+            xl += x * row[it];
+            nx += x;
+        }
+    }
+    for (int q = threadIdx.x; q < nf; q += NT) {
+        const int it = f_gen[q] - item_lo;
+        if (f_row[q] == b && f_gen[q] >= 0 && f_pop[q] >= 0 && it >= i0 && it < i1) ps += expf(row[it] - mx);
+    }
+    s = block_sum(s, red);
+    xl = block_sum(xl, red);
+    nx = block_sum(nx, red);
+    ps = block_sum(ps, red);
+    if (threadIdx.x == 0) {
+        float* o = segpart + ((size_t)sg * B + b) * RP;
+        o[0] = mx;
+        o[1] = s;
+        o[2] = xl;
+        o[3] = ps;
+        o[4] = nx;
+    }
+}
+
+// merge the segment partials of a row into one partial (same 5-float format); optionally also the row's lse
+__global__ __launch_bounds__(64) void k_row_partial_merge(int B, int nseg, const float* __restrict__ segpart,
+                                                          float* __restrict__ rowpart, float* __restrict__ lse) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float M = -INFINITY;
+    for (int g = 0; g < nseg; ++g) M = fmaxf(M, segpart[((size_t)g * B + b) * RP]);
+    float s = 0.f, xl = 0.f, ps = 0.f, nx = 0.f;
+    for (int g = 0; g < nseg; ++g) {
+        const float* q = segpart + ((size_t)g * B + b) * RP;
+        const float sc = expf(q[0] - M);
+        s += q[1] * sc;
+        xl += q[2];
+        ps += q[3] * sc;
+        nx += q[4];
+    }
+    if (rowpart) {
+        float* o = rowpart + (size_t)b * RP;
+        o[0] = M;
+        o[1] = s;
+        o[2] = xl;
+        o[3] = ps;
+        o[4] = nx;
+    }
+    if (lse) lse[b] = M + logf(s);
+}
+
 // Combine the R shards' row partials: lse, n_b, P_b per row, then the step scalars (train.py:145-157):
 // out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
 __global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __restrict__ rowpart_all, int nf,
@@ -973,11 +1050,34 @@ __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kch
 // da2 = (sum_z part) * (1 - h2^2)
 __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __restrict__ part, const float* __restrict__ h2,
                                             float* __restrict__ da2) {
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-        float s = 0.f;
-        for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
-        const float t = h2 ? h2[i] : 0.f;
-        da2[i] = s * (1.f - t * t);
+    // n % 4 == 0 (H % 4 == 0): 16 B per lane, 8 slabs in flight
+    const int n4 = n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n4; i += gridDim.x * NT) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int z = 0;
+        for (; z + 8 <= nsplit; z += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p4[(size_t)(z + u) * n4 + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s.x += x[u].x;
+                s.y += x[u].y;
+                s.z += x[u].z;
+                s.w += x[u].w;
+            }
+        }
+        for (; z < nsplit; ++z) {
+            const float4 x = p4[(size_t)z * n4 + i];
+            s.x += x.x;
+            s.y += x.y;
+            s.z += x.z;
+            s.w += x.w;
+        }
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h2) t = reinterpret_cast<const float4*>(h2)[i];
+        reinterpret_cast<float4*>(da2)[i] = make_float4(s.x * (1.f - t.x * t.x), s.y * (1.f - t.y * t.y), s.z * (1.f - t.z * t.z), s.w * (1.f - t.w * t.w));
     }
 }
 
@@ -1098,29 +1198,41 @@ __global__ __launch_bounds__(NT) void k_enc0_grad(int B, int I, int H, int nu, c
     for (int q = 0; q < MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* d4 = reinterpret_cast<const float4*>(da1);
     const int q0 = u < nu ? uptr[u] : 0, q1 = u < nu ? uptr[u + 1] : B;
-    for (int q = q0 + w; q < q1; q += NT / 64) {
-        int b;
-        float sc;
-        if (u < nu) {
-            b = rowidx[q];
-            const int pos = csr_pos[q];
-            const int it = indices[pos];
-            const bool kp = drop_keep ? (drop_keep[pos] != 0)
-                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
-            sc = kp ? (values ? values[pos] : 1.f) * row_scale[b] : 0.f;
-        } else {
-            b = q;  // bias row: every batch row, weight 1
-            sc = 1.f;
+    // 4 entries per trip and wave: their (dependent) index chains and da1 row loads overlap
+    for (int q = q0 + w; q < q1; q += 4 * (NT / 64)) {
+        int b[4];
+        float sc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qt = q + t * (NT / 64);
+            const bool ok = qt < q1;
+            const int qc = ok ? qt : q;
+            if (u < nu) {
+                b[t] = rowidx[qc];
+                const int pos = csr_pos[qc];
+                const int it = indices[pos];
+                const bool kp = drop_keep ? (drop_keep[pos] != 0)
+                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b[t] * (uint64_t)Ig + item_lo + it, keep);
+                sc[t] = (ok && kp) ? (values ? values[pos] : 1.f) * row_scale[b[t]] : 0.f;
+            } else {
+                b[t] = qc;  // bias row: every batch row, weight 1
+                sc[t] = ok ? 1.f : 0.f;
+            }
         }
 #pragma unroll
         for (int qq = 0; qq < MAXQ; ++qq) {
             const int c4 = lane + 64 * qq;
             if (c4 < H4) {
-                const float4 d = d4[(size_t)b * H4 + c4];
-                acc[qq].x += sc * d.x;
-                acc[qq].y += sc * d.y;
-                acc[qq].z += sc * d.z;
-                acc[qq].w += sc * d.w;
+                float4 d[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[t] = d4[(size_t)b[t] * H4 + c4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[qq].x += sc[t] * d[t].x;
+                    acc[qq].y += sc[t] * d[t].y;
+                    acc[qq].z += sc[t] * d[t].z;
+                    acc[qq].w += sc[t] * d[t].w;
+                }
             }
         }
     }
@@ -1358,7 +1470,7 @@ inline size_t gq0_rows(const ltg_config* cfg, int max_rows) {
 
 struct Workspace {
     // generator backward
-    float *rowpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
+    float *rowpart, *segpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     size_t bytes;
@@ -1381,6 +1493,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
         if (ns2 > nsplit) nsplit = ns2;
     }
     w.rowpart = take(R * RP);
+    w.segpart = take(((I + RS_SEG - 1) / RS_SEG) * R * RP);
     w.nb = take(R);
     w.Pb = take(R);
     w.scal = take(16);
@@ -1486,12 +1599,26 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     }
 }
 
+// bytes of the segment-partial scratch for `rows` rows (the first two carve entries of the workspace)
+inline size_t segpart_bytes(const ltg_config* cfg, int rows) {
+    const size_t nseg = ((size_t)cfg->n_items + RS_SEG - 1) / RS_SEG;
+    return align_up((size_t)rows * RP * sizeof(float)) + align_up(nseg * rows * RP * sizeof(float));
+}
+
 int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
-                     const ltg_gen_acts* acts, float* probs_out, hipStream_t st) {
+                     const ltg_gen_acts* acts, float* probs_out, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     const int R = bt->n_rows, I = cfg->n_items;
     if (R <= 0) return LTG_OK;
     fwd_stage_enc(cfg, gen, bt, o, acts, 0, st);
     fwd_stage_rest(cfg, gen, bt, o, acts, 0, st);
+    if (ws && I > 2 * RS_SEG && ws_bytes >= segpart_bytes(cfg, R)) {
+        // large item slab: one pass over the logits in (segment, row) blocks, then a per-row merge
+        float* segpart = reinterpret_cast<float*>((char*)ws + align_up((size_t)R * RP * sizeof(float)));
+        const int nseg = (I + RS_SEG - 1) / RS_SEG;
+        hipLaunchKernelGGL(k_row_partial_seg, dim3(nseg, R), dim3(NT), 0, st, I, cfg->item_lo, bt->indptr, bt->indices, bt->values, acts->logits,
+                           0, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, segpart);
+        hipLaunchKernelGGL(k_row_partial_merge, dim3((R + 63) / 64), dim3(64), 0, st, R, nseg, segpart, (float*)nullptr, acts->lse);
+    } else
     hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
     if (probs_out) {
         const int gx = (I + NT - 1) / NT < 64 ? (I + NT - 1) / NT : 64;
@@ -1528,13 +1655,11 @@ size_t ltg_workspace_bytes(const ltg_config* cfg, int32_t max_rows, int32_t max_
 int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_fwd_opts* opts,
                     const ltg_gen_acts* acts, float* probs_out, void* ws, size_t ws_bytes, ltg_stream stream) {
     clear_errors();
-    (void)ws;
-    (void)ws_bytes;
     if (!cfg_ok(cfg) || !gen || !batch || !opts || !acts || batch->n_rows < 0) return LTG_EINVAL;
     if (!batch->indptr || !batch->indices || !acts->h1 || !acts->mulv || !acts->z || !acts->h2 || !acts->logits || !acts->lse ||
         !acts->kl_rows || !acts->row_scale)
         return LTG_EINVAL;
-    return vae_forward_impl(cfg, gen, batch, opts, acts, probs_out, (hipStream_t)stream);
+    return vae_forward_impl(cfg, gen, batch, opts, acts, probs_out, (hipStream_t)stream, ws, ws_bytes);
 }
 
 int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, const float* lse,
@@ -1592,7 +1717,15 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
 // ltg_g_step runs the same stages back to back with one "rank".
 
 static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_pairs* fake, const ltg_gen_acts* acts,
-                          float* rowpart, hipStream_t st) {
+                          float* rowpart, hipStream_t st, float* segpart = nullptr, float* lse = nullptr) {
+    const int I = cfg->n_items, B = bt->n_rows;
+    if (segpart && I > 2 * RS_SEG) {
+        const int nseg = (I + RS_SEG - 1) / RS_SEG;
+        hipLaunchKernelGGL(k_row_partial_seg, dim3(nseg, B), dim3(NT), 0, st, I, cfg->item_lo, bt->indptr, bt->indices, bt->values, acts->logits,
+                           fake ? fake->n : 0, fake ? fake->row : nullptr, fake ? fake->niche : nullptr, fake ? fake->pop : nullptr, segpart);
+        hipLaunchKernelGGL(k_row_partial_merge, dim3((B + 63) / 64), dim3(64), 0, st, B, nseg, segpart, rowpart, lse);
+        return;
+    }
     hipLaunchKernelGGL(k_row_partial, dim3(bt->n_rows), dim3(NT), 0, st, cfg->n_items, cfg->item_lo, bt->indptr, bt->indices, bt->values,
                        acts->logits, fake ? fake->n : 0, fake ? fake->row : nullptr, fake ? fake->niche : nullptr,
                        fake ? fake->pop : nullptr, rowpart);
@@ -1738,7 +1871,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     }
     fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st);
     fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
-    g_row_partial(cfg, bt, fake, acts, w.rowpart, st);
+    g_row_partial(cfg, bt, fake, acts, w.rowpart, st, w.segpart);
     if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
     // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)
     int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork, acts->h2);
@@ -1757,12 +1890,15 @@ int ltg_g_fwd_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_bat
 }
 
 int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,
-                   const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, ltg_stream stream) {
+                   const ltg_fwd_opts* opts, const ltg_gen_acts* acts, float* rowpart_out, void* ws, size_t ws_bytes,
+                   ltg_stream stream) {
     clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !opts || !rowpart_out) return LTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     fwd_stage_rest(cfg, gen, bt, opts, acts, 1, st);
-    g_row_partial(cfg, bt, (fake && fake->n > 0) ? fake : nullptr, acts, rowpart_out, st);
+    float* segpart = (ws && ws_bytes >= segpart_bytes(cfg, bt->n_rows))
+                         ? reinterpret_cast<float*>((char*)ws + align_up((size_t)bt->n_rows * RP * sizeof(float))) : nullptr;
+    g_row_partial(cfg, bt, (fake && fake->n > 0) ? fake : nullptr, acts, rowpart_out, st, segpart);
     return check_launch();
 }
 

@@ -196,6 +196,15 @@ class Engine:
             self._ws_key = (rows, pairs)
         return self._ws
 
+    def _fwd_scratch(self, rows):
+        """segment-partial scratch of the forward (large item slabs only): 5 floats per (4096-item segment, row)"""
+        if self.I <= 8192:
+            return None
+        need = (rows * 5 * 4 + 256) + ((self.I + 4095) // 4096) * rows * 5 * 4 + 512
+        if getattr(self, "_fs", None) is None or self._fs.numel() < need:
+            self._fs = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._fs
+
     def new_acts(self, rows):
         return Acts(rows, self.I, self.H, self.Z, self.device)
 
@@ -218,8 +227,9 @@ class Engine:
         """sess.run(generator_out, {input_ph: X})  -- train.py:200, :339; test.py:146."""
         assert acts.rows >= batch.n_rows
         o = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
+        ws = self._fwd_scratch(batch.n_rows)
         rc = self.lib.ltg_vae_forward(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(o),
-                                      C.byref(acts.c), _ptr(probs_out), None, 0, self.stream())
+                                      C.byref(acts.c), _ptr(probs_out), _ptr(ws), ws.numel() if ws is not None else 0, self.stream())
         cabi.check(rc, "ltg_vae_forward")
 
     def sample_pairs(self, samp_c, acts, gen_out, pop_out, cnt_out, out_off=0):
@@ -271,8 +281,10 @@ class Engine:
                                           self.stream()), "ltg_g_fwd_enc")
 
     def g_fwd_rest(self, batch, fake, acts, fopts, rowpart_out):
+        ws = self.workspace(batch.n_rows, fake.n if fake else 1)
         cabi.check(self.lib.ltg_g_fwd_rest(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fake.c) if fake else None,
-                                           C.byref(fopts), C.byref(acts.c), _ptr(rowpart_out), self.stream()), "ltg_g_fwd_rest")
+                                           C.byref(fopts), C.byref(acts.c), _ptr(rowpart_out), _ptr(ws), ws.numel(), self.stream()),
+                   "ltg_g_fwd_rest")
 
     def rowstats_combine(self, rowpart_all, n_ranks, n_rows, lse_out):
         ws = self.workspace(n_rows, 1)
