@@ -184,8 +184,10 @@ class KernelProfiler:
             avg = float(np.mean(ms))
             fl = float(np.mean([self.work(name, sh)[0] for _, sh, _ in self.samples]))
             by = float(np.mean([self.work(name, sh)[1] for _, sh, _ in self.samples]))
-        else:
+        elif calib and name in calib:
             avg, fl, by = calib[name]["avg_ms"], calib[name]["flops"], calib[name]["bytes"]
+        else:
+            return None
         bf = self.a.precision == "bf16" and name in ("dec1_fwd", "dh2", "dec1_bwd_adam")
         peak_f = PEAK["mfma_bf16"] if bf else PEAK["mfma_fp32"]
         t_f, t_b = fl / peak_f, by / PEAK["hbm"]

@@ -119,4 +119,5 @@ def read_config(path="config.ini"):
 
 if __name__ == "__main__":
     cfg = read_config()
-    train_GAN(dataset=sys.argv[1], **cfg)
+    max_epochs = os.environ.get("LTGAN_MAX_EPOCHS")      # optional cap for smoke runs (not in the reference)
+    train_GAN(dataset=sys.argv[1], max_epochs=int(max_epochs) if max_epochs else None, **cfg)
