@@ -351,3 +351,119 @@ def test_rank_metrics_match_oracle(n, I):
     np.testing.assert_allclose(out[ok, 0], nd, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(out[ok, 1], r20, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(out[ok, 2], r50, rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------
+# injected random tensors (ltg.h: "every random tensor can be injected through an optional pointer")
+# ------------------------------------------------------------------------------------------------
+def test_injected_randomness_g_and_d_steps():
+    """keep flags for the input dropout (per CSR entry), eps, the three discriminator masks: fed explicitly, the
+    on-device RNG must not be consulted (masks are drawn from numpy here, unrelated to the counter RNG)."""
+    import torch
+    from ltgan.engine import Pairs
+    I, B = 640, 48
+    rng, X, P = _problem(I, B, seed=99)
+    hs = (20, 24, 40, 36)
+    D = O.init_discriminator(I, *hs, seed=6)
+    eng = _engine(I, "fp32", hs=hs, lr=1e-3)
+    eng.set_generator(Hh.gen_to_engine(P))
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    dev = eng.device
+    rows, gen, pop = _fake_pairs(rng, X, I)
+    valid = (gen >= 0) & (pop >= 0)
+    nf = len(rows)
+    keep, dkeep = 0.75, 0.7
+    # --- injected tensors
+    mask = (rng.random((B, I)) < keep)
+    keep_entries = np.concatenate([mask[b, X.indices[X.indptr[b]:X.indptr[b + 1]]] for b in range(B)]).astype(np.uint8)
+    eps = rng.standard_normal((B, eng.Z)).astype(np.float32)
+    dmf = [(rng.random((nf, w)) < dkeep).astype(np.uint8) for w in hs[1:]]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fake = Pairs(t(pop), t(gen), t(rows))
+    batch = _upload_batch(eng, X, with_csc=True)
+    acts = eng.new_acts(B)
+    cnt = int(valid.sum())
+    loss = eng.g_step(batch, fake, acts, torch.tensor([cnt], dtype=torch.int32, device=dev), 0.07, 1.0, keep, 1.0, dkeep, rng_step=5,
+                      d_rng_step=6, drop_keep=t(keep_entries), eps=t(eps), drop_fake=[t(m) for m in dmf]).cpu().numpy()
+    T = O.d_tower(D, np.where(valid, pop, 0), np.where(valid, gen, 0), [m.astype(np.float64) for m in dmf], dkeep)
+    sum_y = float((T["y"] * valid).sum())
+    losses, g, F = O.g_loss_and_grads(P, X.toarray(), mask.astype(np.float64), keep, eps.astype(np.float64), 0.07, 1.0, rows[valid],
+                                      gen[valid], cnt, sum_y, 1.0, np.float64, quant=False)
+    assert abs(loss[4] - sum_y) < 1e-4 * max(1.0, abs(sum_y))
+    for i, k in enumerate(("g_loss", "vae_loss", "gan_loss")):
+        assert abs(loss[i] - losses[k]) < 1e-3 * abs(losses[k]) + 1e-6, k
+    ad = O.SharedAdam(1e-3)
+    P64 = {k: np.asarray(v, np.float64) for k, v in P.items()}
+    ad.apply(P64, g, O.G_KEYS)
+    want_m = Hh.gen_to_engine({k: ad.m[k] for k in O.G_KEYS})
+    for i in range(8):
+        assert Hh.rel_err(eng.g_m[i].cpu().numpy(), want_m[i]) < 5e-4, ("m", i)
+    # --- discriminator step with injected masks for both towers
+    nr = 40
+    rp = rng.integers(0, I, nr).astype(np.int32)
+    rn = rng.integers(0, I, nr).astype(np.int32)
+    dmr = [(rng.random((nr, w)) < dkeep).astype(np.uint8) for w in hs[1:]]
+    real = Pairs(t(rp), t(rn))
+    eng.adam_t = 0
+    dl = float(eng.d_step(real, fake, dkeep, rng_step=9, drop_real=[t(m) for m in dmr], drop_fake=[t(m) for m in dmf]).cpu().numpy()[0])
+    Tr = O.d_tower(D, rp, rn, [m.astype(np.float64) for m in dmr], dkeep)
+    want = -np.log(Tr["y"]).sum() - (np.log(1 - T["y"]) * valid).sum()
+    assert abs(dl - want) < 1e-4 * max(1.0, abs(want))
+    gr = O.d_tower_backward(D, Tr, [m.astype(np.float64) for m in dmr], dkeep, -(1 - Tr["y"]))
+    gf = O.d_tower_backward(D, T, [m.astype(np.float64) for m in dmf], dkeep, T["y"] * valid)
+    ad2 = O.SharedAdam(1e-3)
+    D64 = {k: np.asarray(v, np.float64) for k, v in D.items()}
+    ad2.apply(D64, {k: gr[k] + gf[k] for k in gr}, O.D_KEYS)
+    for i, k in enumerate(O.D_KEYS):
+        assert Hh.rel_err(eng.d_m[i].cpu().numpy().reshape(-1), ad2.m[k].reshape(-1)) < 5e-4, ("dm", k)
+
+
+def test_injected_sampler_uniforms():
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import _ptr
+    I, B = 500, 40
+    rng = np.random.default_rng(17)
+    eng = _engine(I, "fp32")
+    cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, valid = _sampler_problem(rng, B, I, False)
+    slot_ptr = np.concatenate([[0], np.cumsum(n_sample)]).astype(np.int32)
+    ns = int(slot_ptr[-1])
+    logits = rng.normal(0, 1.5, (B, I)).astype(np.float32)
+    mx = logits.max(1, keepdims=True).astype(np.float64)
+    lse = (mx + np.log(np.exp(logits - mx).sum(1, keepdims=True)))[:, 0].astype(np.float32)
+    u_g = rng.random(len(cand_idx)).astype(np.float32)
+    u_p = rng.random(ns).astype(np.float32)
+    acts = eng.new_acts(B)
+    acts.logits.copy_(torch.from_numpy(logits))
+    acts.lse.copy_(torch.from_numpy(lse))
+    dev = eng.device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d = [t(x) for x in (cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, slot_ptr, valid)]
+    ug, up = t(u_g), t(u_p)
+    samp = cabi.ltg_sample_inputs(B, int(np.diff(cand_ptr).max()), *[_ptr(x) for x in d], 3, _ptr(ug), _ptr(up), None)
+    gen = torch.full((ns,), -7, dtype=torch.int32, device=dev)
+    pop = torch.full((ns,), -7, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng.sample_pairs(samp, acts, gen, pop, cnt)
+    torch.cuda.synchronize()
+    gen, pop = gen.cpu().numpy(), pop.cpu().numpy()
+    total = 0
+    for b in range(B):
+        if n_sample[b] == 0:
+            continue
+        c = cand_idx[cand_ptr[b]:cand_ptr[b + 1]]
+        p = np.exp((logits[b, c] - lse[b]).astype(np.float64))
+        want = O.sample_user(c, p, int(n_sample[b]), u_g[cand_ptr[b]:cand_ptr[b + 1]].astype(np.float64))
+        s0 = slot_ptr[b]
+        xg, xp, kept = O.build_fake_pairs(want, pop_idx[pop_ptr[b]:pop_ptr[b + 1]], u_p[s0:s0 + len(want)], valid)
+        key = np.sort(O.gumbel_keys(p, u_g[cand_ptr[b]:cand_ptr[b + 1]].astype(np.float64)))[::-1]
+        k = len(want)
+        if k < len(key) and abs(key[k - 1] - key[k]) < 1e-4:
+            continue                                            # fp32-vs-fp64 tie at the selection boundary
+        assert np.array_equal(gen[s0:s0 + k], np.where(kept, want, -1)), b
+        exp_pop = np.full(k, -1)
+        exp_pop[np.array(kept, bool)] = xp
+        assert np.array_equal(pop[s0:s0 + k], exp_pop), b
+        total += int(np.sum(kept))
+    assert total > 0
