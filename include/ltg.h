@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 5
+#define LTG_ABI_VERSION 6
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -273,6 +273,21 @@ int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stre
 int ltg_rank_metrics(const ltg_config* cfg, const float* logits, const ltg_batch* tr,
                      const ltg_batch* te, int32_t k_ndcg, int32_t k_r1, int32_t k_r2, float* out,
                      ltg_stream stream);
+
+/* The same metrics cut at their two exchange points for item-sharded runs (cfg->item_lo / n_items = this rank's
+ * slab; tr holds LOCAL column ids of the slab, te GLOBAL ids; score/count arrays are indexed like te->indices, i.e.
+ * by the absolute entry positions te->indptr holds):
+ *   ltg_rank_scores  score_out[e] = logit of held-out entry e if this rank owns the item (-inf if it is a fold-in
+ *                    item of that row, train.py:341), 0 otherwise                       -> all-reduce(sum)
+ *   ltg_rank_counts  count_out[e] = #{local items ranked before entry e} (ties: lower GLOBAL id first, like
+ *                    ltg_rank_metrics)                                                  -> all-reduce(sum)
+ *   ltg_rank_finish  NDCG / Recall per row from the summed counts (eval_functions.py:24-38, :54-62). */
+int ltg_rank_scores(const ltg_config* cfg, const float* logits, const ltg_batch* tr, const ltg_batch* te,
+                    float* score_out, ltg_stream stream);
+int ltg_rank_counts(const ltg_config* cfg, const float* logits, const ltg_batch* tr, const ltg_batch* te,
+                    const float* score, int32_t* count_out, ltg_stream stream);
+int ltg_rank_finish(const ltg_batch* te, const int32_t* counts, int32_t k_ndcg, int32_t k_r1, int32_t k_r2,
+                    float* out, ltg_stream stream);
 
 #ifdef __cplusplus
 }

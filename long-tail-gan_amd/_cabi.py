@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
-LTG_ABI_VERSION = 5
+LTG_ABI_VERSION = 6
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -106,6 +106,9 @@ SYMBOLS = {
     "ltg_refresh_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,
                                    C.c_int32, C.c_int32, vp, vp]),
+    "ltg_rank_scores": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), vp, vp]),
+    "ltg_rank_counts": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), vp, vp, vp]),
+    "ltg_rank_finish": (C.c_int, [C.POINTER(ltg_batch), vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
 }
 
 _lib = None

@@ -1369,9 +1369,30 @@ __global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __res
 // rank(h) = #{i : score_i > score_h or (score_i == score_h and i < h)}, score = -inf on fold-in items.
 // ---------------------------------------------------------------------------------------------
 constexpr int RM_T = 16;  // held-out items processed per pass
-__global__ __launch_bounds__(NT) void k_rank_metrics(int I, const float* __restrict__ logits, const int32_t* __restrict__ tr_ptr,
+// Shared by the one-GPU path (score_in == nullptr, count_out == nullptr: everything in one launch) and the item-sharded
+// path (this rank's slab [item_lo, item_lo + I): scores of the held-out entries come all-reduced in score_in, the counts
+// of LOCAL items that beat each entry go to count_out for the all-reduce; te ids are GLOBAL, tr ids LOCAL).
+__device__ __forceinline__ void rank_finish_row(const int* cnt, int np, int k_ndcg, int k_r1, int k_r2, double* acc) {
+    for (int t = 0; t < np; ++t) {
+        const int r = cnt[t];
+        if (r < k_ndcg) acc[0] += 1.0 / log2((double)r + 2.0);
+        if (r < k_r1) acc[1] += 1.0;
+        if (r < k_r2) acc[2] += 1.0;
+    }
+}
+__device__ __forceinline__ void rank_write_row(float* out, const double* acc, int nte, int k_ndcg, int k_r1, int k_r2) {
+    double idcg = 0.0;
+    for (int r = 0; r < min(nte, k_ndcg); ++r) idcg += 1.0 / log2((double)r + 2.0);
+    out[0] = idcg != 0.0 ? (float)(acc[0] / idcg) : 0.f;
+    out[1] = nte > 0 ? (float)(acc[1] / (double)min(k_r1, nte)) : 0.f;
+    out[2] = nte > 0 ? (float)(acc[2] / (double)min(k_r2, nte)) : 0.f;
+    out[3] = idcg != 0.0 ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(NT) void k_rank_metrics(int I, int item_lo, const float* __restrict__ logits, const int32_t* __restrict__ tr_ptr,
                                                      const int32_t* __restrict__ tr_idx, const int32_t* __restrict__ te_ptr,
-                                                     const int32_t* __restrict__ te_idx, int k_ndcg, int k_r1, int k_r2,
+                                                     const int32_t* __restrict__ te_idx, const float* __restrict__ score_in,
+                                                     int32_t* __restrict__ count_out, int k_ndcg, int k_r1, int k_r2,
                                                      float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_bits[];  // ceil(I/32) words
     __shared__ int s_cnt[RM_T];
@@ -1393,9 +1414,14 @@ __global__ __launch_bounds__(NT) void k_rank_metrics(int I, const float* __restr
     for (int p0 = 0; p0 < nte; p0 += RM_T) {
         const int np = min(RM_T, nte - p0);
         if (tid < np) {
-            const int it = te_idx[t0 + p0 + tid];
+            const int it = te_idx[t0 + p0 + tid];       // global id
             s_it[tid] = it;
-            s_sc[tid] = ((s_bits[it >> 5] >> (it & 31)) & 1u) ? -INFINITY : row[it];
+            if (score_in) {
+                s_sc[tid] = score_in[t0 + p0 + tid];
+            } else {
+                const int l = it - item_lo;
+                s_sc[tid] = ((s_bits[l >> 5] >> (l & 31)) & 1u) ? -INFINITY : row[l];
+            }
             s_cnt[tid] = 0;
         }
         __syncthreads();
@@ -1404,9 +1430,10 @@ __global__ __launch_bounds__(NT) void k_rank_metrics(int I, const float* __restr
         for (int t = 0; t < RM_T; ++t) cnt[t] = 0;
         for (int i = tid; i < I; i += NT) {
             const float sc = ((s_bits[i >> 5] >> (i & 31)) & 1u) ? -INFINITY : row[i];
+            const int ig = i + item_lo;
 #pragma unroll
             for (int t = 0; t < RM_T; ++t)
-                if (t < np) cnt[t] += (sc > s_sc[t] || (sc == s_sc[t] && i < s_it[t])) ? 1 : 0;
+                if (t < np) cnt[t] += (sc > s_sc[t] || (sc == s_sc[t] && ig < s_it[t])) ? 1 : 0;
         }
 #pragma unroll
         for (int t = 0; t < RM_T; ++t) {
@@ -1418,24 +1445,46 @@ __global__ __launch_bounds__(NT) void k_rank_metrics(int I, const float* __restr
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            for (int t = 0; t < np; ++t) {
-                const int r = s_cnt[t];
-                if (r < k_ndcg) s_acc[0] += 1.0 / log2((double)r + 2.0);
-                if (r < k_r1) s_acc[1] += 1.0;
-                if (r < k_r2) s_acc[2] += 1.0;
-            }
+        if (count_out) {
+            if (tid < np) count_out[t0 + p0 + tid] = s_cnt[tid];
+        } else if (tid == 0) {
+            rank_finish_row(s_cnt, np, k_ndcg, k_r1, k_r2, s_acc);
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        double idcg = 0.0;
-        for (int r = 0; r < min(nte, k_ndcg); ++r) idcg += 1.0 / log2((double)r + 2.0);
-        out[(size_t)b * 4 + 0] = idcg != 0.0 ? (float)(s_acc[0] / idcg) : 0.f;
-        out[(size_t)b * 4 + 1] = nte > 0 ? (float)(s_acc[1] / (double)min(k_r1, nte)) : 0.f;
-        out[(size_t)b * 4 + 2] = nte > 0 ? (float)(s_acc[2] / (double)min(k_r2, nte)) : 0.f;
-        out[(size_t)b * 4 + 3] = idcg != 0.0 ? 1.f : 0.f;
+    if (tid == 0 && !count_out) rank_write_row(out + (size_t)b * 4, s_acc, nte, k_ndcg, k_r1, k_r2);
+}
+
+// scores of the held-out entries this rank owns (-inf on fold-in items), 0 for the others -> all-reduce(sum)
+__global__ __launch_bounds__(NT) void k_rank_scores(int I, int item_lo, int n_rows, const float* __restrict__ logits,
+                                                    const int32_t* __restrict__ tr_ptr, const int32_t* __restrict__ tr_idx,
+                                                    const int32_t* __restrict__ te_ptr, const int32_t* __restrict__ te_idx,
+                                                    float* __restrict__ score_out) {
+    const int b = blockIdx.x;
+    const int a0 = tr_ptr[b], a1 = tr_ptr[b + 1];
+    for (int e = te_ptr[b] + threadIdx.x; e < te_ptr[b + 1]; e += NT) {
+        const int l = te_idx[e] - item_lo;
+        float sc = 0.f;
+        if (l >= 0 && l < I) {
+            int lo = a0, hi = a1;                       // tr rows are sorted (CSR with sorted indices)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (tr_idx[mid] < l) lo = mid + 1; else hi = mid;
+            }
+            sc = (lo < a1 && tr_idx[lo] == l) ? -INFINITY : logits[(size_t)b * I + l];
+        }
+        score_out[e] = sc;
     }
+}
+
+__global__ void k_rank_finish(int n_rows, const int32_t* __restrict__ te_ptr, const int32_t* __restrict__ counts, int k_ndcg, int k_r1,
+                              int k_r2, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int t0 = te_ptr[b], nte = te_ptr[b + 1] - t0;
+    rank_finish_row(counts + t0, nte, k_ndcg, k_r1, k_r2, acc);
+    rank_write_row(out + (size_t)b * 4, acc, nte, k_ndcg, k_r1, k_r2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1961,8 +2010,40 @@ int ltg_rank_metrics(const ltg_config* cfg, const float* logits, const ltg_batch
     if (tr->n_rows == 0) return LTG_OK;
     const size_t lds = (size_t)((cfg->n_items + 31) / 32) * sizeof(unsigned);
     if (lds > 64 * 1024) return LTG_EINVAL;
-    hipLaunchKernelGGL(k_rank_metrics, dim3(tr->n_rows), dim3(NT), lds, (hipStream_t)stream, cfg->n_items, logits, tr->indptr, tr->indices,
-                       te->indptr, te->indices, k_ndcg, k_r1, k_r2, out);
+    hipLaunchKernelGGL(k_rank_metrics, dim3(tr->n_rows), dim3(NT), lds, (hipStream_t)stream, cfg->n_items, cfg->item_lo, logits,
+                       tr->indptr, tr->indices, te->indptr, te->indices, (const float*)nullptr, (int32_t*)nullptr, k_ndcg, k_r1, k_r2, out);
+    return check_launch();
+}
+
+int ltg_rank_scores(const ltg_config* cfg, const float* logits, const ltg_batch* tr, const ltg_batch* te, float* score_out,
+                    ltg_stream stream) {
+    clear_errors();
+    if (!cfg || !logits || !tr || !te || !score_out || tr->n_rows != te->n_rows) return LTG_EINVAL;
+    if (tr->n_rows == 0) return LTG_OK;
+    hipLaunchKernelGGL(k_rank_scores, dim3(tr->n_rows), dim3(NT), 0, (hipStream_t)stream, cfg->n_items, cfg->item_lo, tr->n_rows, logits,
+                       tr->indptr, tr->indices, te->indptr, te->indices, score_out);
+    return check_launch();
+}
+
+int ltg_rank_counts(const ltg_config* cfg, const float* logits, const ltg_batch* tr, const ltg_batch* te, const float* score,
+                    int32_t* count_out, ltg_stream stream) {
+    clear_errors();
+    if (!cfg || !logits || !tr || !te || !score || !count_out || tr->n_rows != te->n_rows) return LTG_EINVAL;
+    if (tr->n_rows == 0) return LTG_OK;
+    const size_t lds = (size_t)((cfg->n_items + 31) / 32) * sizeof(unsigned);
+    if (lds > 64 * 1024) return LTG_EINVAL;
+    hipLaunchKernelGGL(k_rank_metrics, dim3(tr->n_rows), dim3(NT), lds, (hipStream_t)stream, cfg->n_items, cfg->item_lo, logits,
+                       tr->indptr, tr->indices, te->indptr, te->indices, score, count_out, 0, 0, 0, (float*)nullptr);
+    return check_launch();
+}
+
+int ltg_rank_finish(const ltg_batch* te, const int32_t* counts, int32_t k_ndcg, int32_t k_r1, int32_t k_r2, float* out,
+                    ltg_stream stream) {
+    clear_errors();
+    if (!te || !counts || !out) return LTG_EINVAL;
+    if (te->n_rows == 0) return LTG_OK;
+    hipLaunchKernelGGL(k_rank_finish, dim3((te->n_rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, te->n_rows, te->indptr, counts,
+                       k_ndcg, k_r1, k_r2, out);
     return check_launch();
 }
 

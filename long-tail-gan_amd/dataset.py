@@ -218,10 +218,16 @@ class DeviceData:
 class EvalData:
     """Fold-in / held-out CSR pair on the device (load_tr_te_data, train.py:83-84, test.py:68-69)."""
 
-    def __init__(self, tr_csr, te_csr, device):
+    def __init__(self, tr_csr, te_csr, device, item_lo=0, item_hi=None):
+        """item_lo/item_hi: this rank's item slab -- the fold-in matrix is cut to those columns (re-indexed from 0, it
+        is both the generator input and the -inf mask); the held-out matrix keeps GLOBAL ids on every rank."""
         dev = torch.device(device)
         tr = tr_csr.tocsr()
         te = te_csr.tocsr()
+        self.row_norm2 = None
+        if (item_lo, item_hi) not in ((0, None), (0, tr.shape[1])):
+            self.row_norm2 = torch.from_numpy(np.asarray(tr.multiply(tr).sum(axis=1), dtype=np.float32).reshape(-1)).to(dev)
+            tr = tr[:, item_lo:item_hi].tocsr()
         tr.sort_indices()
         te.sort_indices()
         self.n = tr.shape[0]
@@ -231,4 +237,5 @@ class EvalData:
         self.tr_host, self.te_host = tr, te
 
     def rows(self, lo, hi):
-        return (CsrRows(self.tr_indptr, self.tr_indices, lo, hi), CsrRows(self.te_indptr, self.te_indices, lo, hi))
+        return (CsrRows(self.tr_indptr, self.tr_indices, lo, hi, row_norm2=self.row_norm2),
+                CsrRows(self.te_indptr, self.te_indices, lo, hi))

@@ -16,8 +16,8 @@ def discriminator(n_items, FEATURE_LEN, h0_size, h1_size, h2_size, h3_size, engi
         raise ValueError("pass engine=<the Engine created by generator_VAECF> (one shared graph, train.py:127-136)")
     want = (h0_size, h1_size, h2_size, h3_size)
     have = (engine.h0, engine.h1, engine.h2, engine.h3)
-    if want != have or engine.feature_len != FEATURE_LEN or engine.I != n_items:
-        raise ValueError("engine was built for D sizes %s / feature_len %d / n_items %d" % (have, engine.feature_len, engine.I))
+    if want != have or engine.feature_len != FEATURE_LEN or engine.I_global != n_items:
+        raise ValueError("engine was built for D sizes %s / feature_len %d / n_items %d" % (have, engine.feature_len, engine.I_global))
     x_generated_id = Placeholder("x_generated")      # discriminator.py:5
     x_popular_n_id = Placeholder("x_popular_n")      # :6
     x_popular_g_id = Placeholder("x_popular_g")      # :7

@@ -312,6 +312,18 @@ class Engine:
                                        k_r2, _ptr(out), self.stream())
         cabi.check(rc, "ltg_rank_metrics")
 
+    # ------------------------------------------------------------------ ranking metrics cut at their exchange points
+    def rank_scores(self, acts, tr, te, score_out):
+        cabi.check(self.lib.ltg_rank_scores(C.byref(self.cfg), _ptr(acts.logits), C.byref(tr.c), C.byref(te.c), _ptr(score_out),
+                                            self.stream()), "ltg_rank_scores")
+
+    def rank_counts(self, acts, tr, te, score, count_out):
+        cabi.check(self.lib.ltg_rank_counts(C.byref(self.cfg), _ptr(acts.logits), C.byref(tr.c), C.byref(te.c), _ptr(score),
+                                            _ptr(count_out), self.stream()), "ltg_rank_counts")
+
+    def rank_finish(self, te, counts, out, k_ndcg=100, k_r1=20, k_r2=50):
+        cabi.check(self.lib.ltg_rank_finish(C.byref(te.c), _ptr(counts), k_ndcg, k_r1, k_r2, _ptr(out), self.stream()), "ltg_rank_finish")
+
     # ------------------------------------------------------------------ views in the reference's shapes
     def generator_params_tf(self):
         """The 8 tensors in the reference's order and TF shapes (MultiVAE.py:129-141); W_p1 is a

@@ -107,3 +107,47 @@ class ShardedTrainer(Trainer):
                 eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
             self.last_anneal.append(a)
         return self.g_losses
+
+
+class ShardedEvaluator:
+    """Validation / test scoring over item shards (train.py:333-348, test.py:138-173).  Per chunk of users: the
+    sharded forward (one all-reduce of the encoder pre-activation), then two small exchanges for the ranking:
+      1. all-reduce(sum) of the held-out entries' scores   (float32 per held-out entry; the owner contributes)
+      2. all-reduce(sum) of the per-entry rank counts      (int32 per held-out entry)
+    The softmax is never materialised: ranking by logits equals ranking by probabilities row by row.  Every rank
+    ends with the identical metric table."""
+
+    def __init__(self, engine, ev, group=None, chunk=20000):
+        self.eng, self.ev, self.group = engine, ev, group
+        self.chunk = int(min(chunk, max(1, ev.n)))
+        self.acts = engine.new_acts(self.chunk)
+        dev = engine.device
+        n_te = max(1, int(ev.te_indices.numel()))
+        self.score = torch.zeros(n_te, dtype=torch.float32, device=dev)
+        self.count = torch.zeros(n_te, dtype=torch.int32, device=dev)
+        self.out = torch.zeros(ev.n, 4, dtype=torch.float32, device=dev)
+        self.rowpart = torch.zeros(self.chunk * 5, dtype=torch.float32, device=dev)
+
+    def run(self, rng_step=0, keep_prob=0.75):
+        eng, ev = self.eng, self.ev
+        te_ptr = ev.te_host.indptr
+        for lo in range(0, ev.n, self.chunk):
+            hi = min(ev.n, lo + self.chunk)
+            tr, te = ev.rows(lo, hi)
+            fo = eng.fwd_opts(keep_prob, 0.0, rng_step + lo)
+            eng.g_fwd_enc(tr, self.acts, fo)
+            dist.all_reduce(self.acts.h1[: hi - lo], op=dist.ReduceOp.SUM, group=self.group)
+            eng.g_fwd_rest(tr, None, self.acts, fo, self.rowpart)
+            e0, e1 = int(te_ptr[lo]), int(te_ptr[hi])
+            eng.rank_scores(self.acts, tr, te, self.score)
+            if e1 > e0:
+                dist.all_reduce(self.score[e0:e1], op=dist.ReduceOp.SUM, group=self.group)
+            eng.rank_counts(self.acts, tr, te, self.score, self.count)
+            if e1 > e0:
+                dist.all_reduce(self.count[e0:e1], op=dist.ReduceOp.SUM, group=self.group)
+            eng.rank_finish(te, self.count, self.out[lo:])
+        o = self.out.cpu().numpy().astype(np.float64)
+        ok = o[:, 3] > 0
+        n = int(ok.sum())
+        return dict(ndcg=float(o[ok, 0].mean()) if n else float("nan"), recall20=float(o[ok, 1].mean()) if n else float("nan"),
+                    recall50=float(o[ok, 2].mean()) if n else float("nan"), n_users=n)

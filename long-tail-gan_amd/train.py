@@ -9,6 +9,9 @@ the VAE-CF generator against the MLP discriminator and prints the reference's pr
 (train.py:280,303,329,348).  Checkpoints: chkpt/<dataset>_<model_name>_<GANLAMBDA>/model_<epoch>.pt
 (own format keyed by the reference's variable names; `to_restore=1` resumes from the latest one --
 the reference parses that key and ignores it, train.py:374).
+
+Multi-GPU: launch the same command under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1`;
+each rank owns an item slab (ltgan.sharded), rank 0 prints and writes the (full, world-size independent) checkpoints.
 """
 from __future__ import annotations
 
@@ -25,6 +28,7 @@ if __package__ in (None, ""):
     from ltgan.discriminator import discriminator
     from ltgan.engine import D_NAMES, G_NAMES
     from ltgan.generator import generator_VAECF as generator
+    from ltgan.sharded import ShardedEvaluator, ShardedTrainer, item_slab
     from ltgan.trainer import Evaluator, Trainer
 else:
     from . import data_processing as dp
@@ -32,17 +36,42 @@ else:
     from .discriminator import discriminator
     from .engine import D_NAMES, G_NAMES
     from .generator import generator_VAECF as generator
+    from .sharded import ShardedEvaluator, ShardedTrainer, item_slab
     from .trainer import Evaluator, Trainer
 
+SLAB_TENSORS = (0, 3, 7)        # W_q0 [I,H], W_p1t [I,H], b_p1 [I]: sharded by item; everything else is replicated
 
-def save_checkpoint(path, eng, tr, epoch):
+
+def _full(ts, eng, world):
+    """slab tensors of every rank -> full tensors on the host (equal-sized padded all-gather)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return [t.cpu() for t in ts]
+    out = []
+    per = item_slab(eng.I_global, 0, world)[1]
+    for i, t in enumerate(ts):
+        if i not in SLAB_TENSORS:
+            out.append(t.cpu())
+            continue
+        pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        out.append(torch.cat(parts)[: eng.I_global].cpu())
+    return out
+
+
+def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
     import torch
     st = {"epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step, "d_w1": eng.d_emb.cpu()}
+    gp, gm, gv = _full(eng.g_p, eng, world), _full(eng.g_m, eng, world), _full(eng.g_v, eng, world)     # collective: every rank
     for i, n in enumerate(G_NAMES):
-        st[n], st[n + "/Adam"], st[n + "/Adam_1"] = eng.g_p[i].cpu(), eng.g_m[i].cpu(), eng.g_v[i].cpu()
+        st[n], st[n + "/Adam"], st[n + "/Adam_1"] = gp[i], gm[i], gv[i]
     for i, n in enumerate(D_NAMES):
         st[n], st[n + "/Adam"], st[n + "/Adam_1"] = eng.d_p[i].cpu(), eng.d_m[i].cpu(), eng.d_v[i].cpu()
-    torch.save(st, path)
+    if rank == 0:
+        torch.save(st, path)
 
 
 def load_checkpoint(path, eng, tr):
@@ -57,25 +86,41 @@ def load_checkpoint(path, eng, tr):
 
 
 def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BATCH_SIZE, DISPLAY_ITER, LEARNING_RATE, to_restore,
-              model_name, dataset, GANLAMBDA, precision="bf16", device="cuda:0", max_epochs=None):
+              model_name, dataset, GANLAMBDA, precision="bf16", device=None, max_epochs=None):
     """Codes/train.py:30-356 (same argument list)."""
+    import builtins
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if device is None:
+        import torch
+        device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get("LTGAN_DIST_BACKEND", "nccl"))       # "nccl" is RCCL on ROCm
+    print = builtins.print if rank == 0 else (lambda *a, **k: None)                      # noqa: A001  (rank 0 reports)
     DATA_DIR = dataset + "/"
     dataset_name = dataset.split("/")[-1].strip() or dataset.split("/")[-2].strip()
     output_path = "chkpt/" + dataset_name + "_" + model_name + "_" + str(GANLAMBDA) + "/"   # train.py:45 (relative to CWD, Q14)
     os.makedirs(output_path, exist_ok=True)
-    idx = IndexData.from_dir(DATA_DIR, verbose=True)
+    idx = IndexData.from_dir(DATA_DIR, verbose=rank == 0)
     n_items, N = idx.n_items, idx.N
     vtr, vte, _ = dp.load_tr_te_data(os.path.join(DATA_DIR, "validation_tr.csv"), os.path.join(DATA_DIR, "validation_te.csv"), n_items)
     print("Number of Users: ", N)
     print("Batches Per Epoch: ", (N + BATCH_SIZE - 1) // BATCH_SIZE)
+    lo, hi = item_slab(n_items, rank, world) if world > 1 else (0, n_items)
     gen_net, generator_out, g_vae_loss, g_params, p_dims, total_anneal_steps, anneal_cap = generator(
-        DATA_DIR, h_sizes=(h0_size, h1_size, h2_size, h3_size), lr=LEARNING_RATE, precision=precision, device=device)
+        DATA_DIR, h_sizes=(h0_size, h1_size, h2_size, h3_size), lr=LEARNING_RATE, precision=precision, device=device,
+        item_lo=lo, item_hi=hi)
     eng = gen_net.engine
     discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size, engine=eng)
-    data = DeviceData(idx, BATCH_SIZE, eng.device)
-    tr = Trainer(eng, data, num_sub_epochs=NUM_SUB_EPOCHS, gan_lambda=GANLAMBDA, total_anneal_steps=total_anneal_steps,
-                 anneal_cap=anneal_cap)
-    ev = Evaluator(eng, EvalData(vtr, vte, eng.device))
+    data = DeviceData(idx, BATCH_SIZE, eng.device, item_lo=lo, item_hi=hi)
+    kw = dict(num_sub_epochs=NUM_SUB_EPOCHS, gan_lambda=GANLAMBDA, total_anneal_steps=total_anneal_steps, anneal_cap=anneal_cap)
+    if world > 1:
+        tr = ShardedTrainer(eng, data, **kw)
+        ev = ShardedEvaluator(eng, EvalData(vtr, vte, eng.device, item_lo=lo, item_hi=hi))
+    else:
+        tr = Trainer(eng, data, **kw)
+        ev = Evaluator(eng, EvalData(vtr, vte, eng.device))
     start = 0
     if to_restore:
         ck = sorted(glob.glob(os.path.join(output_path, "model_*.pt")), key=lambda p: int(p.split("_")[-1][:-3]))
@@ -99,9 +144,13 @@ def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BAT
         print("global-epoch:", i, "gen-epoch:", NUM_SUB_EPOCHS - 1, "Vad: NDCG:", m["ndcg"], "Recall@20:", m["recall20"], "Recall@50:",
               m["recall50"], "Num_users:", m["n_users"], m["n_users"], m["n_users"])
         print("")
-        save_checkpoint(os.path.join(output_path, "model_%d.pt" % i), eng, tr, i)
+        save_checkpoint(os.path.join(output_path, "model_%d.pt" % i), eng, tr, i, rank, world)
         print("Model saved at global-epoch", i)
         last = m
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return last
 
 

@@ -34,6 +34,31 @@ def main():
     eng = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi)
     data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
     tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1)
+    # ---- ranking metrics over the shards (before training: parameters are identical, only the all-reduce order differs)
+    import scipy.sparse as sp
+    from ltgan.dataset import EvalData
+    from ltgan.sharded import ShardedEvaluator
+    from ltgan.trainer import Evaluator
+    rs = np.random.default_rng(11)
+    n_ev = min(idx.N, 230)
+    fold = idx.train[:n_ev]
+    te_rows = np.repeat(np.arange(n_ev), 6)
+    te = sp.csr_matrix((np.ones(len(te_rows), np.float32), (te_rows, rs.integers(0, I, len(te_rows)))), shape=(n_ev, I))
+    te.data[:] = 1.0
+    te = te[:, :].tolil()
+    te[3] = 0                                                    # a user without held-out items (IDCG == 0: dropped, like the reference)
+    te = te.tocsr()
+    te.eliminate_zeros()
+    m_ref = Evaluator(ref, EvalData(fold, te, dev), chunk=100)
+    want = m_ref.run(rng_step=900)
+    m_sh = ShardedEvaluator(eng, EvalData(fold, te, dev, item_lo=lo, item_hi=hi), chunk=100)
+    got = m_sh.run(rng_step=900)
+    a, b = m_ref.out.cpu().numpy(), m_sh.out.cpu().numpy()
+    same = np.all(a == b, axis=1).mean()
+    assert same > 0.97, ("rows with identical metrics", same)
+    assert got["n_users"] == want["n_users"] == n_ev - 1
+    for k in ("ndcg", "recall20", "recall50"):
+        assert abs(got[k] - want[k]) < 2e-3, (k, got[k], want[k])
     for epoch in range(2):
         ref_tr.create_phase()
         tr.create_phase()

@@ -58,3 +58,35 @@ def test_train_cli_needs_config_in_cwd(tmp_path):
     script = os.path.join(ROOT, "long-tail-gan_amd", "train.py")
     out = subprocess.run([sys.executable, script, "/nonexistent"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "config.ini" in out.stderr
+
+
+def test_train_cli_under_torchrun_item_sharded(tmp_path):
+    """Two ranks (gloo, both on the one GPU of the test box) run the same CLI: rank 0 prints the reference's lines,
+    the checkpoint holds FULL tensors, and a single-process run resumes from it (world-size independent format)."""
+    import torch
+    from ltgan.dataset import materialize_askubuntu
+    ds = str(tmp_path / "Askubuntu_Sample")
+    materialize_askubuntu(os.path.join(ROOT, "tests", "golden", "askubuntu_raw.npz"), ds)
+    cwd = str(tmp_path / "run")
+    os.makedirs(cwd)
+    script = os.path.join(ROOT, "long-tail-gan_amd", "train.py")
+    open(os.path.join(cwd, "config.ini"), "w").write(CONFIG.format(num_epoch=8, to_restore=0))
+    env = dict(os.environ, LTGAN_MAX_EPOCHS="1", LTGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", script, ds]
+    out = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    txt = out.stdout
+    assert txt.count("global-epoch: 0 Data Creation Finished user_err_cnt: 468") == 1           # rank 0 only
+    ndcg = [float(l.split("NDCG:")[1].split()[0]) for l in txt.splitlines() if "Vad: NDCG:" in l]
+    assert len(ndcg) == 1 and 0.15 < ndcg[0] < 0.5
+    ck = os.path.join(cwd, "chkpt", "Askubuntu_Sample_LT_GAN_1.0", "model_0.pt")
+    st = torch.load(ck, map_location="cpu")
+    for k in ("weight_q_0to1", "weight_p_1to2", "weight_p_1to2/Adam", "weight_q_0to1/Adam_1"):
+        assert tuple(st[k].shape) == (1000, 600), k
+    assert tuple(st["bias_p_2"].shape) == (1000,) and float(st["weight_p_1to2/Adam_1"].abs().sum()) > 0
+    open(os.path.join(cwd, "config.ini"), "w").write(CONFIG.format(num_epoch=8, to_restore=1))
+    env = dict(os.environ, LTGAN_MAX_EPOCHS="1")
+    out = subprocess.run([sys.executable, script, ds], cwd=cwd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "Restored" in out.stdout and "global-epoch: 1 Data Creation Finished" in out.stdout

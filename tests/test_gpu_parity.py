@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 SEED = 1234
 
 
-def _engine(I, precision, hs=(100, 150, 250, 300), lr=1e-4):
+def _engine(I, precision, hs=(100, 150, 250, 300), lr=1e-4, **kw):
     import torch
     from ltgan.engine import Engine
     assert torch.cuda.is_available()
-    return Engine(I, h_sizes=hs, lr=lr, precision=precision, seed=SEED)
+    return Engine(I, h_sizes=hs, lr=lr, precision=precision, seed=SEED, **kw)
 
 
 def _problem(I, B, seed=0, mean_nnz=18):
@@ -467,3 +467,57 @@ def test_injected_sampler_uniforms():
         assert np.array_equal(pop[s0:s0 + k], exp_pop), b
         total += int(np.sum(kept))
     assert total > 0
+
+
+def test_rank_metrics_cut_at_exchange_points_equals_fused():
+    """ltg_rank_scores / ltg_rank_counts / ltg_rank_finish over two item slabs (sums done by hand instead of the
+    all-reduce) == ltg_rank_metrics on the full rows, bit for bit; ties and masked held-out items included."""
+    import torch
+    import scipy.sparse as sp
+    from ltgan.engine import CsrRows
+    I, B = 1000, 37
+    rng = np.random.default_rng(23)
+    logits = np.round(rng.normal(0, 1, (B, I)), 1).astype(np.float32)           # many exact ties
+    X = Hh.random_history(rng, B, I, mean_nnz=30)
+    te_r = np.repeat(np.arange(B), 9)
+    te = sp.csr_matrix((np.ones(len(te_r), np.float32), (te_r, rng.integers(0, I, len(te_r)))), shape=(B, I))
+    te.data[:] = 1.0
+    te[5, X[5].indices[:3]] = 1.0                                               # held-out items that are also fold-in items
+    te = te.tolil(); te[7] = 0; te = te.tocsr(); te.eliminate_zeros(); te.sort_indices()
+    full = _engine(I, "fp32")
+    dev = full.device
+    t = lambda a, dt=np.int32: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dt))).to(dev)
+    te_c = CsrRows(t(te.indptr), t(te.indices), 0, B)
+    acts = full.new_acts(B)
+    acts.logits.copy_(torch.from_numpy(logits))
+    out_full = torch.zeros(B, 4, device=dev)
+    full.rank_metrics(acts, CsrRows(t(X.indptr), t(X.indices), 0, B), te_c, out_full)
+    cut = 448
+    score = torch.zeros(te.nnz, device=dev)
+    count = torch.zeros(te.nnz, dtype=torch.int32, device=dev)
+    shards = []
+    for lo, hi in ((0, cut), (cut, I)):
+        e = _engine(I, "fp32", item_lo=lo, item_hi=hi)
+        a = e.new_acts(B)
+        a.logits.copy_(torch.from_numpy(np.ascontiguousarray(logits[:, lo:hi])))
+        Xs = X[:, lo:hi].tocsr(); Xs.sort_indices()
+        trc = CsrRows(t(Xs.indptr), t(Xs.indices), 0, B)
+        s = torch.zeros(te.nnz, device=dev)
+        e.rank_scores(a, trc, te_c, s)
+        score += s
+        shards.append((e, a, trc))
+    for e, a, trc in shards:
+        c = torch.zeros(te.nnz, dtype=torch.int32, device=dev)
+        e.rank_counts(a, trc, te_c, score, c)
+        count += c
+    out_cut = torch.zeros(B, 4, device=dev)
+    shards[0][0].rank_finish(te_c, count, out_cut)
+    torch.cuda.synchronize()
+    assert torch.equal(out_full, out_cut)
+    # and the oracle on the same matrix
+    pred = logits.astype(np.float64).copy()
+    pred[X.nonzero()] = -np.inf
+    want = O.ndcg_binary_at_k(pred, te.toarray(), 100)
+    got = out_cut.cpu().numpy()
+    ok = got[:, 3] > 0
+    assert ok.sum() == B - 1 and np.allclose(got[ok, 0], want, atol=1e-6)
