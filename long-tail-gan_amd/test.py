@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Test CLI with the reference's surface (Codes/test.py:30-203):
+
+    cd <dir holding config.ini> && python <repo>/long-tail-gan_amd/test.py <dataset_dir> <checkpoint>
+
+restores a checkpoint written by train.py (`model_<epoch>.pt`), scores `test_tr.csv` / `test_te.csv` in chunks of
+20 000 users (test.py:76) with the generator forward (dropout ON: Q3), masks the fold-in items to -inf (test.py:149)
+and prints `NDCG@100 \\t Recall@20 \\t Recall@50` (test.py:173).  Scores never leave the GPU (ltg_rank_metrics).
+Under `python -m torch.distributed.run --nproc-per-node N` the items are sharded like in train.py.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import ltgan  # noqa: F401  (alias of this package directory)
+    from ltgan import data_processing as dp
+    from ltgan.dataset import EvalData, count_items
+    from ltgan.discriminator import discriminator
+    from ltgan.generator import generator_VAECF as generator
+    from ltgan.sharded import ShardedEvaluator, item_slab
+    from ltgan.train import load_checkpoint, read_config
+    from ltgan.trainer import Evaluator
+else:
+    from . import data_processing as dp
+    from .dataset import EvalData, count_items
+    from .discriminator import discriminator
+    from .generator import generator_VAECF as generator
+    from .sharded import ShardedEvaluator, item_slab
+    from .train import load_checkpoint, read_config
+    from .trainer import Evaluator
+
+
+class _Counters:
+    """load_checkpoint also restores the trainer's counters; the test flow has no trainer."""
+    update_count = 0.0
+    rng_step = 0
+
+
+def test_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BATCH_SIZE, DISPLAY_ITER, LEARNING_RATE, to_restore,
+             model_name, dataset, GANLAMBDA, output_path, precision="bf16", device=None, batch_size_test=20000):
+    """Codes/test.py:30-173 (same argument list)."""
+    import builtins
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if device is None:
+        import torch
+        device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get("LTGAN_DIST_BACKEND", "nccl"))
+    print = builtins.print if rank == 0 else (lambda *a, **k: None)                      # noqa: A001
+    DATA_DIR = dataset + "/"
+    n_items = count_items(DATA_DIR)
+    print("Loading Test Matrix...", end="")
+    tr, te, _ = dp.load_tr_te_data(os.path.join(DATA_DIR, "test_tr.csv"), os.path.join(DATA_DIR, "test_te.csv"), n_items)
+    print("N_test:", tr.shape[0])
+    lo, hi = item_slab(n_items, rank, world) if world > 1 else (0, n_items)
+    gen_net, *_ = generator(DATA_DIR, h_sizes=(h0_size, h1_size, h2_size, h3_size), lr=LEARNING_RATE, precision=precision,
+                            device=device, item_lo=lo, item_hi=hi)
+    eng = gen_net.engine
+    discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size, engine=eng)
+    load_checkpoint(output_path, eng, _Counters())
+    print("Model Loaded")
+    if world > 1:
+        ev = ShardedEvaluator(eng, EvalData(tr, te, eng.device, item_lo=lo, item_hi=hi), chunk=batch_size_test)
+    else:
+        ev = Evaluator(eng, EvalData(tr, te, eng.device), chunk=batch_size_test)
+    m = ev.run(rng_step=2 * 10 ** 9)
+    print(str(m["ndcg"]) + "\t" + str(m["recall20"]) + "\t" + str(m["recall50"]))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return m
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 3:
+        sys.exit("usage: test.py <dataset_dir> <checkpoint>   (config.ini is read from the current directory)")
+    test_GAN(dataset=sys.argv[1], output_path=sys.argv[2], **read_config())

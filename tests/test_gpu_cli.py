@@ -52,6 +52,21 @@ def test_train_cli_two_epochs_and_resume(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "Restored" in out.stdout and "global-epoch: 2 Data Creation Finished" in out.stdout
     assert "model_2.pt" in os.listdir(ck)
+    # test.py: restore -> chunked scoring -> "NDCG@100<TAB>R@20<TAB>R@50" (Codes/test.py:134-173)
+    tscript = os.path.join(ROOT, "long-tail-gan_amd", "test.py")
+    out = subprocess.run([sys.executable, tscript, ds, os.path.join(ck, "model_2.pt")], cwd=cwd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "Model Loaded" in out.stdout
+    vals = [float(x) for x in out.stdout.strip().splitlines()[-1].split("\t")]
+    assert len(vals) == 3 and 0.15 < vals[0] < 0.5 and 0.0 < vals[1] <= vals[2] <= 1.0
+    # the same under torchrun (2 ranks, item-sharded): same numbers up to all-reduce order
+    env2 = dict(os.environ, LTGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", tscript, ds, os.path.join(ck, "model_2.pt")]
+    out2 = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, env=env2, timeout=1200)
+    assert out2.returncode == 0, out2.stdout[-2000:] + out2.stderr[-4000:]
+    vals2 = [float(x) for x in [l for l in out2.stdout.strip().splitlines() if l.count("\t") == 2][-1].split("\t")]
+    assert max(abs(a - b) for a, b in zip(vals, vals2)) < 3e-3
 
 
 def test_train_cli_needs_config_in_cwd(tmp_path):
