@@ -227,6 +227,15 @@ constexpr int ST_KP = 608;      // K padded to 19 x 32
 constexpr int ST_LDW = 616;     // LDS row stride in bf16 (1232 B: 16-B aligned rows, conflict-free fragment reads)
 constexpr int ST_KS = ST_KP / 32;
 
+// A wave-uniform GLOBAL pointer pinned to SGPRs: `ltg_uniform_ptr(base + uniform) + (unsigned)lane_offset` selects the
+// scalar-base form of global_load/store (one 32-bit VGPR offset) instead of a 64-bit VGPR address per access.
+typedef char __attribute__((address_space(1))) ltg_gchar;
+typedef unsigned ltg_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ltg_gchar* ltg_uniform_ptr(const void* p) {
+    const uint64_t x = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return (ltg_gchar*)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ uint2 ltg_pack4(float4 v) {
     return make_uint2((unsigned)ltg_f2bf(v.x) | ((unsigned)ltg_f2bf(v.y) << 16), (unsigned)ltg_f2bf(v.z) | ((unsigned)ltg_f2bf(v.w) << 16));
 }
@@ -415,26 +424,41 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     __shared__ __attribute__((aligned(16))) unsigned short Dl[2][128 * DW_LDD];
     __shared__ __attribute__((aligned(16))) float Cs[8 * 32 * DW_LDC];   // per-wave [32][80] gradient blocks
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
+    float4 *W4 = reinterpret_cast<float4*>(st.p[3]), *M4 = reinterpret_cast<float4*>(st.m[3]), *V4 = reinterpret_cast<float4*>(st.v[3]);
+    float *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
     unsigned short* Wb = st.wp1t_bf16;
-    // stationary B fragments: B[k = b][n] = h2[b][n] (n < H), 1 (n == H), 0 beyond
+    // stationary B fragments: B[k = b][n] = h2[b][n] (n < H), 1 (n == H), 0 beyond.  Built through LDS in four
+    // 32-row slices (coalesced float4 reads, bf16 image with a conflict-free 650-element row stride); gathering the
+    // 160 values of a lane straight from global memory makes the compiler hoist 160 loads and spill the fragments.
     ltg_bf16x8 bf[5][4];
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-        const int n = 80 * w + 16 * nt + lr;
+    {
+        constexpr int HS = 650;
+        unsigned short* Hs = reinterpret_cast<unsigned short*>(Cs);   // [32][HS] bf16 = 41.6 KB of the 86 KB slab area
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            ltg_u16x8 t;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int b = ks * 32 + 8 * lq + j;
-                const float v = h2[(size_t)min(b, B - 1) * H + min(n, H - 1)];
-                t[j] = b < B ? (n < H ? ltg_f2bf(v) : (n == H ? (unsigned short)0x3F80 : (unsigned short)0)) : (unsigned short)0;
+            for (int e = tid; e < 32 * 160; e += ST_NT) {
+                const int rr = e / 160, n = 4 * (e % 160), b = ks * 32 + rr;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < B && n < H) v = *reinterpret_cast<const float4*>(h2 + (size_t)b * H + n);
+                uint2 pk = ltg_pack4(v);
+                if (b < B && n == H) pk.x = 0x3F80u;                  // the ones column
+                unsigned* dst = reinterpret_cast<unsigned*>(Hs + rr * HS + n);
+                dst[0] = pk.x;
+                dst[1] = pk.y;
             }
-            bf[nt][ks] = __builtin_bit_cast(ltg_bf16x8, t);
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                const int n = 80 * w + 16 * nt + lr;
+                ltg_u16x8 t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = Hs[(8 * lq + j) * HS + n];
+                bf[nt][ks] = __builtin_bit_cast(ltg_bf16x8, t);
+            }
+            __syncthreads();
         }
     }
-    const int ntiles = (I + 31) / 32, G = gridDim.x;
+    const int ntiles = I / 32, G = gridDim.x;   // full tiles only: the host sends the ragged tail (I % 32 rows) to k_dec1_bwd_adam
     // dlog tile loader: thread -> (row b = tid / 4, 8 items at 8 * (tid % 4))
     const int lb = tid >> 2, lseg = tid & 3;
     const float* lrow = dlog + (size_t)min(lb, B - 1) * I;
@@ -455,86 +479,146 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     if (t < ntiles) {
         fetch(t, x0, x1);
         stash(Dl[0], t, x0, x1);
+        fetch(t + G < ntiles ? t + G : t, x0, x1);
     }
     __syncthreads();
     const int tq = lr >> 2, tp = lr & 3;
-    for (; t < ntiles; t += G) {
-        const bool more = t + G < ntiles;
-        if (more) fetch(t + G, x0, x1);
-        ltg_f32x4 acc[2][5];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned short* D = Dl[cur];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;
-                const unsigned short* base = D + (ks * 32 + 8 * lq + tq) * DW_LDD + mt * 16 + 4 * tp;
-                const ltg_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)base);
-                const ltg_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * DW_LDD));
-                ltg_u16x8 au;
-                au[0] = a0[0]; au[1] = a0[1]; au[2] = a0[2]; au[3] = a0[3];
-                au[4] = a1[0]; au[5] = a1[1]; au[6] = a1[2]; au[7] = a1[3];
-                const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt][ks], acc[mt][nt], 0, 0, 0);
-            }
-        }
-        // Adam epilogue: the wave's [32 items][80 columns] gradient block takes a round trip through its private
-        // LDS slab so that theta / m / v are walked in float4 over 320-B row segments (16 B per lane).
-        float* Cw = Cs + w * (32 * DW_LDC);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Cw[(mt * 16 + 4 * lq + q) * DW_LDC + 16 * nt + lr] = acc[mt][nt][q];
-        __syncthreads();
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 pv[5], mv[5], vv[5], gv[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int e = lane + 64 * (5 * half + j);          // 640 float4 per wave: row = e / 20, chunk = e % 20
-                const int rr = e / 20, c4 = e % 20;
-                const int i = t * 32 + rr, n = 80 * w + 4 * c4;
-                const size_t o = ((size_t)min(i, I - 1) * H + min(n, H - 4)) >> 2;
-                pv[j] = reinterpret_cast<const float4*>(W)[o];
-                mv[j] = reinterpret_cast<const float4*>(mW)[o];
-                vv[j] = reinterpret_cast<const float4*>(vW)[o];
-                gv[j] = *reinterpret_cast<const float4*>(Cw + rr * DW_LDC + 4 * c4);
-            }
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int e = lane + 64 * (5 * half + j);
-                const int rr = e / 20, c4 = e % 20;
-                const int i = t * 32 + rr, n = 80 * w + 4 * c4;
-                if (i < I && n < H) {
-                    float4 p = pv[j], mm = mv[j], v2 = vv[j];
-                    const float4 g = gv[j];
-#define LTG_ADAM4(f)                                  \
+    // ---- Adam epilogue geometry.  A wave's [32 items][80 columns] gradient block = 32 x 20 16-byte chunks:
+    //   pass 1: lane -> chunk c1 = lane % 16 of rows r1 + 4 jj (r1 = lane / 16, jj = 0..7)  -- 8 float4 per lane
+    //   pass 2: lane -> chunk c2 = 16 + lane % 4 of rows r2 + 16 jj (r2 = lane / 4, jj = 0..1) -- 2 float4 per lane
+    // Row-constant lane predicates (no per-element branches), constant strides between the jj of a lane.  theta / m / v
+    // travel in five software-pipelined stages of 2 float4 per lane and tile (pass-1 rows 0..7, 8..15, 16..23, 24..31,
+    // pass 2) over two register sets: the loads of the next stage -- at the end of a tile: of the NEXT tile's first
+    // stage -- are issued before the current stage is consumed, so HBM requests stay in flight through the MFMA phase
+    // and the barriers.  (Deeper stages do not fit: the stationary fragments hold 80 of the 256 VGPRs.)
+    float* Cw = Cs + w * (32 * DW_LDC);
+    const int ncw = max(0, min(20, (H - 80 * w) >> 2));      // valid chunks of this wave's column block
+    const int c1 = lane & 15, r1 = lane >> 4, c2 = 16 + (lane & 3), r2 = lane >> 2;
+    // lane offsets of the two passes in BYTES: into theta/m/v rows, the shadow rows; in floats into the wave's LDS slab
+    const unsigned rowB = (unsigned)H * 4u;
+    const unsigned lo1 = r1 * rowB + 16u * (20 * w + c1), lo2 = r2 * rowB + 16u * (20 * w + c2);
+    const int cl1 = r1 * DW_LDC + 4 * c1, cl2 = r2 * DW_LDC + 4 * c2;
+    const unsigned sl1 = 2u * (r1 * ST_KP + 80 * w + 4 * c1), sl2 = 2u * (r2 * ST_KP + 80 * w + 4 * c2);
+    const bool ones_here = 80 * w <= H && H < 80 * w + 80;  // the wave that owns the ones column (bias gradient)
+    ltg_f32x4 Ap[2], Am[2], Av[2], Bp[2], Bm[2], Bv[2];
+#define DW_ADAM1(f)                                   \
     mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;        \
     v2.f = ad.b2 * v2.f + (1.f - ad.b2) * g.f * g.f;  \
     p.f = p.f - ad.lr_t * mm.f / (sqrtf(v2.f) + ad.eps);
-                    LTG_ADAM4(x) LTG_ADAM4(y) LTG_ADAM4(z) LTG_ADAM4(w)
-#undef LTG_ADAM4
-                    const size_t o = ((size_t)i * H + n) >> 2;
-                    reinterpret_cast<float4*>(W)[o] = p;
-                    reinterpret_cast<float4*>(mW)[o] = mm;
-                    reinterpret_cast<float4*>(vW)[o] = v2;
-                    if (Wb) *reinterpret_cast<uint2*>(Wb + (size_t)i * ST_KP + n) = ltg_pack4(p);
-                } else if (i < I && n == H) {
-                    adam_update(bb, mb, vb, i, gv[j].x, ad);   // the ones column: bias gradient
-                }
-            }
-        }
-        if (more) stash(Dl[cur ^ 1], t + G, x0, x1);
-        __syncthreads();
-        cur ^= 1;
+    // addressing: (uniform row base, computed on the scalar unit) + (one 32-bit lane offset per pass) -- global_load with
+    // an SGPR base, so the unrolled stages do not pin a VGPR pair per access
+#define DW_AT(T, BASE, UB, LB) (*(T __attribute__((address_space(1)))*)(ltg_uniform_ptr(reinterpret_cast<const char*>(BASE) + (UB)) + (LB)))
+#define DW_LD(S, tt, NJ, UROW, RSTEP, LOFF)                                             \
+    _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
+        const size_t u = (size_t)((tt) * 32 + (UROW) + (RSTEP) * jj) * rowB;            \
+        S##p[jj] = DW_AT(const ltg_f32x4, W4, u, LOFF);                                    \
+        S##m[jj] = DW_AT(const ltg_f32x4, M4, u, LOFF);                                    \
+        S##v[jj] = DW_AT(const ltg_f32x4, V4, u, LOFF);                                    \
     }
+#define DW_AP(S, tt, NJ, UROW, RSTEP, LOFF, CLOFF, SLOFF)                               \
+    _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
+        const int urow = (UROW) + (RSTEP) * jj;                                         \
+        const float4 g = *reinterpret_cast<const float4*>(Cw + urow * DW_LDC + (CLOFF)); \
+        ltg_f32x4 p = S##p[jj], mm = S##m[jj], v2 = S##v[jj];                           \
+        DW_ADAM1(x) DW_ADAM1(y) DW_ADAM1(z) DW_ADAM1(w)                                 \
+        const size_t u = (size_t)((tt) * 32 + urow) * rowB;                             \
+        DW_AT(ltg_f32x4, W4, u, LOFF) = p;                                              \
+        DW_AT(ltg_f32x4, M4, u, LOFF) = mm;                                             \
+        DW_AT(ltg_f32x4, V4, u, LOFF) = v2;                                             \
+        const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                    \
+        DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + urow) * (ST_KP * 2), SLOFF) = ltg_u32x2{pk.x, pk.y}; \
+    }
+    // one tile: set A holds the first stage of tile t (requested one stage earlier); six stages alternate A, B so the
+    // next tile starts on A again -- one loop body, no register-set swap (a swap would have to wait for loads in flight)
+#define DW_BODY()                                                                                              \
+    {                                                                                                                \
+        const bool more = t + G < ntiles;                                                                            \
+        const int tn = more ? t + G : t;                                                                             \
+        ltg_f32x4 acc[2][5];                                                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                             \
+            _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};            \
+        const unsigned short* D = Dl[cur];                                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                       \
+                typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;                                         \
+                const unsigned short* base = D + (ks * 32 + 8 * lq + tq) * DW_LDD + mt * 16 + 4 * tp;                \
+                const ltg_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)base);                           \
+                const ltg_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * DW_LDD));            \
+                ltg_u16x8 au;                                                                                        \
+                au[0] = a0[0]; au[1] = a0[1]; au[2] = a0[2]; au[3] = a0[3];                                          \
+                au[4] = a1[0]; au[5] = a1[1]; au[6] = a1[2]; au[7] = a1[3];                                          \
+                const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);                                            \
+                _Pragma("unroll") for (int nt = 0; nt < 5; ++nt)                                                     \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt][ks], acc[mt][nt], 0, 0, 0);     \
+            }                                                                                                        \
+        }                                                                                                            \
+        /* the wave's gradient block takes a round trip through its private LDS slab (MFMA C layout -> row chunks) */ \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                             \
+            _Pragma("unroll") for (int nt = 0; nt < 5; ++nt)                                                         \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) Cw[(mt * 16 + 4 * lq + q) * DW_LDC + 16 * nt + lr] = acc[mt][nt][q]; \
+        __syncthreads();                                                                                             \
+        /* dlog: x (tile t + G, requested one tile ago) -> the idle LDS buffer; request tile t + 2G.  Both             \
+           unconditional (clamped): a branch around either ends in vmcnt(0) at its join. */                          \
+        stash(Dl[cur ^ 1], more ? t + G : t, x0, x1);                                                                \
+        fetch(t + 2 * G < ntiles ? t + 2 * G : t, x0, x1);                                                           \
+        if (ones_here && lane < 32)                                                                                  \
+            adam_update(bb, mb, vb, t * 32 + lane, Cw[lane * DW_LDC + (H - 80 * w)], ad);                            \
+        if (ncw == 20) { /* wave-uniform: no lane predicates, so every s_waitcnt below is an exact count */          \
+            DW_LD(B, t, 2, 8, 4, lo1)                                                                                \
+            DW_AP(A, t, 2, 0, 4, lo1, cl1, sl1)                                                                      \
+            DW_LD(A, t, 2, 16, 4, lo1)                                                                               \
+            DW_AP(B, t, 2, 8, 4, lo1, cl1, sl1)                                                                      \
+            DW_LD(B, t, 2, 24, 4, lo1)                                                                               \
+            DW_AP(A, t, 2, 16, 4, lo1, cl1, sl1)                                                                     \
+            DW_LD(A, t, 1, 0, 16, lo2)                                                                               \
+            DW_AP(B, t, 2, 24, 4, lo1, cl1, sl1)                                                                     \
+            DW_LD(B, t, 1, 16, 16, lo2)                                                                              \
+            DW_AP(A, t, 1, 0, 16, lo2, cl2, sl2)                                                                     \
+            DW_LD(A, tn, 2, 0, 4, lo1) /* first stage of the next tile (of this one again at the end: unused) */     \
+            DW_AP(B, t, 1, 16, 16, lo2, cl2, sl2)                                                                    \
+        } else {                                                                                                     \
+            /* the wave whose column block is cut by H (and the ones column): 32 x ncw chunks, plain batches of 5 */ \
+            for (int e0 = 0; e0 < 32 * ncw; e0 += 320) {                                                             \
+                ltg_f32x4 gp[5], gm[5], gv[5];                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                      \
+                    const int e = min(e0 + lane + 64 * j, 32 * ncw - 1);                                             \
+                    const unsigned lb2 = (unsigned)(e / ncw) * rowB + 16u * (20 * w + e % ncw);                      \
+                    const size_t u = (size_t)(t * 32) * rowB;                                                        \
+                    gp[j] = DW_AT(const ltg_f32x4, W4, u, lb2);                                                      \
+                    gm[j] = DW_AT(const ltg_f32x4, M4, u, lb2);                                                      \
+                    gv[j] = DW_AT(const ltg_f32x4, V4, u, lb2);                                                      \
+                }                                                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                      \
+                    /* the arithmetic is unconditional (clamped e), only the stores are predicated: loads that are   \
+                       consumed inside a lane-predicated block stay "pending" for the waitcnt pass on the skip path  \
+                       and turn into vmcnt(0) at the loop header for EVERY wave */                                   \
+                    const int er = e0 + lane + 64 * j, e = min(er, 32 * ncw - 1);                                    \
+                    const int row = e / ncw, cc = e % ncw;                                                           \
+                    const float4 g = *reinterpret_cast<const float4*>(Cw + row * DW_LDC + 4 * cc);                   \
+                    ltg_f32x4 p = gp[j], mm = gm[j], v2 = gv[j];                                                     \
+                    DW_ADAM1(x) DW_ADAM1(y) DW_ADAM1(z) DW_ADAM1(w)                                                  \
+                    if (er < 32 * ncw) {                                                                             \
+                        const size_t u = (size_t)(t * 32) * rowB;                                                    \
+                        const unsigned lb2 = (unsigned)row * rowB + 16u * (20 * w + cc);                             \
+                        DW_AT(ltg_f32x4, W4, u, lb2) = p;                                                            \
+                        DW_AT(ltg_f32x4, M4, u, lb2) = mm;                                                           \
+                        DW_AT(ltg_f32x4, V4, u, lb2) = v2;                                                           \
+                        const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                                 \
+                        DW_AT(ltg_u32x2, Wb, (size_t)(t * 32) * (ST_KP * 2), 2u * (row * ST_KP + 80 * w + 4 * cc)) = ltg_u32x2{pk.x, pk.y}; \
+                    }                                                                                                \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+        cur ^= 1;                                                                                                    \
+    }
+    if (t < ntiles && ncw == 20) { DW_LD(A, t, 2, 0, 4, lo1) }
+    for (; t < ntiles; t += G) DW_BODY()
+#undef DW_AT
+#undef DW_LD
+#undef DW_AP
+#undef DW_ADAM1
+#undef DW_BODY
 }
 
 // (re)build the bf16 shadow of W_p1t from the fp32 master rows (set-up / after loading weights)
@@ -1084,11 +1168,11 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
 // dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
 template <bool BF16, int VAR>
 __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
-                                                      const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
+                                                      const float* __restrict__ h2, ltg_gen_state st, AdamC ad, int i_begin) {
     // VAR 0: 32x32 tiles, scalar Adam epilogue; 1: 64x128, 2: 64x64, 3: 32x128 tiles with the float4 epilogue
     constexpr bool BIG = VAR != 0;
     constexpr int BM = VAR == 0 ? 32 : (VAR == 3 ? 32 : 64), BN = VAR == 0 ? 32 : (VAR == 2 ? 64 : 128);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = i_begin + blockIdx.y * BM, n0 = blockIdx.x * BN;   // i_begin: first item row of this launch
     float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
     unsigned short* Wb = st.wp1t_bf16;  // optional bf16 shadow [I][ST_KP], kept in step with the master weights
     auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)k * I + m]; };
@@ -1847,15 +1931,17 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     {
         const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
         if (stream_ok(cfg, gen, B) && (cfg->reserved0 & 15) == 0) {
-            const int ntl = (I + 31) / 32;
+            const int ntl = I / 32;
             hipLaunchKernelGGL(k_dec1_bwd_adam_stream, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+            if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
+                hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
         } else if (!bf) {
-            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
-            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
-        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
-        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
-        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
-        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
     }
     prs.after(LTG_K_DEC1_BWD_ADAM);
     pr.before(LTG_K_DZ);
