@@ -98,9 +98,9 @@ def load_user_items(csv_file_path):
     return out
 
 
-def overlap_matrix(show2id_path, user_tag_matrix_path):
-    """Dense float64 matrix OC[a, b] = |U_a & U_b| / min(|U_a|, |U_b|) (data_processing.py:100-164),
-    NaN for ids that never occur in the user-tag file."""
+def _tag_membership(show2id_path, user_tag_matrix_path):
+    """(M, size): binary user x tag CSR of the user-tag file restricted to ids of item2id.txt (TAG_SETS of
+    data_processing.py:110-140 are sets: a (user, tag) pair counts once), |U_a| per tag."""
     show2id = _read_show2id(show2id_path)
     tp = pd.read_csv(user_tag_matrix_path)
     users = tp.iloc[:, 0].astype(str).to_numpy()
@@ -111,11 +111,17 @@ def overlap_matrix(show2id_path, user_tag_matrix_path):
     _, uidx = np.unique(users, return_inverse=True)
     n_tags = int(max(int(v) for v in show2id.values())) + 1
     M = sparse.csr_matrix((np.ones(len(tid), np.int64), (uidx, tid)), shape=(uidx.max() + 1, n_tags))
-    M.data[:] = 1  # a (user, tag) pair counts once: TAG_SETS are sets
     M.sum_duplicates()
     M.data[:] = 1
-    inter = np.asarray((M.T @ M).todense(), dtype=np.int64)
     size = np.asarray(M.sum(axis=0)).reshape(-1).astype(np.int64)
+    return M, size
+
+
+def overlap_matrix(show2id_path, user_tag_matrix_path):
+    """Dense float64 matrix OC[a, b] = |U_a & U_b| / min(|U_a|, |U_b|) (data_processing.py:100-164),
+    NaN for ids that never occur in the user-tag file."""
+    M, size = _tag_membership(show2id_path, user_tag_matrix_path)
+    inter = np.asarray((M.T @ M).todense(), dtype=np.int64)
     denom = np.minimum(size[:, None], size[None, :]).astype(np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):
         oc = (inter * 1.0) / (1.0 * denom)
@@ -123,6 +129,41 @@ def overlap_matrix(show2id_path, user_tag_matrix_path):
     oc[missing, :] = np.nan
     oc[:, missing] = np.nan
     return oc
+
+
+class SparseOverlap:
+    """The same coefficients without the O(I^2) table: the co-occurrence counts |U_a & U_b| as a CSR
+    matrix (only pairs of tags that share a user are stored) + |U_a|.  `block(rows, cols)` materialises the small
+    sub-blocks the two consumers need with exactly the dense path's arithmetic (int64 count * 1.0 / float64 min)."""
+
+    def __init__(self, show2id_path, user_tag_matrix_path):
+        M, self.size = _tag_membership(show2id_path, user_tag_matrix_path)
+        self.inter = (M.T @ M).tocsr()
+        self.inter.sort_indices()
+        self.present = self.size > 0
+        self.n = len(self.size)
+
+    def block(self, rows, cols):
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        cnt = np.asarray(self.inter[rows][:, cols].todense(), dtype=np.int64)
+        denom = np.minimum(self.size[rows][:, None], self.size[cols][None, :]).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            oc = (cnt * 1.0) / (1.0 * denom)
+        oc[~self.present[rows], :] = np.nan
+        oc[:, ~self.present[cols]] = np.nan
+        return oc
+
+    def row_max(self, rows):
+        """max over `rows` of OC[row, :] as a dense length-n vector (0 where no row shares a user with the column),
+        and whether any row is an id without users (its coefficients are undefined: KeyError in the reference)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        out = np.zeros(self.n, dtype=np.float64)
+        ip, ix, dt = self.inter.indptr, self.inter.indices, self.inter.data
+        for r in rows.tolist():
+            c = ix[ip[r]:ip[r + 1]]
+            v = (dt[ip[r]:ip[r + 1]].astype(np.int64) * 1.0) / (1.0 * np.minimum(self.size[r], self.size[c]).astype(np.float64))
+            np.maximum.at(out, c, v)
+        return out, bool((~self.present[rows]).any())
 
 
 class _OverlapView(dict):
@@ -149,8 +190,35 @@ class _Row:
         return int(self.present.sum())
 
 
-def load_overlap_coeff(show2id_path, user_tag_matrix_path):
-    """data_processing.py:110-167 -> OVERLAP_COEFFS[a][b] (float)."""
+class _SparseOverlapView:
+    """OVERLAP_COEFFS[a][b] over SparseOverlap (rows are produced on demand)."""
+
+    def __init__(self, sp):
+        self.sparse = sp
+
+    def __contains__(self, a):
+        return 0 <= a < self.sparse.n and bool(self.sparse.present[a])
+
+    def __getitem__(self, a):
+        if a not in self:
+            raise KeyError(a)
+        sp = self.sparse
+        return _Row(sp.block([a], np.arange(sp.n))[0], sp.present)
+
+    def __len__(self):
+        return int(self.sparse.present.sum())
+
+
+# above this many tags the dense I x I float64 table is replaced by the sparse co-occurrence form
+SPARSE_OVERLAP_MIN_TAGS = 8192
+
+
+def load_overlap_coeff(show2id_path, user_tag_matrix_path, sparse_form=None):
+    """data_processing.py:110-167 -> OVERLAP_COEFFS[a][b] (float).  sparse_form: None = by size, True / False = force."""
+    if sparse_form is None:
+        sparse_form = int(max(int(v) for v in _read_show2id(show2id_path).values())) + 1 > SPARSE_OVERLAP_MIN_TAGS
+    if sparse_form:
+        return _SparseOverlapView(SparseOverlap(show2id_path, user_tag_matrix_path))
     return _OverlapView(overlap_matrix(show2id_path, user_tag_matrix_path))
 
 
@@ -169,16 +237,18 @@ def load_vectors(user_popular_data, user_niche_data, OVERLAP_COEFFS, ITEM_FEATUR
     """data_processing.py:227-271: for each niche item of a user (file order) the popular item of the
     user with the largest overlap (first maximum wins: strict '>' at :254); pairs touching an id
     outside ITEM_FEATURE_DICT are dropped (:258-260)."""
-    oc = _matrix(OVERLAP_COEFFS)
-    valid = np.zeros(oc.shape[0], bool)
-    valid[[k for k in ITEM_FEATURE_DICT if 0 <= k < oc.shape[0]]] = True
+    sp = OVERLAP_COEFFS.sparse if isinstance(OVERLAP_COEFFS, _SparseOverlapView) else None
+    oc = None if sp is not None else _matrix(OVERLAP_COEFFS)
+    n_ids = sp.n if sp is not None else oc.shape[0]
+    valid = np.zeros(n_ids, bool)
+    valid[[k for k in ITEM_FEATURE_DICT if 0 <= k < n_ids]] = True
     x_niche, x_pop = {}, {}
     for u in range(N):
         if u not in user_popular_data or u not in user_niche_data:
             continue
         pops = np.asarray(user_popular_data[u])
         nics = np.asarray(user_niche_data[u])
-        sub = oc[np.ix_(nics, pops)]
+        sub = sp.block(nics, pops) if sp is not None else oc[np.ix_(nics, pops)]
         if np.isnan(sub).any():
             raise KeyError("overlap coefficient missing for user %d" % u)  # the reference raises KeyError
         best = pops[np.argmax(sub, axis=1)]  # argmax returns the FIRST maximum
@@ -193,7 +263,8 @@ def load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP
     max(2n, 10-n) other niche items ranked by their max overlap with any of the user's niche items;
     ties keep the iteration order of the Python set difference (stable sort, :214) -- reproduced by
     performing that very set operation; ascending ids."""
-    oc = _matrix(OVERLAP_COEFFS)
+    sp = OVERLAP_COEFFS.sparse if isinstance(OVERLAP_COEFFS, _SparseOverlapView) else None
+    oc = None if sp is not None else _matrix(OVERLAP_COEFFS)
     out = {}
     niche_set = set(NICHE_TAGS)
     for u in range(N):
@@ -207,7 +278,20 @@ def load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP
             cur.add(t)
         others = np.asarray(list(niche_set - cur), dtype=np.int64)  # CPython set-difference order
         picked = [int(t) for t in nics]
-        if len(others):
+        if len(others) and sp is not None:
+            # sparse form: only tags that share a user with one of the user's niche items score > 0; the stable
+            # descending sort of the reference (:214) = positives by (score desc, set order), then zeros in set order
+            full, bad = sp.row_max(nics)
+            if bad or not sp.present[others].all():
+                raise KeyError("overlap coefficient missing for user %d" % u)
+            score = full[others]
+            k = min(want, len(others))
+            pos = np.nonzero(score > 0)[0]
+            order = pos[np.argsort(-score[pos], kind="stable")][:k]
+            if len(order) < k:
+                order = np.concatenate([order, np.nonzero(score <= 0)[0][:k - len(order)]])
+            picked += others[order].tolist()
+        elif len(others):
             score = oc[np.ix_(np.asarray(nics), others)].max(axis=0)
             if np.isnan(score).any():
                 raise KeyError("overlap coefficient missing for user %d" % u)

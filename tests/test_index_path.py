@@ -109,3 +109,25 @@ def test_candidate_sets_bit_exact(loaded, gold):
     assert np.array_equal(ptr, gold["cand_ptr"]) and np.array_equal(idx, gold["cand_idx"])
     lens = np.diff(ptr)
     assert lens.min() == 10 and lens.max() == 900
+
+
+def test_sparse_overlap_form_is_bit_exact(ds, loaded, gold):
+    """the co-occurrence CSR form (no I x I table) reproduces the same real pairs, candidate sets and
+    coefficients bit for bit on Askubuntu_Sample."""
+    sp = dp.load_overlap_coeff(os.path.join(ds, "item2id.txt"), os.path.join(ds, "item_counts.csv"), sparse_form=True)
+    assert isinstance(sp, dp._SparseOverlapView) and sp.sparse.inter.nnz < 1000 * 1000
+    dense = loaded["oc"].matrix
+    rs = np.random.default_rng(0)
+    rows, cols = rs.integers(0, 1000, 40), rs.integers(0, 1000, 60)
+    assert np.array_equal(sp.sparse.block(rows, cols), dense[np.ix_(rows, cols)], equal_nan=True)
+    assert sp[0][1] == float(gold["oc_0_1"]) and sp[0][0] == 1.0 and len(sp) == len(loaded["oc"])
+    xn, xp = dp.load_vectors(loaded["upop"], loaded["unic"], sp, loaded["fdict"], 10001)
+    keys = sorted(xn)
+    ptr, nic = _ragged(xn, keys)
+    _, pop = _ragged(xp, keys)
+    assert np.array_equal(ptr, gold["vec_ptr"]) and np.array_equal(nic, gold["vec_niche"]) and np.array_equal(pop, gold["vec_pop"])
+    cand = dp.load_items_to_sample(loaded["upop"], loaded["unic"], loaded["niche"], sp, 10001)
+    keys = sorted(cand)
+    ptr, idx = _ragged(cand, keys)
+    assert np.array_equal(np.array(keys), gold["cand_users"])
+    assert np.array_equal(ptr, gold["cand_ptr"]) and np.array_equal(idx, gold["cand_idx"])
