@@ -168,12 +168,14 @@ def test_g_step_parity(precision, I, B):
         _check_adam_move(move_got, move_want, want_m[i], ad.lr_t(5), ("theta", i))
 
 
-@pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (1, 0), (0, 5)])
+@pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (1, 0), (0, 5), (260, 250)])
 def test_d_step_parity(nr, nf):
     import torch
     from ltgan.engine import Pairs
     I = 500
-    hs = (100, 150, 250, 300) if nr > 100 else (12, 20, 28, 16)
+    hs = (100, 150, 250, 300) if nr > 300 else (12, 20, 28, 16)
+    if nr == 260:
+        hs = (2048, 1024, 512, 256)          # BASELINE config 5: the wide discriminator (3 540 993 parameters), fp32
     rng = np.random.default_rng(nr * 7 + nf)
     D = O.init_discriminator(I, *hs, seed=3)
     D["b1"] = rng.normal(0, 0.05, D["b1"].shape).astype(np.float32)
