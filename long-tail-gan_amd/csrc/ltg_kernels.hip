@@ -483,23 +483,20 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     }
     __syncthreads();
     const int tq = lr >> 2, tp = lr & 3;
-    // ---- Adam epilogue geometry.  A wave's [32 items][80 columns] gradient block = 32 x 20 16-byte chunks:
-    //   pass 1: lane -> chunk c1 = lane % 16 of rows r1 + 4 jj (r1 = lane / 16, jj = 0..7)  -- 8 float4 per lane
-    //   pass 2: lane -> chunk c2 = 16 + lane % 4 of rows r2 + 16 jj (r2 = lane / 4, jj = 0..1) -- 2 float4 per lane
-    // Row-constant lane predicates (no per-element branches), constant strides between the jj of a lane.  theta / m / v
-    // travel in five software-pipelined stages of 2 float4 per lane and tile (pass-1 rows 0..7, 8..15, 16..23, 24..31,
-    // pass 2) over two register sets: the loads of the next stage -- at the end of a tile: of the NEXT tile's first
-    // stage -- are issued before the current stage is consumed, so HBM requests stay in flight through the MFMA phase
-    // and the barriers.  (Deeper stages do not fit: the stationary fragments hold 80 of the 256 VGPRs.)
-    float* Cw = Cs + w * (32 * DW_LDC);
-    const int ncw = max(0, min(20, (H - 80 * w) >> 2));      // valid chunks of this wave's column block
-    const int c1 = lane & 15, r1 = lane >> 4, c2 = 16 + (lane & 3), r2 = lane >> 2;
-    // lane offsets of the two passes in BYTES: into theta/m/v rows, the shadow rows; in floats into the wave's LDS slab
+    // ---- Adam epilogue geometry.  The 32 rows of a tile are CONTIGUOUS in theta / m / v (32 x H floats, the tile starts on
+    // a 256-B boundary), so ownership is by rows, not by the column blocks the products were computed in: wave w walks
+    // rows 4w..4w+3 = 4 H/4 consecutive float4 as ten 1-KiB wave accesses (float4 e = 64 jj + lane; the tail lanes of
+    // the tenth access mirror the last element: same load, same result, same store).  The gradient of element (row,
+    // chunk) is fetched from the LDS slab of whichever wave computed that column block.  No lane predicates, no
+    // wave-dependent branches: every s_waitcnt in the loop is an exact count.  theta / m / v travel in six
+    // software-pipelined stages (2+2+2+2+1+1 float4 per lane) alternating over two register sets; the loads of the
+    // next stage -- at the end of a tile: of the NEXT tile's first stage -- are issued before the current stage is
+    // consumed, so HBM requests stay in flight through the MFMA phase and the barriers.  (Deeper stages do not fit: the
+    // stationary fragments hold 80 of the 256 VGPRs.)
+    float* Cw = Cs + w * (32 * DW_LDC);                        // this wave's product slab
+    const int H4 = H >> 2, nel = 4 * H4;                       // float4 per row / per wave and tile (host: 9 * 64 < nel <= 10 * 64)
     const unsigned rowB = (unsigned)H * 4u;
-    const unsigned lo1 = r1 * rowB + 16u * (20 * w + c1), lo2 = r2 * rowB + 16u * (20 * w + c2);
-    const int cl1 = r1 * DW_LDC + 4 * c1, cl2 = r2 * DW_LDC + 4 * c2;
-    const unsigned sl1 = 2u * (r1 * ST_KP + 80 * w + 4 * c1), sl2 = 2u * (r2 * ST_KP + 80 * w + 4 * c2);
-    const bool ones_here = 80 * w <= H && H < 80 * w + 80;  // the wave that owns the ones column (bias gradient)
+    const unsigned lo = 16u * lane, lo9 = 16u * (unsigned)(min(576 + lane, nel - 1) - 576);
     ltg_f32x4 Ap[2], Am[2], Av[2], Bp[2], Bm[2], Bv[2];
 #define DW_ADAM1(f)                                   \
     mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;        \
@@ -508,25 +505,26 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     // addressing: (uniform row base, computed on the scalar unit) + (one 32-bit lane offset per pass) -- global_load with
     // an SGPR base, so the unrolled stages do not pin a VGPR pair per access
 #define DW_AT(T, BASE, UB, LB) (*(T __attribute__((address_space(1)))*)(ltg_uniform_ptr(reinterpret_cast<const char*>(BASE) + (UB)) + (LB)))
-#define DW_LD(S, tt, NJ, UROW, RSTEP, LOFF)                                             \
+#define DW_LD(S, tt, NJ, J0, LOFF)                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
-        const size_t u = (size_t)((tt) * 32 + (UROW) + (RSTEP) * jj) * rowB;            \
-        S##p[jj] = DW_AT(const ltg_f32x4, W4, u, LOFF);                                    \
-        S##m[jj] = DW_AT(const ltg_f32x4, M4, u, LOFF);                                    \
-        S##v[jj] = DW_AT(const ltg_f32x4, V4, u, LOFF);                                    \
+        const size_t u = (size_t)((tt) * 32 + 4 * w) * rowB + 1024u * ((J0) + jj);      \
+        S##p[jj] = DW_AT(const ltg_f32x4, W4, u, LOFF);                                 \
+        S##m[jj] = DW_AT(const ltg_f32x4, M4, u, LOFF);                                 \
+        S##v[jj] = DW_AT(const ltg_f32x4, V4, u, LOFF);                                 \
     }
-#define DW_AP(S, tt, NJ, UROW, RSTEP, LOFF, CLOFF, SLOFF)                               \
+#define DW_AP(S, tt, NJ, J0, LOFF)                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
-        const int urow = (UROW) + (RSTEP) * jj;                                         \
-        const float4 g = *reinterpret_cast<const float4*>(Cw + urow * DW_LDC + (CLOFF)); \
+        const int e = min(64 * ((J0) + jj) + lane_v, nel - 1);                          \
+        const int rl = e / H4, ch = e - rl * H4, wb = ch / 20, lc = ch - 20 * wb;       \
+        const float4 g = *reinterpret_cast<const float4*>(Cs + wb * (32 * DW_LDC) + (4 * w + rl) * DW_LDC + 4 * lc); \
         ltg_f32x4 p = S##p[jj], mm = S##m[jj], v2 = S##v[jj];                           \
         DW_ADAM1(x) DW_ADAM1(y) DW_ADAM1(z) DW_ADAM1(w)                                 \
-        const size_t u = (size_t)((tt) * 32 + urow) * rowB;                             \
+        const size_t u = (size_t)((tt) * 32 + 4 * w) * rowB + 1024u * ((J0) + jj);      \
         DW_AT(ltg_f32x4, W4, u, LOFF) = p;                                              \
         DW_AT(ltg_f32x4, M4, u, LOFF) = mm;                                             \
         DW_AT(ltg_f32x4, V4, u, LOFF) = v2;                                             \
         const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                    \
-        DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + urow) * (ST_KP * 2), SLOFF) = ltg_u32x2{pk.x, pk.y}; \
+        DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + 4 * w) * (ST_KP * 2), (unsigned)(rl * (ST_KP * 2) + 8 * ch)) = ltg_u32x2{pk.x, pk.y}; \
     }
     // one tile: set A holds the first stage of tile t (requested one stage earlier); six stages alternate A, B so the
     // next tile starts on A again -- one loop body, no register-set swap (a swap would have to wait for loads in flight)
@@ -534,6 +532,9 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     {                                                                                                                \
         const bool more = t + G < ntiles;                                                                            \
         const int tn = more ? t + G : t;                                                                             \
+        int lane_v = lane; /* opaque per tile: keeps the ten (row, chunk) -> LDS / shadow offsets of a lane from being   \
+                              hoisted out of the loop into 20+ VGPRs (they are a handful of VALU ops to recompute) */  \
+        asm volatile("" : "+v"(lane_v));                                                                           \
         ltg_f32x4 acc[2][5];                                                                                         \
         _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                             \
             _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};            \
@@ -561,58 +562,47 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
            unconditional (clamped): a branch around either ends in vmcnt(0) at its join. */                          \
         stash(Dl[cur ^ 1], more ? t + G : t, x0, x1);                                                                \
         fetch(t + 2 * G < ntiles ? t + 2 * G : t, x0, x1);                                                           \
-        if (ones_here && lane < 32)                                                                                  \
-            adam_update(bb, mb, vb, t * 32 + lane, Cw[lane * DW_LDC + (H - 80 * w)], ad);                            \
-        if (ncw == 20) { /* wave-uniform: no lane predicates, so every s_waitcnt below is an exact count */          \
-            DW_LD(B, t, 2, 8, 4, lo1)                                                                                \
-            DW_AP(A, t, 2, 0, 4, lo1, cl1, sl1)                                                                      \
-            DW_LD(A, t, 2, 16, 4, lo1)                                                                               \
-            DW_AP(B, t, 2, 8, 4, lo1, cl1, sl1)                                                                      \
-            DW_LD(B, t, 2, 24, 4, lo1)                                                                               \
-            DW_AP(A, t, 2, 16, 4, lo1, cl1, sl1)                                                                     \
-            DW_LD(A, t, 1, 0, 16, lo2)                                                                               \
-            DW_AP(B, t, 2, 24, 4, lo1, cl1, sl1)                                                                     \
-            DW_LD(B, t, 1, 16, 16, lo2)                                                                              \
-            DW_AP(A, t, 1, 0, 16, lo2, cl2, sl2)                                                                     \
-            DW_LD(A, tn, 2, 0, 4, lo1) /* first stage of the next tile (of this one again at the end: unused) */     \
-            DW_AP(B, t, 1, 16, 16, lo2, cl2, sl2)                                                                    \
-        } else {                                                                                                     \
-            /* the wave whose column block is cut by H (and the ones column): 32 x ncw chunks, plain batches of 5 */ \
-            for (int e0 = 0; e0 < 32 * ncw; e0 += 320) {                                                             \
-                ltg_f32x4 gp[5], gm[5], gv[5];                                                                       \
-                _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                      \
-                    const int e = min(e0 + lane + 64 * j, 32 * ncw - 1);                                             \
-                    const unsigned lb2 = (unsigned)(e / ncw) * rowB + 16u * (20 * w + e % ncw);                      \
-                    const size_t u = (size_t)(t * 32) * rowB;                                                        \
-                    gp[j] = DW_AT(const ltg_f32x4, W4, u, lb2);                                                      \
-                    gm[j] = DW_AT(const ltg_f32x4, M4, u, lb2);                                                      \
-                    gv[j] = DW_AT(const ltg_f32x4, V4, u, lb2);                                                      \
-                }                                                                                                    \
-                _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                      \
-                    /* the arithmetic is unconditional (clamped e), only the stores are predicated: loads that are   \
-                       consumed inside a lane-predicated block stay "pending" for the waitcnt pass on the skip path  \
-                       and turn into vmcnt(0) at the loop header for EVERY wave */                                   \
-                    const int er = e0 + lane + 64 * j, e = min(er, 32 * ncw - 1);                                    \
-                    const int row = e / ncw, cc = e % ncw;                                                           \
-                    const float4 g = *reinterpret_cast<const float4*>(Cw + row * DW_LDC + 4 * cc);                   \
-                    ltg_f32x4 p = gp[j], mm = gm[j], v2 = gv[j];                                                     \
-                    DW_ADAM1(x) DW_ADAM1(y) DW_ADAM1(z) DW_ADAM1(w)                                                  \
-                    if (er < 32 * ncw) {                                                                             \
-                        const size_t u = (size_t)(t * 32) * rowB;                                                    \
-                        const unsigned lb2 = (unsigned)row * rowB + 16u * (20 * w + cc);                             \
-                        DW_AT(ltg_f32x4, W4, u, lb2) = p;                                                            \
-                        DW_AT(ltg_f32x4, M4, u, lb2) = mm;                                                           \
-                        DW_AT(ltg_f32x4, V4, u, lb2) = v2;                                                           \
-                        const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                                 \
-                        DW_AT(ltg_u32x2, Wb, (size_t)(t * 32) * (ST_KP * 2), 2u * (row * ST_KP + 80 * w + 4 * cc)) = ltg_u32x2{pk.x, pk.y}; \
-                    }                                                                                                \
-                }                                                                                                    \
-            }                                                                                                        \
+        /* bias b_p1 of rows 4w .. 4w+3 (gradient = the ones column, column H of the product): lanes >= 4 mirror    \
+           lane 3, loads here, update at the end of the tile -- no predicate, nothing waits for these loads */       \
+        const int ib = t * 32 + 4 * w + min(lane, 3);                                                                \
+        float pbv = bb[ib], mbv = mb[ib], vbv = vb[ib];                                                              \
+        DW_LD(B, t, 2, 2, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(A, t, 2, 0, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(A, t, 2, 4, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(B, t, 2, 2, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(B, t, 2, 6, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(A, t, 2, 4, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(A, t, 1, 8, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(B, t, 2, 6, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(B, t, 1, 9, lo9)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(A, t, 1, 8, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(A, tn, 2, 0, lo) /* first stage of the next tile (of this one again at the end: unused) */             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(B, t, 1, 9, lo9)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        {                                                                                                            \
+            const float gbias = Cs[(H / 80) * (32 * DW_LDC) + (4 * w + min(lane, 3)) * DW_LDC + H % 80];             \
+            mbv = ad.b1 * mbv + (1.f - ad.b1) * gbias;                                                               \
+            vbv = ad.b2 * vbv + (1.f - ad.b2) * gbias * gbias;                                                       \
+            pbv = pbv - ad.lr_t * mbv / (sqrtf(vbv) + ad.eps);                                                       \
+            mb[ib] = mbv;                                                                                            \
+            vb[ib] = vbv;                                                                                            \
+            bb[ib] = pbv;                                                                                            \
         }                                                                                                            \
         __syncthreads();                                                                                             \
         cur ^= 1;                                                                                                    \
     }
-    if (t < ntiles && ncw == 20) { DW_LD(A, t, 2, 0, 4, lo1) }
+    if (t < ntiles) { DW_LD(A, t, 2, 0, lo) }
     for (; t < ntiles; t += G) DW_BODY()
 #undef DW_AT
 #undef DW_LD
@@ -1581,6 +1571,8 @@ inline bool stream_ok(const ltg_config* cfg, const ltg_gen_state* gen, int rows)
     return gen->wp1t_bf16 && cfg->precision == LTG_PREC_BF16 && cfg->n_items >= 8192 && (cfg->n_items % 8) == 0 && rows <= 128 && cfg->h_enc <= ST_KP &&
            (cfg->h_enc % 4) == 0 && (cfg->reserved0 & 15) != 9;
 }
+// k_dec1_bwd_adam_stream walks the 4 H/4 float4 a wave owns per tile as exactly ten 64-lane accesses
+inline bool dw_stream_ok(int H) { return (H % 4) == 0 && H > 576 && H <= 640; }
 inline int dh2_stream_chunk(int I) {
     int c = (I + 255) / 256;
     return (c + ST_BN - 1) / ST_BN * ST_BN;
@@ -1930,7 +1922,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     prs.before(LTG_K_DEC1_BWD_ADAM);
     {
         const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
-        if (stream_ok(cfg, gen, B) && (cfg->reserved0 & 15) == 0) {
+        if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->reserved0 & 15) == 0) {
             const int ntl = I / 32;
             hipLaunchKernelGGL(k_dec1_bwd_adam_stream, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
             if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
