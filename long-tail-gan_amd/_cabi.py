@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libltg_hip.so")
+LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")   # LTG_HIP_LIB: another build of the SAME library (A/B timing)
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1

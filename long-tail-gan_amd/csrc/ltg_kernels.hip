@@ -273,38 +273,44 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
                                                            float* __restrict__ logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup)
+    // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup).  Rows >= M MIRROR row M - 1:
+    // their products equal row M - 1's and are stored to row M - 1's addresses (same value twice) -- no row predicate
+    // anywhere in the loop, so every s_waitcnt is an exact count and the prefetch is never drained.
     ltg_bf16x8 af[ST_KS];
     {
-        const int row = 16 * w + lr;
-        const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)min(row, M - 1) * H);
+        const int row = min(16 * w + lr, M - 1);
+        const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)row * H);
         const int H4 = H >> 2;
 #pragma unroll
         for (int ks = 0; ks < ST_KS; ++ks) {
             const int c4 = ks * 8 + 2 * lq;
             const float4 x0 = hr[min(c4, H4 - 1)], x1 = hr[min(c4 + 1, H4 - 1)];
-            const bool ok0 = row < M && c4 < H4, ok1 = row < M && c4 + 1 < H4;
-            ltg_u16x8 t;
-            t[0] = ok0 ? ltg_f2bf(x0.x) : 0; t[1] = ok0 ? ltg_f2bf(x0.y) : 0; t[2] = ok0 ? ltg_f2bf(x0.z) : 0; t[3] = ok0 ? ltg_f2bf(x0.w) : 0;
-            t[4] = ok1 ? ltg_f2bf(x1.x) : 0; t[5] = ok1 ? ltg_f2bf(x1.y) : 0; t[6] = ok1 ? ltg_f2bf(x1.z) : 0; t[7] = ok1 ? ltg_f2bf(x1.w) : 0;
+            const uint2 p0 = ltg_pack4(x0), p1 = ltg_pack4(x1);
+            const unsigned k0 = c4 < H4 ? 0xFFFFFFFFu : 0u, k1 = c4 + 1 < H4 ? 0xFFFFFFFFu : 0u;   // K padding -> 0
+            ltg_u32x4 t;
+            t[0] = p0.x & k0; t[1] = p0.y & k0; t[2] = p1.x & k1; t[3] = p1.y & k1;
             af[ks] = __builtin_bit_cast(ltg_bf16x8, t);
         }
     }
-    const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x;
+    const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
     StW r0, r1;
     int t = blockIdx.x, cur = 0;
     if (t < ntiles) {
         st_fetch_w(Wb, I, t * ST_BN, r0);
         st_stash_w(st_lds, r0);
+        st_fetch_w(Wb, I, min(t + G, last) * ST_BN, r1);
     }
-    if (t + G < ntiles) st_fetch_w(Wb, I, (t + G) * ST_BN, r1);
     __syncthreads();
-    // ST_STEP(RL, RS): LDS[cur] holds tile t, RS holds tile t+G (in flight since the previous step); tile t+2G
-    // is requested into RL, so two tiles of HBM loads are always outstanding per workgroup.  (A macro, not a
-    // lambda: register arrays captured by reference end up in scratch.)
+    // ST_STEP(RL, RS): LDS[cur] holds tile tc = min(t, last), RS holds tile min(t + G, last) (in flight since the previous
+    // step); tile min(t + 2G, last) is requested into RL, so two tiles of HBM loads are always outstanding per workgroup.
+    // Tile indices are clamped instead of guarded: a step past the end recomputes the last tile and stores the same
+    // logits again.  (A macro, not a lambda: register arrays captured by reference end up in scratch.)
 #define ST_STEP(RL, RS)                                                                                                         \
     {                                                                                                                           \
-        if (t + 2 * G < ntiles) st_fetch_w(Wb, I, (t + 2 * G) * ST_BN, RL);                                                     \
+        const int tc = min(t, last);                                                                                            \
+        const int ia = min(tc * ST_BN + lr, I - 1), ib = min(tc * ST_BN + 16 + lr, I - 1);                                      \
+        const float biasa = bp1[ia], biasb = bp1[ib]; /* BEFORE the prefetch: waiting for a younger load drains it */           \
+        st_fetch_w(Wb, I, min(t + 2 * G, last) * ST_BN, RL);                                                                    \
         const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
         ltg_f32x4 acc0 = ltg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = ltg_f32x4{0.f, 0.f, 0.f, 0.f};                                   \
         _Pragma("unroll") for (int ks = 0; ks < ST_KS; ++ks) {                                                                  \
@@ -313,25 +319,20 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], __builtin_bit_cast(ltg_bf16x8, b0), acc0, 0, 0, 0);          \
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], __builtin_bit_cast(ltg_bf16x8, b1), acc1, 0, 0, 0);          \
         }                                                                                                                       \
-        {                                                                                                                       \
-            const int ia = t * ST_BN + lr, ib = ia + 16;                                                                        \
-            const float biasa = bp1[min(ia, I - 1)], biasb = bp1[min(ib, I - 1)];                                               \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                     \
-                const int row = 16 * w + 4 * lq + q;                                                                            \
-                if (row < M && ia < I) logits[(size_t)row * I + ia] = acc0[q] + biasa;                                          \
-                if (row < M && ib < I) logits[(size_t)row * I + ib] = acc1[q] + biasb;                                          \
-            }                                                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                         \
+            const size_t ro = (size_t)min(16 * w + 4 * lq + q, M - 1) * I;                                                      \
+            logits[ro + ia] = acc0[q] + biasa;                                                                                  \
+            logits[ro + ib] = acc1[q] + biasb;                                                                                  \
         }                                                                                                                       \
-        if (t + G < ntiles) st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                \
+        st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                    \
         __syncthreads();                                                                                                        \
         cur ^= 1;                                                                                                               \
     }
-    while (t < ntiles) {
+    for (; t < ntiles; t += 2 * G) {
         ST_STEP(r0, r1)
         t += G;
-        if (t >= ntiles) break;
         ST_STEP(r1, r0)
-        t += G;
+        t -= G;
     }
 #undef ST_STEP
 }
@@ -346,59 +347,65 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
 #pragma unroll
     for (int n = 0; n < NTL; ++n) acc[n] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
     const int ibeg = blockIdx.x * chunk, iend = min(I, ibeg + chunk);
+    if (ibeg >= iend) return;
     const int row = 16 * w + lr;
     const float* drow = dlog + (size_t)min(row, B - 1) * I;
-    // A fragment of a 32-item step: dlog[row][i0 + 8*lq .. +7] (I % 8 == 0: whole 32-B groups, 16-B aligned)
-    auto load_a = [&](int i0, float4& x0, float4& x1) {
-        const int ib = min(i0 + 8 * lq, I - 8);
-        x0 = *reinterpret_cast<const float4*>(drow + ib);
-        x1 = *reinterpret_cast<const float4*>(drow + ib + 4);
-    };
-    StW r;
-    float4 a0, a1, n0, n1;
-    if (ibeg < iend) {
-        st_fetch_w(Wb, I, ibeg, r);
-        st_stash_w(st_lds, r);
-        load_a(ibeg, a0, a1);
+    const int ilast = ibeg + (iend - ibeg - 1) / ST_BN * ST_BN;      // start of the chunk's last 32-item step
+    // A fragment of a 32-item step: dlog[row][i0 + 8*lq .. +7] (I % 8 == 0: whole 32-B groups, 16-B aligned).  Loads are
+    // unconditional (clamped); rows >= B and steps past the end of the chunk are zeroed with a bit mask, so a clamped
+    // duplicate step adds nothing.  No branch in the loop: every s_waitcnt is an exact count.
+#define DH_LOAD_A(i0, X0, X1)                                                      \
+    {                                                                              \
+        const int ib_ = min(min((i0), ilast) + 8 * lq, I - 8);                     \
+        X0 = *reinterpret_cast<const float4*>(drow + ib_);                         \
+        X1 = *reinterpret_cast<const float4*>(drow + ib_ + 4);                     \
     }
+    StW r0, r1;
+    float4 e0, e1, o0, o1;     // A fragments of the even / odd steps
+    st_fetch_w(Wb, I, ibeg, r0);
+    st_stash_w(st_lds, r0);
+    DH_LOAD_A(ibeg, e0, e1)
+    st_fetch_w(Wb, I, min(ibeg + ST_BN, ilast), r1);
+    DH_LOAD_A(ibeg + ST_BN, o0, o1)
     __syncthreads();
     int cur = 0;
-    for (int i0 = ibeg; i0 < iend; i0 += ST_BN) {
-        const int inext = i0 + ST_BN;
-        if (inext < iend) {
-            st_fetch_w(Wb, I, inext, r);
-            load_a(inext, n0, n1);
-        }
-        ltg_u16x8 au;
-        {
-            const bool ok = row < B && i0 + 8 * lq < iend;  // chunk is a multiple of 32 and I % 8 == 0: groups are whole
-            au[0] = ok ? ltg_f2bf(a0.x) : 0; au[1] = ok ? ltg_f2bf(a0.y) : 0; au[2] = ok ? ltg_f2bf(a0.z) : 0; au[3] = ok ? ltg_f2bf(a0.w) : 0;
-            au[4] = ok ? ltg_f2bf(a1.x) : 0; au[5] = ok ? ltg_f2bf(a1.y) : 0; au[6] = ok ? ltg_f2bf(a1.z) : 0; au[7] = ok ? ltg_f2bf(a1.w) : 0;
-        }
-        const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);
-        const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;
-        // transposed fragment reads: lane 4q+p of each 16-lane group addresses row (8*lq + q), columns 4p..4p+3;
-        // it receives column (lane & 15) of the four rows -> k = 8*lq + q (first read), 8*lq + 4 + q (second)
-        const int tq = lr >> 2, tp = lr & 3;
-        const unsigned short* tbase = Wl + (8 * lq + tq) * ST_LDW + 4 * tp;
-#pragma unroll
-        for (int n = 0; n < NTL; ++n) {
-            typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;
-            const ltg_s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + n * 16));
-            const ltg_s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + 4 * ST_LDW + n * 16));
-            ltg_u16x8 bu;
-            bu[0] = b0[0]; bu[1] = b0[1]; bu[2] = b0[2]; bu[3] = b0[3];
-            bu[4] = b1[0]; bu[5] = b1[1]; bu[6] = b1[2]; bu[7] = b1[3];
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(ltg_bf16x8, bu), acc[n], 0, 0, 0);
-        }
-        if (inext < iend) {
-            st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, r);
-            a0 = n0;
-            a1 = n1;
-        }
-        __syncthreads();
-        cur ^= 1;
+    const int tq = lr >> 2, tp = lr & 3;
+    // DH_STEP(RL, RS, X0, X1): LDS[cur] = W tile of step i0, RS = W tile of the next step (in flight), X = A fragment of
+    // step i0 (requested two steps ago); requests the W tile two steps ahead into RL and, once X is converted, the A
+    // fragment two steps ahead into X again -- two steps of HBM loads are always outstanding.
+#define DH_STEP(RL, RS, X0, X1)                                                                                                 \
+    {                                                                                                                           \
+        st_fetch_w(Wb, I, min(i0 + 2 * ST_BN, ilast), RL);                                                                      \
+        const unsigned keep = (row < B && i0 + 8 * lq < iend) ? 0xFFFFFFFFu : 0u;                                               \
+        const uint2 pa = ltg_pack4(X0), pb = ltg_pack4(X1);                                                                     \
+        ltg_u32x4 au;                                                                                                           \
+        au[0] = pa.x & keep; au[1] = pa.y & keep; au[2] = pb.x & keep; au[3] = pb.y & keep;                                     \
+        const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);                                                               \
+        DH_LOAD_A(i0 + 2 * ST_BN, X0, X1)                                                                                       \
+        const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
+        /* transposed fragment reads: lane 4q+p of each 16-lane group addresses row (8*lq + q), columns 4p..4p+3; it */        \
+        /* receives column (lane & 15) of the four rows -> k = 8*lq + q (first read), 8*lq + 4 + q (second) */                  \
+        const unsigned short* tbase = Wl + (8 * lq + tq) * ST_LDW + 4 * tp;                                                     \
+        _Pragma("unroll") for (int n = 0; n < NTL; ++n) {                                                                       \
+            typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;                                                        \
+            const ltg_s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + n * 16));                              \
+            const ltg_s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + 4 * ST_LDW + n * 16));                 \
+            ltg_u16x8 bu;                                                                                                       \
+            bu[0] = b0[0]; bu[1] = b0[1]; bu[2] = b0[2]; bu[3] = b0[3];                                                         \
+            bu[4] = b1[0]; bu[5] = b1[1]; bu[6] = b1[2]; bu[7] = b1[3];                                                         \
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(ltg_bf16x8, bu), acc[n], 0, 0, 0);          \
+        }                                                                                                                       \
+        st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                    \
+        __syncthreads();                                                                                                        \
+        cur ^= 1;                                                                                                               \
+        i0 += ST_BN;                                                                                                            \
     }
+    for (int i0 = ibeg; i0 < iend;) {
+        DH_STEP(r0, r1, e0, e1)
+        DH_STEP(r1, r0, o0, o1)
+    }
+#undef DH_STEP
+#undef DH_LOAD_A
     float* out = part + (size_t)blockIdx.x * B * H;
 #pragma unroll
     for (int n = 0; n < NTL; ++n) {
