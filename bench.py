@@ -206,6 +206,26 @@ class KernelProfiler:
                 "note": "dominant kernel = largest (avg duration x launches per step) among the probed kernels"}
 
 
+def copy_ceiling(device, nbytes=1 << 30, reps=5):
+    """Device-to-device copy rate of THIS box (read + write bytes / time), the practical HBM ceiling next to the 8 TB/s
+    spec the roofline fraction is quoted against: boxes of the pool differ by ~10 % in it, and so do the HBM-bound kernels."""
+    import torch
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(reps):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    return {"value": best, "unit": "GB/s", "what": "torch D2D copy of 1 GiB, read + write bytes, best of %d" % reps}
+
+
 def main():
     a = parse()
     import torch
@@ -305,6 +325,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         res["roofline"] = prof.roofline(dominant, calib) if dominant else None
+        if res["roofline"] is not None:
+            res["roofline"]["copy_ceiling_this_box"] = copy_ceiling(device)
         if calib:
             res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
         if n1_ref:
