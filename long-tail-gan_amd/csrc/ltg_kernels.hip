@@ -1901,79 +1901,86 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
 }
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
-                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false,
-                            bool overlap = false) {
+                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
-    const Probe pr{o->probe, st};
-    // Critical path: da2 -> dz -> dh1 -> sweep of W_q0.  The three weight-gradient + Adam kernels only consume
-    // it, so with `overlap` they run on the caller's aux stream, each released by a re-recorded ev_fork after
-    // the last READER of the weights it updates (dz reads W_p0, dh1 reads W_q1) has been enqueued on `st`.
-    hipStream_t side = overlap ? (hipStream_t)o->aux_stream : st;
-    hipEvent_t evf = (hipEvent_t)o->ev_fork, evj = (hipEvent_t)o->ev_join;
-    auto release_side = [&]() {
-        if (overlap) {
-            (void)hipEventRecord(evf, st);
-            (void)hipStreamWaitEvent(side, evf, 0);
-        }
-    };
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
+    // Small item slabs: the critical path da2 -> dz -> dh1 -> sweep of W_q0 stays on `st`; the three weight-gradient + Adam
+    // kernels only consume it and run on the caller's aux stream, each released by a re-recorded ev_fork after the last
+    // READER of the weights it updates (dz reads W_p0, dh1 reads W_q1) has been enqueued on `st`.
+    // Large item slabs: everything on `st`.  Measured alternatives (I = 200 000): the two HBM sweeps side by side only
+    // contend; the chain of short kernels beside the first sweep does not overlap at all -- the persistent sweep holds
+    // every CU (232 VGPRs x 8 waves + 106 KB LDS per CU), the chain's workgroups are only placed when it drains.
+    const bool have_aux = o->aux_stream && o->ev_fork && o->ev_join && I < 8192;
+    const bool small_mode = have_aux;
+    hipStream_t aux = (hipStream_t)o->aux_stream;
+    hipEvent_t evf = (hipEvent_t)o->ev_fork, evj = (hipEvent_t)o->ev_join;
+    hipStream_t s_dw = small_mode ? aux : st;      // dW_p1t + Adam
+    hipStream_t s_wg = have_aux ? aux : st;        // the two middle-layer weight-gradient + Adam kernels
+    hipStream_t s_chain = st;                      // dz, dh1, sparse W_q0 gradient, sweep of W_q0
+    auto release_aux = [&]() {
+        (void)hipEventRecord(evf, st);
+        (void)hipStreamWaitEvent(aux, evf, 0);
+    };
     if (!da2_ready) {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
     }
-    release_side();  // dlog, h2 and the dh2 products with the old W_p1t are all enqueued
-    const Probe prs{o->probe, side};
-    prs.before(LTG_K_DEC1_BWD_ADAM);
-    {
+    if (have_aux) release_aux();  // dlog, h2, da2 and the dh2 products with the old W_p1t are all enqueued
+    auto launch_dw = [&]() {
+        const Probe prs{o->probe, s_dw};
+        prs.before(LTG_K_DEC1_BWD_ADAM);
         const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
         if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->reserved0 & 15) == 0) {
             const int ntl = I / 32;
-            hipLaunchKernelGGL(k_dec1_bwd_adam_stream, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad);
+            hipLaunchKernelGGL(k_dec1_bwd_adam_stream, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
             if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
-                hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
+                hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
         } else if (!bf) {
-            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, side, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-    }
-    prs.after(LTG_K_DEC1_BWD_ADAM);
-    pr.before(LTG_K_DZ);
-    hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
+            if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+            else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        prs.after(LTG_K_DEC1_BWD_ADAM);
+    };
+    launch_dw();
+    const Probe pc{o->probe, s_chain}, pw{o->probe, s_wg};
+    pc.before(LTG_K_DZ);
+    hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, s_chain, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
                        o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
-    pr.after(LTG_K_DZ);
-    release_side();  // dz (the reader of the old W_p0) is enqueued
-    prs.before(LTG_K_WGRAD_P0);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, side, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
+    pc.after(LTG_K_DZ);
+    if (small_mode) release_aux();  // dz (the reader of the old W_p0) is enqueued
+    pw.before(LTG_K_WGRAD_P0);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, s_wg, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
                        gen->p[6], gen->m[6], gen->v[6], ad);
-    prs.after(LTG_K_WGRAD_P0);
-    pr.before(LTG_K_DH1);
-    hipLaunchKernelGGL(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
-    pr.after(LTG_K_DH1);
-    release_side();  // dh1 (the reader of the old W_q1) is enqueued
-    prs.before(LTG_K_WGRAD_Q1);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, side, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
+    pw.after(LTG_K_WGRAD_P0);
+    pc.before(LTG_K_DH1);
+    hipLaunchKernelGGL(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, s_chain, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
+    pc.after(LTG_K_DH1);
+    if (small_mode) release_aux();  // dh1 (the reader of the old W_q1) is enqueued
+    pw.before(LTG_K_WGRAD_Q1);
+    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, s_wg, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
                        gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
-    prs.after(LTG_K_WGRAD_Q1);
-    if (overlap) (void)hipEventRecord(evj, side);
+    pw.after(LTG_K_WGRAD_Q1);
+    if (small_mode) (void)hipEventRecord(evj, aux);
+    const int nu = bt->n_unique;
+    const Probe pe{o->probe, st};
+    pe.before(LTG_K_ENC0_BWD_ADAM);
+    hipLaunchKernelGGL(k_enc0_grad, dim3(nu + 1), dim3(NT), (size_t)4 * H * sizeof(float), s_chain, B, I, H, nu, bt->uptr, bt->rowidx,
+                       bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
+                       acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
     {
-        const int nu = bt->n_unique;
-        pr.before(LTG_K_ENC0_BWD_ADAM);
-        hipLaunchKernelGGL(k_enc0_grad, dim3(nu + 1), dim3(NT), (size_t)4 * H * sizeof(float), st, B, I, H, nu, bt->uptr, bt->rowidx,
-                           bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
-                           acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
         if (gx > 262144) gx = 262144;
         hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, I, H, nu, bt->slot, w.gq0, *gen, ad);
-        pr.after(LTG_K_ENC0_BWD_ADAM);
     }
-    if (overlap) (void)hipStreamWaitEvent(st, evj, 0);  // join: the caller's stream again orders everything
+    pe.after(LTG_K_ENC0_BWD_ADAM);
+    if (small_mode) (void)hipStreamWaitEvent(st, evj, 0);  // join: the caller's stream again orders everything
     return check_launch();
 }
 
@@ -2010,8 +2017,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)
     int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork, acts->h2);
     if (rc != LTG_OK) return rc;
-    // the side stream only pays while the step is a chain of short kernels; HBM-bound sweeps just contend
-    return g_stage_bwd_rest(cfg, gen, bt, o, acts, w.da2, w, st, true, o->aux_stream && o->ev_fork && o->ev_join && cfg->n_items < 8192);
+    return g_stage_bwd_rest(cfg, gen, bt, o, acts, w.da2, w, st, true);
 }
 
 /* ---- the same step cut at its three exchange points (item-sharded multi-GPU; include/ltg.h) ---- */

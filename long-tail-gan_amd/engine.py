@@ -274,7 +274,7 @@ class Engine:
         f = self.fwd_opts(keep_prob, is_training, rng_step, drop_keep, eps, probe)
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
         return cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
-                               None, None, None)
+                               *self._fork_handles())      # ltg_g_bwd_rest forks / joins inside the call
 
     def g_fwd_enc(self, batch, acts, fopts):
         cabi.check(self.lib.ltg_g_fwd_enc(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fopts), C.byref(acts.c),
