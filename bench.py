@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--sub-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=100)
     ap.add_argument("--users", type=int, default=None, help="synthetic workloads: number of user rows to generate (default: a bounded sample)")
+    ap.add_argument("--d-sizes", default="100,150,250,300",
+                    help="discriminator h0,h1,h2,h3 (config.ini defaults; BASELINE config 5 = 2048,1024,512,256)")
+    ap.add_argument("--d-precision", default="fp32", choices=["fp32", "bf16", "fp8"],
+                    help="operand precision of the discriminator GEMMs (fp32 = the reference's arithmetic)")
     ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event kernel probes (use under rocprofv3 --pmc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,6 +232,7 @@ def copy_ceiling(device, nbytes=1 << 30, reps=5):
 
 def main():
     a = parse()
+    a.h_sizes = tuple(int(x) for x in a.d_sizes.split(","))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,7 +261,7 @@ def main():
         from ltgan.sharded import ShardedTrainer, item_slab
         if world > 1 and rank == 0:
             # same workload on ONE GPU, measured in this very job (the other ranks wait): the strong-scaling reference
-            e1 = Engine(idx.n_items, precision=a.precision, device=device)
+            e1 = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
             t1 = Trainer(e1, data, num_sub_epochs=a.sub_epochs)
             t1.epoch()
             torch.cuda.synchronize()
@@ -268,11 +273,11 @@ def main():
             torch.cuda.empty_cache()
         lo, hi = item_slab(idx.n_items, rank, world)
         data = DeviceData(idx, a.batch_size, device, item_lo=lo, item_hi=hi)
-        eng = Engine(idx.n_items, precision=a.precision, device=device, item_lo=lo, item_hi=hi)
+        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device, item_lo=lo, item_hi=hi)
         eng.cfg.reserved0 = a.variant
         tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs)
     else:
-        eng = Engine(idx.n_items, precision=a.precision, device=device)
+        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
         eng.cfg.reserved0 = a.variant
         tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
 

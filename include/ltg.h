@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 6
+#define LTG_ABI_VERSION 7
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -41,6 +41,7 @@ extern "C" {
 
 #define LTG_PREC_BF16 0 /* decoder GEMM operands rounded to bf16, fp32 accumulate (MFMA 16x16x32 bf16) */
 #define LTG_PREC_FP32 1 /* exact fp32 MFMA (16x16x4 f32) everywhere */
+#define LTG_PREC_FP8 2  /* d_precision only: OCP e4m3 operands, static power-of-two scales, fp32 accumulate (16x16x32 fp8) */
 
 typedef void* ltg_stream; /* hipStream_t */
 
@@ -59,6 +60,11 @@ typedef struct ltg_config {
      * only the local rows; CSR indices are local; fake-pair and candidate ids stay global. */
     int32_t item_lo;
     int32_t n_items_global;
+    /* operand precision of the discriminator GEMMs (forward and backward; discriminator.py:16-55 is fp32):
+     * LTG_PREC_FP32 = the reference's arithmetic (default of the host layer), LTG_PREC_BF16, LTG_PREC_FP8
+     * (BASELINE config 5).  Accumulation, activations, loss, Adam and the master weights are fp32 in every mode. */
+    int32_t d_precision;
+    int32_t reserved1;
     float lr, beta1, beta2, adam_eps;
     uint64_t seed;
 } ltg_config;
@@ -288,6 +294,13 @@ int ltg_rank_counts(const ltg_config* cfg, const float* logits, const ltg_batch*
                     const float* score, int32_t* count_out, ltg_stream stream);
 int ltg_rank_finish(const ltg_batch* te, const int32_t* counts, int32_t k_ndcg, int32_t k_r1, int32_t k_r2,
                     float* out, ltg_stream stream);
+
+/* Verification helper of the LTG_PREC_FP8 mode: out[i] = the value the fp8 GEMM operands carry for in[i]
+ * (clamp to +-448, round to nearest-even OCP e4m3) -- lets a test pin its CPU model of the rounding to the hardware. */
+int ltg_fp8_roundtrip(const float* in, float* out, int32_t n, ltg_stream stream);
+/* Verification helper: C[M][N] = A[M][K] . B[K][N] (row-major fp32) through the MFMA block template every GEMM-shaped
+ * kernel is an instance of; mode 0 = fp32 operands, 1 = bf16, 2 = e4m3 with scale 2^4 on both operands. */
+int ltg_debug_gemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* A, const float* B, float* C, ltg_stream stream);
 
 #ifdef __cplusplus
 }

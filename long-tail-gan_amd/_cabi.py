@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
-LTG_ABI_VERSION = 6
+LTG_PREC_FP8 = 2
+LTG_ABI_VERSION = 7
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -24,6 +25,7 @@ class ltg_config(C.Structure):
     _fields_ = [("n_items", C.c_int32), ("h_enc", C.c_int32), ("z_dim", C.c_int32), ("d_feat", C.c_int32),
                 ("d_h0", C.c_int32), ("d_h1", C.c_int32), ("d_h2", C.c_int32), ("d_h3", C.c_int32),
                 ("precision", C.c_int32), ("reserved0", C.c_int32), ("item_lo", C.c_int32), ("n_items_global", C.c_int32),
+                ("d_precision", C.c_int32), ("reserved1", C.c_int32),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("seed", C.c_uint64)]
 
@@ -109,6 +111,8 @@ SYMBOLS = {
     "ltg_rank_scores": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), vp, vp]),
     "ltg_rank_counts": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), vp, vp, vp]),
     "ltg_rank_finish": (C.c_int, [C.POINTER(ltg_batch), vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
+    "ltg_fp8_roundtrip": (C.c_int, [vp, vp, C.c_int32, vp]),
+    "ltg_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -4,12 +4,14 @@
 // WM x WN), operands fetched through element functors (so gathers, transposes, on-the-fly
 // derivatives and ones-augmentation for bias gradients are all "just a loader"), staged in LDS as
 // k-contiguous rows, consumed by
-//   BF16 = true : v_mfma_f32_16x16x32_bf16  (operands rounded to bf16 RNE, fp32 accumulate)
-//   BF16 = false: v_mfma_f32_16x16x4_f32    (exact fp32 fma chain)
+//   MODE 1 (true) : v_mfma_f32_16x16x32_bf16      (operands rounded to bf16 RNE, fp32 accumulate)
+//   MODE 0 (false): v_mfma_f32_16x16x4_f32        (exact fp32 fma chain)
+//   MODE 2        : v_mfma_f32_16x16x32_fp8_fp8   (operands = OCP e4m3 of clamp(x * 2^SA | 2^SB, +-448), fp32 accumulate;
+//                                                  the accumulator is scaled back by 2^-(SA+SB) before the epilogue)
 // and handed to an epilogue functor epi(m, n, acc).
 //
 // Fragment maps (cdna_hip_programming.md section 3):
-//   16x16x32 bf16: lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7
+//   16x16x32 bf16: lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7  (fp8: same, one byte each)
 //   16x16x4  f32 : lane l holds A[row l&15][k = l>>4],       B[k = l>>4][col l&15]
 //   C/D (both)   : col = l&15, row = 4*(l>>4) + reg
 #pragma once
@@ -26,26 +28,40 @@ __device__ __forceinline__ unsigned short ltg_f2bf(float x) {
     return (unsigned short)(u >> 16);
 }
 
-template <bool BF16, int BK_> struct LtgGemmCfg;
-template <int BK_> struct LtgGemmCfg<true, BK_> {
+// float -> OCP e4m3 (gfx950), round to nearest even; |x| is clamped to the format's largest finite value, 448, first
+// (the ones-augmented rows of the bias gradients carry 1 * 2^8 = 256)
+__device__ __forceinline__ unsigned char ltg_f2fp8(float x) {
+    const float c = fminf(fmaxf(x, -448.f), 448.f);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.f, 0, false) & 0xFF);
+}
+
+template <int MODE, int BK_> struct LtgGemmCfg;
+template <int BK_> struct LtgGemmCfg<1, BK_> {
     typedef unsigned short T;
     static constexpr int BK = BK_;
     static constexpr int LDK = BK_ + 8;  // rows stay 16-B aligned for the 16-byte fragment reads
     static_assert(BK_ % 32 == 0, "bf16 K-step is 32");
 };
-template <int BK_> struct LtgGemmCfg<false, BK_> {
+template <int BK_> struct LtgGemmCfg<0, BK_> {
     typedef float T;
     static constexpr int BK = BK_;
     static constexpr int LDK = BK_ + 1;  // odd word stride: conflict-free column walks
     static_assert(BK_ % 4 == 0, "fp32 K-step is 4");
 };
+template <int BK_> struct LtgGemmCfg<2, BK_> {
+    typedef unsigned char T;
+    static constexpr int BK = BK_;
+    static constexpr int LDK = BK_ + 8;  // rows stay 8-B aligned for the 8-byte fragment reads
+    static_assert(BK_ % 32 == 0, "fp8 K-step is 32");
+};
 
 // M, N: logical bounds of the tile grid (rows of A / columns of B); loaders are only called in range.
 // [kbeg, kend): K range of this block (split-K).  A_MCONTIG / B_NCONTIG choose the thread->element
 // map of the global loads so that consecutive threads walk the operand's contiguous dimension.
-template <bool BF16, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, bool VEC_EPI = false, class AF, class BF, class EF>
+template <int MODE, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, bool VEC_EPI = false, int SA = 0, int SB = 0, class AF, class BF, class EF>
 __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int kbeg, int kend, AF a, BF b, EF epi) {
-    typedef LtgGemmCfg<BF16, BK_> Cfg;
+    constexpr bool BF16 = MODE == 1, FP8 = MODE == 2;
+    typedef LtgGemmCfg<MODE, BK_> Cfg;
     typedef typename Cfg::T T;
     constexpr int BK = Cfg::BK, LDK = Cfg::LDK;
     constexpr int NT = 256;
@@ -107,6 +123,7 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
             const int mm = A_MCONTIG ? (e % BM) : (e / BK);
             const int kk = A_MCONTIG ? (e / BM) : (e % BK);
             if constexpr (BF16) As[mm * LDK + kk] = ltg_f2bf(ra[j]);
+            else if constexpr (FP8) As[mm * LDK + kk] = ltg_f2fp8(ra[j] * (float)(1 << SA));
             else As[mm * LDK + kk] = ra[j];
         }
 #pragma unroll
@@ -115,6 +132,7 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
             const int nn = B_NCONTIG ? (e % BN) : (e / BK);
             const int kk = B_NCONTIG ? (e / BN) : (e % BK);
             if constexpr (BF16) Bs[nn * LDK + kk] = ltg_f2bf(rb[j]);
+            else if constexpr (FP8) Bs[nn * LDK + kk] = ltg_f2fp8(rb[j] * (float)(1 << SB));
             else Bs[nn * LDK + kk] = rb[j];
         }
     };
@@ -145,6 +163,20 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
+        } else if constexpr (FP8) {
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 32) {
+                long af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(&As[(wm * WTM + i * 16 + lr) * LDK + ks + 8 * lq]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const long*>(&Bs[(wn * WTN + j * 16 + lr) * LDK + ks + 8 * lq]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
@@ -162,6 +194,13 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
         }
     }
 
+    if constexpr (FP8) {
+        constexpr float inv = 1.f / (float)(1 << (SA + SB));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= inv;
+    }
     if constexpr (VEC_EPI) {
         // The accumulator tile takes a round trip through LDS so that the epilogue walks the output
         // row-major in float4 (16 B per lane, whole 128-B lines per row): epi(m, n, float4) with n % 4 == 0.

@@ -618,6 +618,23 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
 #undef DW_BODY
 }
 
+// out[i] = the e4m3 value the fp8 GEMM mode stores for in[i] (verification helper: pins the oracle's rounding model)
+__global__ __launch_bounds__(NT) void k_fp8_roundtrip(int n, const float* __restrict__ in, float* __restrict__ out) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT)
+        out[i] = __builtin_amdgcn_cvt_f32_fp8((int)ltg_f2fp8(in[i]), 0);
+}
+
+// C[M][N] = A[M][K] . B[K][N] through the block template in one of its operand modes (verification helper)
+template <int MODE>
+__global__ __launch_bounds__(NT) void k_debug_gemm(int M, int N, int K, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                   float* __restrict__ Cm) {
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    auto a = [=] __device__(int m, int k) -> float { return A[(size_t)m * K + k]; };
+    auto b = [=] __device__(int k, int n) -> float { return Bm[(size_t)k * N + n]; };
+    auto epi = [=] __device__(int m, int n, float acc) { Cm[(size_t)m * N + n] = acc; };
+    ltg_gemm_block<MODE, 32, 32, 128, 2, 2, false, true, false, 4, 4>(M, N, m0, n0, 0, K, a, b, epi);
+}
+
 // (re)build the bf16 shadow of W_p1t from the fp32 master rows (set-up / after loading weights)
 __global__ __launch_bounds__(NT) void k_refresh_shadow(int I, int H, const float* __restrict__ W, unsigned short* __restrict__ Wb) {
     const size_t total = (size_t)I * ST_KP;
@@ -675,7 +692,14 @@ struct DropView {
     }
 };
 
+// Discriminator GEMM precision (ltg_config.d_precision): 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 operands,
+// 2 = OCP e4m3 operands with STATIC power-of-two scales per operand class (no amax pass: the classes are bounded --
+// embeddings and weights are N(0, 0.1) truncated at 2 sigma at initialisation, activations are tanh / keep, the gradient
+// classes are bounded by products of those); accumulation is fp32 in every mode.  TS = tile size (32: latency-bound
+// default sizes, 64: the wide discriminator of BASELINE config 5).
+constexpr int FP8_S_EMB = 8, FP8_S_W = 8, FP8_S_ACT = 6, FP8_S_G3 = 8, FP8_S_G1 = 7;
 // branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular->h1, 1 niche->h2
+template <int MODE, int TS>
 __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                              const float* __restrict__ w2, const float* __restrict__ b2, DropView dA,
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const bool br = blockIdx.z != 0;
     const int N = br ? h2 : h1;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
     if (n0 >= N) return;
     const float* W = br ? w2 : w1;
     const float* bias = br ? b2 : b1;
@@ -700,21 +724,22 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
                            : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + (br ? h1 : 0) + nn] = kp ? t / keep : 0.f;
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(n, N, m0, n0, 0, h0, a, b, epi);
+    ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W>(n, N, m0, n0, 0, h0, a, b, epi);
 }
 
 // fully connected layer (discriminator.py:44, :54)
+template <int MODE, int TS>
 __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float* __restrict__ A1,
                                              const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
                                              float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
     auto a = [=] __device__(int m, int k) -> float { return A1[(size_t)m * h12 + k]; };
     auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)k * h3 + nn]; };
     auto epi = [=] __device__(int m, int nn, float acc) {
         const float t = tanhf(acc + b3[nn]);
         A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(n, h3, m0, n0, 0, h12, a, b, epi);
+    ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W>(n, h3, m0, n0, 0, h12, a, b, epi);
 }
 
 // output unit + loss terms (discriminator.py:45,55; train.py:142): one wave per pair row.
@@ -777,6 +802,7 @@ constexpr int D_KCHUNK = 256;  // pair rows per split-K slab
 //   job A  dpre1 = (dpre3 . w3^T) * dact(A1)                       [n][h1+h2]     tiles 64x64
 //   job B  slab[z] += A1^T . dpre3 (+ ones row -> db3), split-K     [(h12+1)][h3]  tiles 32x32
 //   job C  slab[z] += A3^T . ds, sum ds (dw4, db4), split-K         column reduce
+template <int MODE, int TS>
 __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, int nB, int ks, DLayout L,
                                                const float* __restrict__ A1, const float* __restrict__ A3,
                                                const float* __restrict__ ds, const float* __restrict__ dpre3,
@@ -784,22 +810,22 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
                                                float* __restrict__ slab) {
     int bid = blockIdx.x;
     if (bid < nA) {
-        const int tn = (h12 + 31) / 32;
-        const int m0 = (bid / tn) * 32, n0 = (bid % tn) * 32;
+        const int tn = (h12 + TS - 1) / TS;
+        const int m0 = (bid / tn) * TS, n0 = (bid % tn) * TS;
         auto a = [=] __device__(int m, int k) -> float { return dpre3[(size_t)m * h3 + k]; };
         auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)nn * h3 + k]; };
         auto epi = [=] __device__(int m, int nn, float acc) {
             dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
         };
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(n, h12, m0, n0, 0, h3, a, b, epi);
+        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, false, false, FP8_S_G3, FP8_S_W>(n, h12, m0, n0, 0, h3, a, b, epi);
         return;
     }
     bid -= nA;
     const int P = L.off[8];
     if (bid < nB) {
-        const int tm = (h12 + 1 + 31) / 32, tn = (h3 + 31) / 32;
+        const int tm = (h12 + 1 + TS - 1) / TS, tn = (h3 + TS - 1) / TS;
         const int z = bid / (tm * tn), t = bid % (tm * tn);
-        const int m0 = (t / tn) * 32, n0 = (t % tn) * 32;
+        const int m0 = (t / tn) * TS, n0 = (t % tn) * TS;
         const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
         float* out = slab + (size_t)z * P;
         const int ow = L.off[4], ob = L.off[5];
@@ -812,7 +838,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
+        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
         return;
     }
     bid -= nB;
@@ -840,18 +866,19 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
 }
 
 // Backward stage 2: dw1/db1 and dw2/db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), split-K.
+template <int MODE, int TS>
 __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int h2, int ks, DLayout L,
                                                const float* __restrict__ emb, const float* __restrict__ dpre1,
                                                float* __restrict__ slab) {
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
-    const int tm = (h0 + 1 + 31) / 32;
-    const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
+    const int tm = (h0 + 1 + TS - 1) / TS;
+    const int tn1 = (h1 + TS - 1) / TS, tn2 = (h2 + TS - 1) / TS;
     const int per_z = tm * (tn1 + tn2);
     const int z = blockIdx.x / per_z, t = blockIdx.x % per_z;
-    const int m0 = (t / (tn1 + tn2)) * 32;
+    const int m0 = (t / (tn1 + tn2)) * TS;
     const int tcol = t % (tn1 + tn2);
     const bool br = tcol >= tn1;
-    const int n0 = (br ? tcol - tn1 : tcol) * 32;
+    const int n0 = (br ? tcol - tn1 : tcol) * TS;
     const int N = br ? h2 : h1;
     const int coff = br ? h1 : 0;
     const int ow = L.off[br ? 2 : 0], ob = L.off[br ? 3 : 1];
@@ -867,7 +894,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
+    ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
 }
 
 // One Adam sweep over all 8 discriminator tensors (train.py:163): g = sum of the split-K slabs.
@@ -1687,7 +1714,7 @@ inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return di
 
 bool cfg_ok(const ltg_config* c) {
     return c && c->n_items > 0 && c->h_enc > 0 && c->h_enc <= 768 && (c->h_enc % 4) == 0 && c->z_dim > 0 &&
-           (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32);
+           (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32) && c->d_precision >= 0 && c->d_precision <= LTG_PREC_FP8;
 }
 
 inline int Ig_of(const ltg_config* cfg) { return cfg->n_items_global > 0 ? cfg->n_items_global : cfg->n_items; }
@@ -1760,14 +1787,31 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
 }
 
 // forward of one or both towers into ws (A1, A3, y, ds, lrow)
+// (precision mode, tile size) -> template instance of a discriminator GEMM kernel
+inline int d_mode(const ltg_config* cfg) { return cfg->d_precision == LTG_PREC_BF16 ? 1 : (cfg->d_precision == LTG_PREC_FP8 ? 2 : 0); }
+inline int d_tile(const ltg_config* cfg) { return (cfg->reserved0 & 1024) ? 64 : 32; }   // 64x64 tiles measured slower at every size (incl. 2048/1024/512/256): the loaders bound these kernels, not the MFMAs
+#define LTG_D_DISPATCH(KERNEL, MODE, TS, GRID, ST, ...)                                                              \
+    do {                                                                                                             \
+        if ((TS) == 64) {                                                                                            \
+            if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                \
+            else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);           \
+            else hipLaunchKernelGGL((KERNEL<0, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                            \
+        } else {                                                                                                     \
+            if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                \
+            else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);           \
+            else hipLaunchKernelGGL((KERNEL<0, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                            \
+        }                                                                                                            \
+    } while (0)
+
 void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
                   float keep, uint64_t step, const Workspace& w, bool with_bwd, const ltg_probe* probe, hipStream_t st) {
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(k_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
-                       d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
-    LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(k_d_l2, grid2(h3, n, 32, 32), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
+    const int md = d_mode(cfg), ts = d_tile(cfg);
+    LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, ts, ts, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+                                              d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
+    LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts, grid2(h3, n, ts, ts), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
     const dim3 go((n + NT / 64 - 1) / (NT / 64));
     if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
     else hipLaunchKernelGGL(k_d_out<false>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
@@ -1831,13 +1875,15 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
-    const int nA = ((n + 31) / 32) * ((h12 + 31) / 32);
-    const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
+    const int md = d_mode(cfg), ts = d_tile(cfg);
+    auto tiles = [ts](int x) { return (x + ts - 1) / ts; };
+    const int nA = tiles(n) * tiles(h12);
+    const int nB = ks * tiles(h12 + 1) * tiles(h3);
     const int nC = ks * ((h3 + 1 + 31) / 32);
-    LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(k_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, h12, h3, nA, nB, ks, L, w.A1, w.A3, w.ds, w.dpre3, disc->p[4],
-                       o->keep_prob, w.dpre1, w.slab));
-    const int n2 = ks * ((h0 + 1 + 31) / 32) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-    LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(k_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
+    LTG_PROBED(pr, LTG_K_D_BWD1, LTG_D_DISPATCH(k_d_bwd1, md, ts, dim3(nA + nB + nC), st, n, h12, h3, nA, nB, ks, L, w.A1, w.A3, w.ds, w.dpre3, disc->p[4],
+                                                o->keep_prob, w.dpre1, w.slab));
+    const int n2 = ks * tiles(h0 + 1) * (tiles(h1) + tiles(h2));
+    LTG_PROBED(pr, LTG_K_D_BWD2, LTG_D_DISPATCH(k_d_bwd2, md, ts, dim3(n2), st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
     int ga = (L.off[8] + NT - 1) / NT;
     if (ga > 1024) ga = 1024;
     LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, w.slab, *disc, ad, n, w.lrow, loss_out));
@@ -2103,6 +2149,24 @@ int ltg_rank_metrics(const ltg_config* cfg, const float* logits, const ltg_batch
     if (lds > 64 * 1024) return LTG_EINVAL;
     hipLaunchKernelGGL(k_rank_metrics, dim3(tr->n_rows), dim3(NT), lds, (hipStream_t)stream, cfg->n_items, cfg->item_lo, logits,
                        tr->indptr, tr->indices, te->indptr, te->indices, (const float*)nullptr, (int32_t*)nullptr, k_ndcg, k_r1, k_r2, out);
+    return check_launch();
+}
+
+int ltg_fp8_roundtrip(const float* in, float* out, int32_t n, ltg_stream stream) {
+    clear_errors();
+    if (!in || !out || n < 0) return LTG_EINVAL;
+    if (n == 0) return LTG_OK;
+    hipLaunchKernelGGL(k_fp8_roundtrip, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, (hipStream_t)stream, n, in, out);
+    return check_launch();
+}
+
+int ltg_debug_gemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* A, const float* B, float* C, ltg_stream stream) {
+    clear_errors();
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return LTG_EINVAL;
+    const dim3 g((N + 31) / 32, (M + 31) / 32);
+    if (mode == 0) hipLaunchKernelGGL(k_debug_gemm<0>, g, dim3(NT), 0, (hipStream_t)stream, M, N, K, A, B, C);
+    else if (mode == 1) hipLaunchKernelGGL(k_debug_gemm<1>, g, dim3(NT), 0, (hipStream_t)stream, M, N, K, A, B, C);
+    else hipLaunchKernelGGL(k_debug_gemm<2>, g, dim3(NT), 0, (hipStream_t)stream, M, N, K, A, B, C);
     return check_launch();
 }
 

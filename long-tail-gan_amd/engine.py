@@ -77,8 +77,10 @@ class Pairs:
 class Engine:
     def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
                  precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8,
-                 item_lo=0, item_hi=None):
-        """n_items = GLOBAL item count; [item_lo, item_hi) = the slab this rank owns (default: everything)."""
+                 item_lo=0, item_hi=None, d_precision="fp32"):
+        """n_items = GLOBAL item count; [item_lo, item_hi) = the slab this rank owns (default: everything).
+        precision: operands of the three decoder GEMMs; d_precision: operands of the discriminator GEMMs
+        ("fp32" = the reference's arithmetic, "bf16", "fp8" = BASELINE config 5)."""
         self.lib = cabi.load()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
@@ -92,8 +94,10 @@ class Engine:
         self.h0, self.h1, self.h2, self.h3 = h_sizes
         self.feature_len = feature_len or n_items
         self.precision = {"bf16": cabi.LTG_PREC_BF16, "fp32": cabi.LTG_PREC_FP32}[precision]
+        self.d_precision = {"fp32": cabi.LTG_PREC_FP32, "bf16": cabi.LTG_PREC_BF16, "fp8": cabi.LTG_PREC_FP8}[d_precision]
         self.cfg = cabi.ltg_config(self.I, self.H, self.Z, self.feature_len, self.h0, self.h1, self.h2, self.h3,
-                                   self.precision, 0, self.item_lo, n_items if self.sharded else 0, lr, beta1, beta2, eps, seed)
+                                   self.precision, 0, self.item_lo, n_items if self.sharded else 0, self.d_precision, 0,
+                                   lr, beta1, beta2, eps, seed)
         self.lr, self.beta1, self.beta2 = lr, beta1, beta2
         self.adam_t = 0                                              # shared by D and G (Q5)
         self._init_generator(seed)

@@ -81,6 +81,29 @@ def _q(x, quant):
     return bf16_round(x).astype(x.dtype) if quant else x
 
 
+def fp8_e4m3_round(x):
+    """Round to the nearest OCP e4m3 value (3 mantissa bits, normals 2^-6 .. 448, subnormal step 2^-9), ties to even;
+    the hardware path clamps to +-448 (the largest finite e4m3) first (ltg_gemm.h: ltg_f2fp8), so does this."""
+    x = np.clip(np.asarray(x, dtype=np.float64), -448.0, 448.0)
+    _, e = np.frexp(x)                                   # |x| = m * 2^e, m in [0.5, 1)
+    step = np.exp2(np.maximum(e - 4, -9).astype(np.float64))
+    return np.rint(x / step) * step
+
+
+# static scale exponents of the fp8 discriminator mode (csrc/ltg_kernels.hip: FP8_S_*)
+FP8_S = {"emb": 8, "w": 8, "act": 6, "g3": 8, "g1": 7}
+
+
+def _dq(x, mode, cls):
+    """operand quantisation of one discriminator GEMM: mode None (fp32) | "bf16" | "fp8" (static scale of class cls)."""
+    if mode is None:
+        return x
+    if mode == "bf16":
+        return bf16_round(np.asarray(x, np.float32)).astype(x.dtype)
+    sc = float(1 << FP8_S[cls])
+    return (fp8_e4m3_round(np.asarray(x, np.float64) * sc) / sc).astype(x.dtype)
+
+
 # ----------------------------------------------------------------------------------------------
 # MultiVAE generator  (Codes/Base_Recommender/MultiVAE.py:95-230, Codes/generator.py:4-22)
 # ----------------------------------------------------------------------------------------------
@@ -179,27 +202,31 @@ def init_discriminator(feature_len, h0, h1, h2, h3, seed=0):
     }
 
 
-def d_tower(D, pop_ids, niche_ids, masks, keep, dtype=np.float64):
+def d_tower(D, pop_ids, niche_ids, masks, keep, dtype=np.float64, dq=None):
     """t(a,b) of discriminator.py:16-19,25,30,33,44-45 (same code serves :51-55).
-    masks = (mA [K,h1], mB [K,h2], mC [K,h3]) keep indicators."""
+    masks = (mA [K,h1], mB [K,h2], mC [K,h3]) keep indicators.  dq: operand precision of the three GEMMs of the
+    ltg_config.d_precision modes (None = fp32 like the reference, "bf16", "fp8"); the output layer is always fp32."""
     f = lambda a: np.asarray(a, dtype=dtype)
     mA, mB, mC = (f(m) for m in masks)
     ea = f(D["emb"])[pop_ids]
     eb = f(D["emb"])[niche_ids]
-    tA = np.tanh(ea @ f(D["w1"]) + f(D["b1"]))
-    tB = np.tanh(eb @ f(D["w2"]) + f(D["b2"]))
+    tA = np.tanh(_dq(ea, dq, "emb") @ _dq(f(D["w1"]), dq, "w") + f(D["b1"]))
+    tB = np.tanh(_dq(eb, dq, "emb") @ _dq(f(D["w2"]), dq, "w") + f(D["b2"]))
     aA = tA / dtype(keep) * mA
     aB = tB / dtype(keep) * mB
     hin = np.concatenate([aA, aB], 1)
-    tC = np.tanh(hin @ f(D["w3"]) + f(D["b3"]))
+    if dq is not None:
+        hin = hin.astype(np.float32).astype(dtype)      # activations live in fp32 buffers between the kernels
+    tC = np.tanh(_dq(hin, dq, "act") @ _dq(f(D["w3"]), dq, "w") + f(D["b3"]))
     aC = tC / dtype(keep) * mC
     s = aC @ f(D["w4"]) + f(D["b4"])
     y = 1.0 / (1.0 + np.exp(-s))
     return dict(ea=ea, eb=eb, tA=tA, tB=tB, hin=hin, tC=tC, aC=aC, s=s[:, 0], y=y[:, 0])
 
 
-def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64):
-    """gradients of sum(ds * s) wrt the 8 trainable tensors (emb is frozen: discriminator.py:47)."""
+def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64, dq=None):
+    """gradients of sum(ds * s) wrt the 8 trainable tensors (emb is frozen: discriminator.py:47).  dq as in d_tower:
+    the bias gradients of the quantised GEMMs are column sums of the QUANTISED operand (ones-augmented row)."""
     f = lambda a: np.asarray(a, dtype=dtype)
     mA, mB, mC = (f(m) for m in masks)
     ds = f(ds)[:, None]
@@ -208,16 +235,22 @@ def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64):
     g["b4"] = ds.sum(0)
     daC = ds @ f(D["w4"]).T
     dpC = daC * mC / dtype(keep) * (1 - T["tC"] ** 2)
-    g["w3"] = T["hin"].T @ dpC
-    g["b3"] = dpC.sum(0)
-    dhin = dpC @ f(D["w3"]).T
+    if dq is not None:
+        dpC = dpC.astype(np.float32).astype(dtype)
+    qC = _dq(dpC, dq, "g3")
+    g["w3"] = _dq(T["hin"], dq, "act").T @ qC
+    g["b3"] = qC.sum(0)
+    dhin = qC @ _dq(f(D["w3"]), dq, "w").T
     h1 = mA.shape[1]
     dpA = dhin[:, :h1] * mA / dtype(keep) * (1 - T["tA"] ** 2)
     dpB = dhin[:, h1:] * mB / dtype(keep) * (1 - T["tB"] ** 2)
-    g["w1"] = T["ea"].T @ dpA
-    g["b1"] = dpA.sum(0)
-    g["w2"] = T["eb"].T @ dpB
-    g["b2"] = dpB.sum(0)
+    if dq is not None:
+        dpA, dpB = dpA.astype(np.float32).astype(dtype), dpB.astype(np.float32).astype(dtype)
+    qA, qB = _dq(dpA, dq, "g1"), _dq(dpB, dq, "g1")
+    g["w1"] = _dq(T["ea"], dq, "emb").T @ qA
+    g["b1"] = qA.sum(0)
+    g["w2"] = _dq(T["eb"], dq, "emb").T @ qB
+    g["b2"] = qB.sum(0)
     return g
 
 

@@ -23,12 +23,12 @@ def test_header_symbols_are_exported_and_bound():
     lib = cabi.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 6
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 7
 
 
 def test_struct_layouts_match_header():
     from ltgan import _cabi as cabi
-    assert C.sizeof(cabi.ltg_config) == 72 and cabi.ltg_config.seed.offset == 64
+    assert C.sizeof(cabi.ltg_config) == 80 and cabi.ltg_config.seed.offset == 72
     assert C.sizeof(cabi.ltg_gen_state) == 25 * 8 and C.sizeof(cabi.ltg_disc_state) == 25 * 8
     assert C.sizeof(cabi.ltg_batch) == 8 + 8 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
     assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8
@@ -42,11 +42,11 @@ def test_struct_layouts_match_header():
 def test_argument_validation_returns_codes_without_gpu():
     from ltgan import _cabi as cabi
     lib = cabi.load()
-    good = cabi.ltg_config(1000, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
+    good = cabi.ltg_config(1000, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
     assert lib.ltg_workspace_bytes(C.byref(good), 100, 2000) > 0
-    bad = cabi.ltg_config(0, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
+    bad = cabi.ltg_config(0, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
     assert lib.ltg_workspace_bytes(C.byref(bad), 100, 2000) == 0
-    odd = cabi.ltg_config(1000, 602, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1)   # H % 4 != 0
+    odd = cabi.ltg_config(1000, 602, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1, 0, 1e-4, 0.9, 0.999, 1e-8, 1)   # H % 4 != 0
     assert lib.ltg_workspace_bytes(C.byref(odd), 100, 2000) == 0
     # NULL structs -> LTG_EINVAL, before any HIP call
     assert lib.ltg_vae_forward(C.byref(good), None, None, None, None, None, None, 0, None) == -1

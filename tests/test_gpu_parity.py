@@ -523,3 +523,100 @@ def test_rank_metrics_cut_at_exchange_points_equals_fused():
     got = out_cut.cpu().numpy()
     ok = got[:, 3] > 0
     assert ok.sum() == B - 1 and np.allclose(got[ok, 0], want, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# discriminator GEMM precision modes (ltg_config.d_precision; BASELINE config 5 asks for fp8 on the wide discriminator)
+# ------------------------------------------------------------------------------------------------
+def test_fp8_rounding_model_matches_hardware():
+    """the oracle's e4m3 model (oracle.fp8_e4m3_round) against the conversion the kernels use, bit for bit"""
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import _ptr
+    lib = cabi.load()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.normal(0, 1, 20000) * np.exp2(rng.integers(-12, 9, 20000)),
+                        np.exp2(np.arange(-14, 9.0)), -np.exp2(np.arange(-14, 9.0)), 1.5 * np.exp2(np.arange(-12, 8.0)),
+                        np.arange(-470, 471, 1.0), np.arange(0, 64) * 2.0 ** -10, [0.0, 447.9, 448.0, 463.9, 464.1, 1e6, -1e6]]).astype(np.float32)
+    xi = torch.from_numpy(x).cuda()
+    out = torch.empty_like(xi)
+    cabi.check(lib.ltg_fp8_roundtrip(_ptr(xi), _ptr(out), x.size, None), "ltg_fp8_roundtrip")
+    torch.cuda.synchronize()
+    want = O.fp8_e4m3_round(x.astype(np.float64)).astype(np.float32)
+    got = out.cpu().numpy()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (x[bad[:8]], got[bad[:8]], want[bad[:8]])
+
+
+# fp8 tolerances = the pipeline's own noise floor: the fp8 MFMA accumulates with ~1.5e-5 relative error (ltg_debug_gemm,
+# test below); feeding the ORACLE operands perturbed by that much moves its w1 gradient by 0.9 % (default sizes) / 3.2 %
+# (wide) in the energy norm, because every value near an e4m3 rounding boundary flips by a 6 % step.
+@pytest.mark.parametrize("dq,hs,tol", [("bf16", (100, 150, 250, 300), 2e-3), ("fp8", (100, 150, 250, 300), 2e-2),
+                                       ("bf16", (2048, 1024, 512, 256), 2e-3), ("fp8", (2048, 1024, 512, 256), 6e-2),
+                                       ("fp32", (2048, 1024, 512, 256), 5e-4)])
+def test_d_step_precision_modes(dq, hs, tol):
+    """D step with quantised GEMM operands == oracle fed the SAME quantised operands (d6: compare against the oracle
+    fed rounded operands); and close to the fp32 discriminator within the format's own error."""
+    import torch
+    from ltgan.engine import Pairs
+    I, nr, nf = 700, 300, 280
+    rng = np.random.default_rng(41)
+    D = O.init_discriminator(I, *hs, seed=5)
+    for k in ("b1", "b2", "b3", "b4"):
+        D[k] = rng.normal(0, 0.05, D[k].shape).astype(np.float32)
+    eng = _engine(I, "fp32", hs=hs, lr=1e-3, d_precision=dq)
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    dev = eng.device
+    rp, rn = rng.integers(0, I, nr).astype(np.int32), rng.integers(0, I, nr).astype(np.int32)
+    fp, fn = rng.integers(0, I, nf).astype(np.int32), rng.integers(0, I, nf).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    step, keep = 4, 0.7
+    loss = float(eng.d_step(Pairs(t(rp), t(rn)), Pairs(t(fp), t(fn)), keep, rng_step=step).cpu().numpy()[0])
+    dm = Hh.d_masks(SEED, step, nr + nf, hs[1:], keep)
+    mode = None if dq == "fp32" else dq
+    Tr = O.d_tower(D, rp, rn, [m[:nr] for m in dm], keep, dq=mode)
+    Tf = O.d_tower(D, fp, fn, [m[nr:] for m in dm], keep, dq=mode)
+    want_loss = -np.log(Tr["y"]).sum() - np.log(1 - Tf["y"]).sum()
+    assert abs(loss - want_loss) < 1e-4 * abs(want_loss), (loss, want_loss)
+    gr = O.d_tower_backward(D, Tr, [m[:nr] for m in dm], keep, -(1 - Tr["y"]), dq=mode)
+    gf = O.d_tower_backward(D, Tf, [m[nr:] for m in dm], keep, Tf["y"], dq=mode)
+    ad = O.SharedAdam(1e-3)
+    D64 = {k: np.asarray(v, np.float64) for k, v in D.items()}
+    ad.apply(D64, {k: gr[k] + gf[k] for k in gr}, O.D_KEYS)
+    for i, k in enumerate(O.D_KEYS):
+        got, want = eng.d_m[i].cpu().numpy().reshape(-1).astype(np.float64), ad.m[k].reshape(-1)
+        # energy norm: a value that sits on a rounding boundary of the operand format may round the other way on the GPU
+        # (fp32 tanh / products vs the fp64 oracle); one flipped e4m3 operand moves one product term by 6 %
+        assert np.linalg.norm(got - want) < tol * np.linalg.norm(want), ("m", k)
+        assert Hh.rel_err(got, want) < tol, ("m max", k)
+    if mode is not None:       # how far the format itself moves the result from the fp32 discriminator
+        T32 = O.d_tower(D, rp, rn, [m[:nr] for m in dm], keep)
+        lim = 2e-2 if dq == "bf16" else 0.25
+        assert np.max(np.abs(Tr["y"] - T32["y"])) < lim
+
+
+def test_gemm_block_operand_modes():
+    """The MFMA block template against exact products of the operands each mode feeds it (ltg_debug_gemm): fp32 and bf16
+    accumulate to fp32 round-off; the fp8 MFMA of gfx950 accumulates with ~1.5e-5 relative error (measured, asserted)."""
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import _ptr
+    lib = cabi.load()
+    rng = np.random.default_rng(0)
+    for (M, N, K) in ((64, 64, 100), (100, 96, 400), (33, 70, 2048)):
+        A = rng.normal(0, 1, (M, K)).astype(np.float32)
+        B = rng.normal(0, 1, (K, N)).astype(np.float32)
+        a, b = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        for mode, lim in ((0, 3e-6), (1, 3e-6), (2, 1e-4)):
+            c = torch.zeros(M, N, device="cuda")
+            cabi.check(lib.ltg_debug_gemm(mode, M, N, K, _ptr(a), _ptr(b), _ptr(c), None), "ltg_debug_gemm")
+            torch.cuda.synchronize()
+            if mode == 0:
+                qa, qb = A.astype(np.float64), B.astype(np.float64)
+            elif mode == 1:
+                qa, qb = O.bf16_round(A).astype(np.float64), O.bf16_round(B).astype(np.float64)
+            else:
+                qa, qb = O.fp8_e4m3_round(A.astype(np.float64) * 16) / 16, O.fp8_e4m3_round(B.astype(np.float64) * 16) / 16
+            want = qa @ qb
+            assert Hh.rel_err(c.cpu().numpy(), want) < lim, (M, N, K, mode)
