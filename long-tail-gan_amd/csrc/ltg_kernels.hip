@@ -692,11 +692,20 @@ struct DropView {
     }
 };
 
+// float4 of 4 consecutive floats at p[i .. i+3], zero where i + j >= n (n % 4 == 0 at every call site, so a group is
+// either whole or absent; the address is clamped, the load unconditional)
+__device__ __forceinline__ float4 ltg_ld4(const float* __restrict__ p, int i, int n, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(p + min(i, n - 4));
+    const bool k = ok && i < n;
+    return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+}
+
 // Discriminator GEMM precision (ltg_config.d_precision): 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 operands,
 // 2 = OCP e4m3 operands with STATIC power-of-two scales per operand class (no amax pass: the classes are bounded --
 // embeddings and weights are N(0, 0.1) truncated at 2 sigma at initialisation, activations are tanh / keep, the gradient
 // classes are bounded by products of those); accumulation is fp32 in every mode.  TS = tile size (32: latency-bound
-// default sizes, 64: the wide discriminator of BASELINE config 5).
+// default sizes; 128 = the wide discriminator of BASELINE config 5: 128x128x64 tiles fed by 16-B vector loads, every
+// dimension a multiple of 4).
 constexpr int FP8_S_EMB = 8, FP8_S_W = 8, FP8_S_ACT = 6, FP8_S_G3 = 8, FP8_S_G1 = 7;
 // branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular->h1, 1 niche->h2
 template <int MODE, int TS>
@@ -724,7 +733,16 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
                            : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + (br ? h1 : 0) + nn] = kp ? t / keep : 0.f;
     };
-    ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W>(n, N, m0, n0, 0, h0, a, b, epi);
+    if constexpr (TS >= 64) {
+        auto a4 = [=] __device__(int m, int k) -> float4 {
+            const int id = br ? pv.nic(min(m, n - 1)) : pv.pop(min(m, n - 1));
+            return ltg_ld4(emb + (size_t)max(id, 0) * h0, k, h0, m < n && id >= 0);
+        };
+        auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(W + (size_t)min(k, h0 - 1) * N, nn, N, k < h0); };
+        ltg_gemm_block<MODE, TS, TS, 64, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, true>(n, N, m0, n0, 0, h0, a4, b4, epi);
+    } else {
+        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W>(n, N, m0, n0, 0, h0, a, b, epi);
+    }
 }
 
 // fully connected layer (discriminator.py:44, :54)
@@ -739,7 +757,13 @@ __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float
         const float t = tanhf(acc + b3[nn]);
         A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
     };
-    ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W>(n, h3, m0, n0, 0, h12, a, b, epi);
+    if constexpr (TS >= 64) {
+        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A1 + (size_t)min(m, n - 1) * h12, k, h12, m < n); };
+        auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(k, h12 - 1) * h3, nn, h3, k < h12); };
+        ltg_gemm_block<MODE, TS, TS, 64, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W, true>(n, h3, m0, n0, 0, h12, a4, b4, epi);
+    } else {
+        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W>(n, h3, m0, n0, 0, h12, a, b, epi);
+    }
 }
 
 // output unit + loss terms (discriminator.py:45,55; train.py:142): one wave per pair row.
@@ -817,7 +841,13 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
         auto epi = [=] __device__(int m, int nn, float acc) {
             dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
         };
-        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, false, false, FP8_S_G3, FP8_S_W>(n, h12, m0, n0, 0, h3, a, b, epi);
+        if constexpr (TS >= 64) {
+            auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dpre3 + (size_t)min(m, n - 1) * h3, k, h3, m < n); };
+            auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(nn, h12 - 1) * h3, k, h3, nn < h12); };
+            ltg_gemm_block<MODE, TS, TS, 64, 2, 2, false, false, false, FP8_S_G3, FP8_S_W, true>(n, h12, m0, n0, 0, h3, a4, b4, epi);
+        } else {
+            ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, false, false, FP8_S_G3, FP8_S_W>(n, h12, m0, n0, 0, h3, a, b, epi);
+        }
         return;
     }
     bid -= nA;
@@ -838,7 +868,18 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
+        if constexpr (TS >= 64) {
+            // rows m < h12: A1^T; row m == h12: ones (bias gradient); h12 % 4 == 0, so the ones row opens its own group
+            auto a4 = [=] __device__(int m, int k) -> float4 {
+                float4 v = ltg_ld4(A1 + (size_t)min(k, kend - 1) * h12, m, h12, k < kend);
+                if (m == h12 && k < kend) v.x = 1.f;
+                return v;
+            };
+            auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre3 + (size_t)min(k, kend - 1) * h3, nn, h3, k < kend); };
+            ltg_gemm_block<MODE, TS, TS, 64, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3, true>(h12 + 1, h3, m0, n0, kbeg, kend, a4, b4, epi);
+        } else {
+            ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
+        }
         return;
     }
     bid -= nB;
@@ -894,7 +935,19 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
+    if constexpr (TS >= 64) {
+        auto a4 = [=] __device__(int m, int k) -> float4 {
+            const int kc = min(k, kend - 1);
+            const int id = br ? pv.nic(kc) : pv.pop(kc);
+            float4 v = ltg_ld4(emb + (size_t)max(id, 0) * h0, m, h0, k < kend && id >= 0);
+            if (m == h0 && k < kend) v.x = 1.f;       // the ones row: bias gradient (also for pairs with a hole: like the scalar path)
+            return v;
+        };
+        auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre1 + (size_t)min(k, kend - 1) * h12 + coff, nn, N, k < kend); };
+        ltg_gemm_block<MODE, TS, TS, 64, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, true>(h0 + 1, N, m0, n0, kbeg, kend, a4, b4, epi);
+    } else {
+        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
+    }
 }
 
 // One Adam sweep over all 8 discriminator tensors (train.py:163): g = sum of the split-K slabs.
@@ -1789,13 +1842,29 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
 // forward of one or both towers into ws (A1, A3, y, ds, lrow)
 // (precision mode, tile size) -> template instance of a discriminator GEMM kernel
 inline int d_mode(const ltg_config* cfg) { return cfg->d_precision == LTG_PREC_BF16 ? 1 : (cfg->d_precision == LTG_PREC_FP8 ? 2 : 0); }
-inline int d_tile(const ltg_config* cfg) { return (cfg->reserved0 & 1024) ? 64 : 32; }   // 64x64 tiles measured slower at every size (incl. 2048/1024/512/256): the loaders bound these kernels, not the MFMAs
+// tile of discriminator GEMM kernel `which` (0 l1, 1 l2, 2 bwd1, 3 bwd2): 32 = scalar loaders (latency-bound default
+// sizes); 64 / 128 = 16-B vector loaders for a wide discriminator (every dimension a multiple of 4), sized so that each
+// launch still fills the 256 CUs
+inline int d_tile(const ltg_config* cfg, int which) {
+    const bool wide = cfg->d_h0 >= 512 && cfg->d_h1 + cfg->d_h2 >= 512 && cfg->d_h3 >= 128;
+    const bool vec = (cfg->d_h0 % 4) == 0 && (cfg->d_h1 % 4) == 0 && (cfg->d_h2 % 4) == 0 && (cfg->d_h3 % 4) == 0;
+    const int knob = (cfg->reserved0 >> 10) & 7;        // tuning: 1 scalar, 2 all 64, 3 all 128
+    if (!(wide && vec) || knob == 1) return 32;
+    if (knob == 2) return 64;
+    if (knob == 3) return 128;
+    if (which == 1) return d_mode(cfg) == 2 ? 64 : 32;   // l2 (N = h3 = 256): too few 64-tiles to fill the chip unless the loads are the bottleneck
+    return which == 3 ? 128 : 64;
+}
 #define LTG_D_DISPATCH(KERNEL, MODE, TS, GRID, ST, ...)                                                              \
     do {                                                                                                             \
         if ((TS) == 64) {                                                                                            \
             if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                \
             else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);           \
             else hipLaunchKernelGGL((KERNEL<0, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                            \
+        } else if ((TS) == 128) {                                                                                    \
+            if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 128>), GRID, dim3(NT), 0, ST, __VA_ARGS__);               \
+            else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 128>), GRID, dim3(NT), 0, ST, __VA_ARGS__);          \
+            else hipLaunchKernelGGL((KERNEL<0, 128>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                           \
         } else {                                                                                                     \
             if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                \
             else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);           \
@@ -1808,10 +1877,10 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    const int md = d_mode(cfg), ts = d_tile(cfg);
+    const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1);
     LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, ts, ts, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                               d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
-    LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts, grid2(h3, n, ts, ts), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
+    LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts2, grid2(h3, n, ts2, ts2), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
     const dim3 go((n + NT / 64 - 1) / (NT / 64));
     if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
     else hipLaunchKernelGGL(k_d_out<false>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
@@ -1875,15 +1944,16 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
-    const int md = d_mode(cfg), ts = d_tile(cfg);
+    const int md = d_mode(cfg), ts = d_tile(cfg, 2), tsb = d_tile(cfg, 3);
     auto tiles = [ts](int x) { return (x + ts - 1) / ts; };
+    auto tilesb = [tsb](int x) { return (x + tsb - 1) / tsb; };
     const int nA = tiles(n) * tiles(h12);
     const int nB = ks * tiles(h12 + 1) * tiles(h3);
     const int nC = ks * ((h3 + 1 + 31) / 32);
     LTG_PROBED(pr, LTG_K_D_BWD1, LTG_D_DISPATCH(k_d_bwd1, md, ts, dim3(nA + nB + nC), st, n, h12, h3, nA, nB, ks, L, w.A1, w.A3, w.ds, w.dpre3, disc->p[4],
                                                 o->keep_prob, w.dpre1, w.slab));
-    const int n2 = ks * tiles(h0 + 1) * (tiles(h1) + tiles(h2));
-    LTG_PROBED(pr, LTG_K_D_BWD2, LTG_D_DISPATCH(k_d_bwd2, md, ts, dim3(n2), st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
+    const int n2 = ks * tilesb(h0 + 1) * (tilesb(h1) + tilesb(h2));
+    LTG_PROBED(pr, LTG_K_D_BWD2, LTG_D_DISPATCH(k_d_bwd2, md, tsb, dim3(n2), st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
     int ga = (L.off[8] + NT - 1) / NT;
     if (ga > 1024) ga = 1024;
     LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, w.slab, *disc, ad, n, w.lrow, loss_out));
