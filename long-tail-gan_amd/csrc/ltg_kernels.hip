@@ -158,9 +158,17 @@ __global__ __launch_bounds__(NT) void k_bias_tanh(int n, int H, const float* __r
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) h[i] = tanhf(h[i] + bias[i % H]);
 }
 
+// float4 of 4 consecutive floats at p[i .. i+3], zero where i + j >= n (n % 4 == 0 at every call site, so a group is
+// either whole or absent; the address is clamped, the load unconditional)
+__device__ __forceinline__ float4 ltg_ld4(const float* __restrict__ p, int i, int n, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(p + min(i, n - 4));
+    const bool k = ok && i < n;
+    return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+}
+
 // Generic dense layer  C = act(A[M][K] . B[K][N] + bias)  (fp32 MFMA); act: 0 none, 1 tanh.
 // Serves enc-1 (MultiVAE.py:152) and dec-0 (MultiVAE.py:168-172).
-template <int ACT>
+template <int ACT, bool V, int BKV = 128>
 __global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const float* __restrict__ A,
                                                   const float* __restrict__ Bw, const float* __restrict__ bias,
                                                   float* __restrict__ C) {
@@ -171,7 +179,13 @@ __global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const flo
         const float x = acc + bias[n];
         C[(size_t)m * N + n] = ACT == 1 ? tanhf(x) : x;
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
+    if constexpr (V) {   // 16-B loads (K % 4 == 0, N % 4 == 0): same MFMA sequence, a quarter of the load instructions
+        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A + (size_t)min(m, M - 1) * K, k, K, m < M); };
+        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Bw + (size_t)min(k, K - 1) * N, n, N, k < K); };
+        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, true, false, 0, 0, true>(M, N, m0, n0, 0, K, a4, b4, epi);
+    } else {
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
+    }
 }
 
 // Reparameterisation + KL (MultiVAE.py:157-162, :178-181).
@@ -691,14 +705,6 @@ struct DropView {
         return ltg_rng_keep(seed, stream, step, (uint64_t)r * width + c, kp);
     }
 };
-
-// float4 of 4 consecutive floats at p[i .. i+3], zero where i + j >= n (n % 4 == 0 at every call site, so a group is
-// either whole or absent; the address is clamped, the load unconditional)
-__device__ __forceinline__ float4 ltg_ld4(const float* __restrict__ p, int i, int n, bool ok) {
-    const float4 v = *reinterpret_cast<const float4*>(p + min(i, n - 4));
-    const bool k = ok && i < n;
-    return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
-}
 
 // Discriminator GEMM precision (ltg_config.d_precision): 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 operands,
 // 2 = OCP e4m3 operands with STATIC power-of-two scales per operand class (no amax pass: the classes are bounded --
@@ -1290,6 +1296,7 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)
+template <bool V, int BKV = 128>
 __global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
                                            const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
                                            float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
@@ -1305,11 +1312,18 @@ __global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __r
         dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
         dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
+    if constexpr (V) {
+        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(da2 + (size_t)min(m, B - 1) * H, k, H, m < B); };
+        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp0 + (size_t)min(n, Z - 1) * H, k, H, n < Z); };
+        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, true>(B, Z, m0, n0, 0, H, a4, b4, epi);
+    } else {
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
+    }
 }
 
 // generic "weight gradient + Adam": G[m][n] = sum_k L(k,m) * R(k,n) with ones-augmented row m == Min
 // (bias gradient).  L: [K][Min] activations, R: [K][N] upstream gradient.
+template <bool V>
 __global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const float* __restrict__ L,
                                                    const float* __restrict__ R, float* __restrict__ W, float* __restrict__ mW,
                                                    float* __restrict__ vW, float* __restrict__ bias, float* __restrict__ mb,
@@ -1324,10 +1338,21 @@ __global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const 
         if (m < Min) adam_update(W, mW, vW, (size_t)m * N + n, g, ad);
         else adam_update(bias, mb, vb, n, g, ad);
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
+    if constexpr (V) {   // Min % 4 == 0: the ones row (m == Min) opens its own group
+        auto a4 = [=] __device__(int m, int k) -> float4 {
+            float4 v = ltg_ld4(L + (size_t)min(k, K - 1) * Min, m, Min, k < K);
+            if (m == Min && k < K) v.x = 1.f;
+            return v;
+        };
+        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(R + (size_t)min(k, K - 1) * N, n, N, k < K); };
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true, false, 0, 0, true>(Min + 1, N, m0, n0, 0, K, a4, b4, epi);
+    } else {
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
+    }
 }
 
 // dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)
+template <bool V, int BKV = 128>
 __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* __restrict__ dmlv,
                                             const float* __restrict__ Wq1, const float* __restrict__ h1, float* __restrict__ da1) {
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -1337,7 +1362,13 @@ __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* _
         const float t = h1[(size_t)m * H + n];
         da1[(size_t)m * H + n] = acc * (1.f - t * t);
     };
-    ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
+    if constexpr (V) {
+        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dmlv + (size_t)min(m, B - 1) * Z2, k, Z2, m < B); };
+        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wq1 + (size_t)min(n, H - 1) * Z2, k, Z2, n < H); };
+        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, true>(B, H, m0, n0, 0, Z2, a4, b4, epi);
+    } else {
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
+    }
 }
 
 // Sparse gradient rows of W_q0: G[u][:] = sum over the batch entries of item uitem[u] of
@@ -1788,14 +1819,21 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
                     const ltg_gen_acts* acts, int apply_bias_tanh, hipStream_t st) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const Probe pr{o->probe, st};
+    const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
     if (apply_bias_tanh) {
         const int n = R * H;
         hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
     }
-    LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(k_dense_fwd<0>, grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv));
+    pr.before(LTG_K_ENC1);
+    if (vz) hipLaunchKernelGGL((k_dense_fwd<0, true>), grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
+    else hipLaunchKernelGGL((k_dense_fwd<0, false>), grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
+    pr.after(LTG_K_ENC1);
     hipLaunchKernelGGL(k_reparam, dim3(R), dim3(NT), 0, st, Z, acts->mulv, o->eps, o->is_training, cfg->seed, o->rng_step,
                        acts->z, acts->kl_rows);
-    LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(k_dense_fwd<1>, grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2));
+    pr.before(LTG_K_DEC0);
+    if (vz) hipLaunchKernelGGL((k_dense_fwd<1, true>), grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
+    else hipLaunchKernelGGL((k_dense_fwd<1, false>), grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
+    pr.after(LTG_K_DEC0);
     {
         const bool bf = cfg->precision == LTG_PREC_BF16, big = I >= 8192;
         pr.before(LTG_K_DEC1_FWD);
@@ -2022,6 +2060,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
+    const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
     // Small item slabs: the critical path da2 -> dz -> dh1 -> sweep of W_q0 stays on `st`; the three weight-gradient + Adam
     // kernels only consume it and run on the caller's aux stream, each released by a re-recorded ev_fork after the last
     // READER of the weights it updates (dz reads W_p0, dh1 reads W_q1) has been enqueued on `st`.
@@ -2066,21 +2105,29 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     launch_dw();
     const Probe pc{o->probe, s_chain}, pw{o->probe, s_wg};
     pc.before(LTG_K_DZ);
-    hipLaunchKernelGGL(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, s_chain, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
-                       o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
+#define LTG_V2(KERNEL, ...)                                       \
+    do {                                                          \
+        if (vz) hipLaunchKernelGGL(KERNEL<true>, __VA_ARGS__);    \
+        else hipLaunchKernelGGL(KERNEL<false>, __VA_ARGS__);      \
+    } while (0)
+    // (BK = 256 tiles: dz -7 %, dh1 -5 % on their own, but the 66 KB of LDS per workgroup crowd out the kernels of the aux
+    // stream -- the whole G step got 2-3 % slower; measured, not kept)
+    LTG_V2(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, s_chain, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
+           o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
     pc.after(LTG_K_DZ);
     if (small_mode) release_aux();  // dz (the reader of the old W_p0) is enqueued
     pw.before(LTG_K_WGRAD_P0);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, s_wg, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
-                       gen->p[6], gen->m[6], gen->v[6], ad);
+    LTG_V2(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, s_wg, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
+           gen->p[6], gen->m[6], gen->v[6], ad);
     pw.after(LTG_K_WGRAD_P0);
     pc.before(LTG_K_DH1);
-    hipLaunchKernelGGL(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, s_chain, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
+    LTG_V2(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, s_chain, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
     pc.after(LTG_K_DH1);
     if (small_mode) release_aux();  // dh1 (the reader of the old W_q1) is enqueued
     pw.before(LTG_K_WGRAD_Q1);
-    hipLaunchKernelGGL(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, s_wg, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
-                       gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
+    LTG_V2(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, s_wg, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
+           gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
+#undef LTG_V2
     pw.after(LTG_K_WGRAD_Q1);
     if (small_mode) (void)hipEventRecord(evj, aux);
     const int nu = bt->n_unique;
