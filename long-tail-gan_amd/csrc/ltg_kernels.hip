@@ -714,7 +714,7 @@ struct DropView {
 // dimension a multiple of 4).
 constexpr int FP8_S_EMB = 8, FP8_S_W = 8, FP8_S_ACT = 6, FP8_S_G3 = 8, FP8_S_G1 = 7;
 // branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular->h1, 1 niche->h2
-template <int MODE, int TS>
+template <int MODE, int TS, bool V>
 __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                              const float* __restrict__ w2, const float* __restrict__ b2, DropView dA,
@@ -739,20 +739,20 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
                            : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + (br ? h1 : 0) + nn] = kp ? t / keep : 0.f;
     };
-    if constexpr (TS >= 64) {
+    if constexpr (V) {
         auto a4 = [=] __device__(int m, int k) -> float4 {
             const int id = br ? pv.nic(min(m, n - 1)) : pv.pop(min(m, n - 1));
             return ltg_ld4(emb + (size_t)max(id, 0) * h0, k, h0, m < n && id >= 0);
         };
         auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(W + (size_t)min(k, h0 - 1) * N, nn, N, k < h0); };
-        ltg_gemm_block<MODE, TS, TS, 64, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, true>(n, N, m0, n0, 0, h0, a4, b4, epi);
+        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, true>(n, N, m0, n0, 0, h0, a4, b4, epi);
     } else {
         ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W>(n, N, m0, n0, 0, h0, a, b, epi);
     }
 }
 
 // fully connected layer (discriminator.py:44, :54)
-template <int MODE, int TS>
+template <int MODE, int TS, bool V>
 __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float* __restrict__ A1,
                                              const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
                                              float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
@@ -763,10 +763,10 @@ __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float
         const float t = tanhf(acc + b3[nn]);
         A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
     };
-    if constexpr (TS >= 64) {
+    if constexpr (V) {
         auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A1 + (size_t)min(m, n - 1) * h12, k, h12, m < n); };
         auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(k, h12 - 1) * h3, nn, h3, k < h12); };
-        ltg_gemm_block<MODE, TS, TS, 64, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W, true>(n, h3, m0, n0, 0, h12, a4, b4, epi);
+        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_ACT, FP8_S_W, true>(n, h3, m0, n0, 0, h12, a4, b4, epi);
     } else {
         ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W>(n, h3, m0, n0, 0, h12, a, b, epi);
     }
@@ -832,7 +832,7 @@ constexpr int D_KCHUNK = 256;  // pair rows per split-K slab
 //   job A  dpre1 = (dpre3 . w3^T) * dact(A1)                       [n][h1+h2]     tiles 64x64
 //   job B  slab[z] += A1^T . dpre3 (+ ones row -> db3), split-K     [(h12+1)][h3]  tiles 32x32
 //   job C  slab[z] += A3^T . ds, sum ds (dw4, db4), split-K         column reduce
-template <int MODE, int TS>
+template <int MODE, int TS, bool V>
 __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, int nB, int ks, DLayout L,
                                                const float* __restrict__ A1, const float* __restrict__ A3,
                                                const float* __restrict__ ds, const float* __restrict__ dpre3,
@@ -847,10 +847,10 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
         auto epi = [=] __device__(int m, int nn, float acc) {
             dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
         };
-        if constexpr (TS >= 64) {
+        if constexpr (V) {
             auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dpre3 + (size_t)min(m, n - 1) * h3, k, h3, m < n); };
             auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(nn, h12 - 1) * h3, k, h3, nn < h12); };
-            ltg_gemm_block<MODE, TS, TS, 64, 2, 2, false, false, false, FP8_S_G3, FP8_S_W, true>(n, h12, m0, n0, 0, h3, a4, b4, epi);
+            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, false, false, FP8_S_G3, FP8_S_W, true>(n, h12, m0, n0, 0, h3, a4, b4, epi);
         } else {
             ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, false, false, FP8_S_G3, FP8_S_W>(n, h12, m0, n0, 0, h3, a, b, epi);
         }
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        if constexpr (TS >= 64) {
+        if constexpr (V) {
             // rows m < h12: A1^T; row m == h12: ones (bias gradient); h12 % 4 == 0, so the ones row opens its own group
             auto a4 = [=] __device__(int m, int k) -> float4 {
                 float4 v = ltg_ld4(A1 + (size_t)min(k, kend - 1) * h12, m, h12, k < kend);
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
                 return v;
             };
             auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre3 + (size_t)min(k, kend - 1) * h3, nn, h3, k < kend); };
-            ltg_gemm_block<MODE, TS, TS, 64, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3, true>(h12 + 1, h3, m0, n0, kbeg, kend, a4, b4, epi);
+            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3, true>(h12 + 1, h3, m0, n0, kbeg, kend, a4, b4, epi);
         } else {
             ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
         }
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
 }
 
 // Backward stage 2: dw1/db1 and dw2/db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), split-K.
-template <int MODE, int TS>
+template <int MODE, int TS, bool V>
 __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int h2, int ks, DLayout L,
                                                const float* __restrict__ emb, const float* __restrict__ dpre1,
                                                float* __restrict__ slab) {
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    if constexpr (TS >= 64) {
+    if constexpr (V) {
         auto a4 = [=] __device__(int m, int k) -> float4 {
             const int kc = min(k, kend - 1);
             const int id = br ? pv.nic(kc) : pv.pop(kc);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
             return v;
         };
         auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre1 + (size_t)min(k, kend - 1) * h12 + coff, nn, N, k < kend); };
-        ltg_gemm_block<MODE, TS, TS, 64, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, true>(h0 + 1, N, m0, n0, kbeg, kend, a4, b4, epi);
+        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, true>(h0 + 1, N, m0, n0, kbeg, kend, a4, b4, epi);
     } else {
         ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
     }
@@ -1887,27 +1887,31 @@ inline int d_tile(const ltg_config* cfg, int which) {
     const bool wide = cfg->d_h0 >= 512 && cfg->d_h1 + cfg->d_h2 >= 512 && cfg->d_h3 >= 128;
     const bool vec = (cfg->d_h0 % 4) == 0 && (cfg->d_h1 % 4) == 0 && (cfg->d_h2 % 4) == 0 && (cfg->d_h3 % 4) == 0;
     const int knob = (cfg->reserved0 >> 10) & 7;        // tuning: 1 scalar, 2 all 64, 3 all 128
-    if (!(wide && vec) || knob == 1) return 32;
+    if (knob == 1) return 32;
+    if (!(wide && vec)) {
+        // default sizes (100/150/250/300): l2 and backward stage 1 only touch h12 = 400 and h3 = 300 wide rows -> 16-B
+        // loaders on the 32 x 32 tiles; l1 / stage 2 index columns of width h1 = 150 (8-B aligned only) -> scalar
+        const bool v12 = ((cfg->d_h1 + cfg->d_h2) % 4) == 0 && (cfg->d_h3 % 4) == 0;
+        return ((which == 1 || which == 2) && v12) ? -32 : 32;
+    }
     if (knob == 2) return 64;
     if (knob == 3) return 128;
-    if (which == 1) return d_mode(cfg) == 2 ? 64 : 32;   // l2 (N = h3 = 256): too few 64-tiles to fill the chip unless the loads are the bottleneck
+    if (which == 1) return d_mode(cfg) == 2 ? 64 : -32;   // l2 (N = h3 = 256): too few 64-tiles to fill the chip unless the loads are the bottleneck
     return which == 3 ? 128 : 64;
 }
-#define LTG_D_DISPATCH(KERNEL, MODE, TS, GRID, ST, ...)                                                              \
+#define LTG_D_DISPATCH3(KERNEL, MODE, TS, V, GRID, ST, ...)                                                          \
     do {                                                                                                             \
-        if ((TS) == 64) {                                                                                            \
-            if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                \
-            else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);           \
-            else hipLaunchKernelGGL((KERNEL<0, 64>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                            \
-        } else if ((TS) == 128) {                                                                                    \
-            if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 128>), GRID, dim3(NT), 0, ST, __VA_ARGS__);               \
-            else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 128>), GRID, dim3(NT), 0, ST, __VA_ARGS__);          \
-            else hipLaunchKernelGGL((KERNEL<0, 128>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                           \
-        } else {                                                                                                     \
-            if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                \
-            else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);           \
-            else hipLaunchKernelGGL((KERNEL<0, 32>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                            \
-        }                                                                                                            \
+        if ((MODE) == 1) hipLaunchKernelGGL((KERNEL<1, TS, V>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                 \
+        else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, TS, V>), GRID, dim3(NT), 0, ST, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((KERNEL<0, TS, V>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                             \
+    } while (0)
+// TSV: tile size, negative = 32 x 32 tiles with the 16-B vector loaders
+#define LTG_D_DISPATCH(KERNEL, MODE, TSV, GRID, ST, ...)                                                             \
+    do {                                                                                                             \
+        if ((TSV) == 128) LTG_D_DISPATCH3(KERNEL, MODE, 128, true, GRID, ST, __VA_ARGS__);                           \
+        else if ((TSV) == 64) LTG_D_DISPATCH3(KERNEL, MODE, 64, true, GRID, ST, __VA_ARGS__);                        \
+        else if ((TSV) < 0) LTG_D_DISPATCH3(KERNEL, MODE, 32, true, GRID, ST, __VA_ARGS__);                          \
+        else LTG_D_DISPATCH3(KERNEL, MODE, 32, false, GRID, ST, __VA_ARGS__);                                        \
     } while (0)
 
 void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
@@ -1915,10 +1919,10 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1);
-    LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, ts, ts, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+    const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? -ts : ts, t2 = ts2 < 0 ? -ts2 : ts2;
+    LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, t1, t1, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                               d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
-    LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts2, grid2(h3, n, ts2, ts2), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
+    LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts2, grid2(h3, n, t2, t2), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
     const dim3 go((n + NT / 64 - 1) / (NT / 64));
     if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
     else hipLaunchKernelGGL(k_d_out<false>, go, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
@@ -1982,9 +1986,9 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
-    const int md = d_mode(cfg), ts = d_tile(cfg, 2), tsb = d_tile(cfg, 3);
-    auto tiles = [ts](int x) { return (x + ts - 1) / ts; };
-    auto tilesb = [tsb](int x) { return (x + tsb - 1) / tsb; };
+    const int md = d_mode(cfg), ts = d_tile(cfg, 2), tsb = d_tile(cfg, 3), ta = ts < 0 ? -ts : ts, tb = tsb < 0 ? -tsb : tsb;
+    auto tiles = [ta](int x) { return (x + ta - 1) / ta; };
+    auto tilesb = [tb](int x) { return (x + tb - 1) / tb; };
     const int nA = tiles(n) * tiles(h12);
     const int nB = ks * tiles(h12 + 1) * tiles(h3);
     const int nC = ks * ((h3 + 1 + 31) / 32);
