@@ -105,3 +105,24 @@ def test_train_cli_under_torchrun_item_sharded(tmp_path):
     out = subprocess.run([sys.executable, script, ds], cwd=cwd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "Restored" in out.stdout and "global-epoch: 1 Data Creation Finished" in out.stdout
+
+
+def test_bench_contract_one_json_line():
+    """bench.py prints ONE JSON line (the last line of stdout) carrying the driver's keys plus roofline and cpu_baseline."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--sub-epochs", "2",
+                          "--cpu-seconds", "3"], capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = out.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "users/s" and d["value"] > 1000 and d["config"]["workload"] == "askubuntu" and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "users/s" and "sample" in c
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - d["config"]["users"]) < 1e-3 * d["config"]["users"]
