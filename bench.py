@@ -240,11 +240,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    local %= max(1, torch.cuda.device_count())      # more ranks than GPUs only with LTGAN_DIST_BACKEND=gloo (test rigs)
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
+    backend = os.environ.get("LTGAN_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from ltgan.engine import Engine
     from ltgan.trainer import Trainer
     workload = a.workload or ("askubuntu" if world == 1 else "c4")
@@ -253,7 +255,7 @@ def main():
     if mode == "item-shard" and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1)      # exercises the RCCL code path on one GPU
+        dist.init_process_group(backend, rank=0, world_size=1)      # exercises the RCCL code path on one GPU
     idx, data, desc = load_workload(workload, a.batch_size, device, a.users)
     n1_ref = None
     if mode == "item-shard":

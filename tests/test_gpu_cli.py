@@ -126,3 +126,21 @@ def test_bench_contract_one_json_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "users/s" and "sample" in c
     assert abs(d["ms_per_step"] * 1e-3 * d["value"] - d["config"]["users"]) < 1e-3 * d["config"]["users"]
+
+
+def test_bench_two_ranks_item_sharded():
+    """The N > 1 branch of bench.py (rank-0 reference run, item-sharded loop, max over ranks, one JSON line from rank 0)
+    with 2 ranks on the one GPU of the test box (gloo instead of RCCL)."""
+    import json
+    env = dict(os.environ, LTGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--users", "400",
+           "--sub-epochs", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["workload"] == "c4" and d["config"]["items"] == 100032
+    assert d["value"] > 0 and d["n1_same_workload"]["value"] > 0 and d["strong_scaling_vs_1gpu"] > 0
+    assert d["roofline"]["kernel"] == "dec1_bwd_adam" and d["roofline"]["bound"] == "hbm"
