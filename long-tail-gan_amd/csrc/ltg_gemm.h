@@ -58,11 +58,10 @@ template <int BK_> struct LtgGemmCfg<2, BK_> {
 // M, N: logical bounds of the tile grid (rows of A / columns of B); loaders are only called in range.
 // [kbeg, kend): K range of this block (split-K).  A_MCONTIG / B_NCONTIG choose the thread->element
 // map of the global loads so that consecutive threads walk the operand's contiguous dimension.
-// VLOAD: the functors return FOUR consecutive elements of the contiguous dimension (float4; the caller clamps the
-// address and zeroes what lies outside the operand), 16 B per lane instead of 4 -- for GEMMs large enough to be bound by
-// their loads rather than by launch latency:
+// VLOAD (bit 0: operand A, bit 1: operand B): that functor returns FOUR consecutive elements of the contiguous dimension
+// (float4; the caller clamps the address and zeroes what lies outside the operand), 16 B per lane instead of 4:
 //   a(m, k): A_MCONTIG ? (m..m+3, k) : (m, k..k+3)      b(k, n): B_NCONTIG ? (k, n..n+3) : (k..k+3, n)
-template <int MODE, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, bool VEC_EPI = false, int SA = 0, int SB = 0, bool VLOAD = false, class AF, class BF, class EF>
+template <int MODE, int BM, int BN, int BK_, int WM, int WN, bool A_MCONTIG, bool B_NCONTIG, bool VEC_EPI = false, int SA = 0, int SB = 0, int VLOAD = 0, class AF, class BF, class EF>
 __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int kbeg, int kend, AF a, BF b, EF epi) {
     constexpr bool BF16 = MODE == 1, FP8 = MODE == 2;
     typedef LtgGemmCfg<MODE, BK_> Cfg;
@@ -96,13 +95,14 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
 
+    constexpr bool VA = (VLOAD & 1) != 0, VB = (VLOAD & 2) != 0;
     static_assert(!VLOAD || (BM % 4 == 0 && BN % 4 == 0 && BK % 4 == 0 && EA % 4 == 0 && EB % 4 == 0), "vector loads need multiples of 4");
     float ra[EA], rb[EB];
     // Loads are UNCONDITIONAL: indices are clamped into [0,M) x [kbeg,kend) (resp. [0,N)) and the value
     // is zeroed by a select afterwards, so the loaders never branch (a divergent branch per element
     // costs ~25 instructions and serialises dependent gathers).  Loaders may assume in-range indices.
     auto fetch = [&](int k0) {
-        if constexpr (VLOAD) {
+        if constexpr (VA) {
 #pragma unroll
             for (int j = 0; j < EA / 4; ++j) {
                 const int v = tid + NT * j;
@@ -110,14 +110,6 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
                 const int kk = A_MCONTIG ? v / (BM / 4) : (v % (BK / 4)) * 4;
                 const float4 x = a(m0 + mm, k0 + kk);
                 ra[4 * j] = x.x; ra[4 * j + 1] = x.y; ra[4 * j + 2] = x.z; ra[4 * j + 3] = x.w;
-            }
-#pragma unroll
-            for (int j = 0; j < EB / 4; ++j) {
-                const int v = tid + NT * j;
-                const int nn = B_NCONTIG ? (v % (BN / 4)) * 4 : v / (BK / 4);
-                const int kk = B_NCONTIG ? v / (BN / 4) : (v % (BK / 4)) * 4;
-                const float4 x = b(k0 + kk, n0 + nn);
-                rb[4 * j] = x.x; rb[4 * j + 1] = x.y; rb[4 * j + 2] = x.z; rb[4 * j + 3] = x.w;
             }
         } else {
 #pragma unroll
@@ -129,6 +121,17 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
                 const float v = a(min(gm, M - 1), min(gk, kend - 1));
                 ra[j] = (gk < kend && gm < M) ? v : 0.f;
             }
+        }
+        if constexpr (VB) {
+#pragma unroll
+            for (int j = 0; j < EB / 4; ++j) {
+                const int v = tid + NT * j;
+                const int nn = B_NCONTIG ? (v % (BN / 4)) * 4 : v / (BK / 4);
+                const int kk = B_NCONTIG ? v / (BN / 4) : (v % (BK / 4)) * 4;
+                const float4 x = b(k0 + kk, n0 + nn);
+                rb[4 * j] = x.x; rb[4 * j + 1] = x.y; rb[4 * j + 2] = x.z; rb[4 * j + 3] = x.w;
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
                 const int e = tid + NT * j;
@@ -151,7 +154,7 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
         else return x;
     };
     auto stash = [&]() {
-        if constexpr (VLOAD) {
+        if constexpr (VA) {
 #pragma unroll
             for (int j = 0; j < EA / 4; ++j) {
                 const int v = tid + NT * j;
@@ -159,14 +162,6 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
                 const int kk = A_MCONTIG ? v / (BM / 4) : (v % (BK / 4)) * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) As[(mm + (A_MCONTIG ? i : 0)) * LDK + kk + (A_MCONTIG ? 0 : i)] = cvtA(ra[4 * j + i]);
-            }
-#pragma unroll
-            for (int j = 0; j < EB / 4; ++j) {
-                const int v = tid + NT * j;
-                const int nn = B_NCONTIG ? (v % (BN / 4)) * 4 : v / (BK / 4);
-                const int kk = B_NCONTIG ? v / (BN / 4) : (v % (BK / 4)) * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Bs[(nn + (B_NCONTIG ? i : 0)) * LDK + kk + (B_NCONTIG ? 0 : i)] = cvtB(rb[4 * j + i]);
             }
         } else {
 #pragma unroll
@@ -176,6 +171,17 @@ __device__ __forceinline__ void ltg_gemm_block(int M, int N, int m0, int n0, int
                 const int kk = A_MCONTIG ? (e / BM) : (e % BK);
                 As[mm * LDK + kk] = cvtA(ra[j]);
             }
+        }
+        if constexpr (VB) {
+#pragma unroll
+            for (int j = 0; j < EB / 4; ++j) {
+                const int v = tid + NT * j;
+                const int nn = B_NCONTIG ? (v % (BN / 4)) * 4 : v / (BK / 4);
+                const int kk = B_NCONTIG ? v / (BN / 4) : (v % (BK / 4)) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[(nn + (B_NCONTIG ? i : 0)) * LDK + kk + (B_NCONTIG ? 0 : i)] = cvtB(rb[4 * j + i]);
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
                 const int e = tid + NT * j;

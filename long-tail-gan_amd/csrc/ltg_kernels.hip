@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const flo
     if constexpr (V) {   // 16-B loads (K % 4 == 0, N % 4 == 0): same MFMA sequence, a quarter of the load instructions
         auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A + (size_t)min(m, M - 1) * K, k, K, m < M); };
         auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Bw + (size_t)min(k, K - 1) * N, n, N, k < K); };
-        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, true, false, 0, 0, true>(M, N, m0, n0, 0, K, a4, b4, epi);
+        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, true, false, 0, 0, 3>(M, N, m0, n0, 0, K, a4, b4, epi);
     } else {
         ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
     }
@@ -714,7 +714,7 @@ struct DropView {
 // dimension a multiple of 4).
 constexpr int FP8_S_EMB = 8, FP8_S_W = 8, FP8_S_ACT = 6, FP8_S_G3 = 8, FP8_S_G1 = 7;
 // branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular->h1, 1 niche->h2
-template <int MODE, int TS, bool V>
+template <int MODE, int TS, int V>
 __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                              const float* __restrict__ w2, const float* __restrict__ b2, DropView dA,
@@ -745,14 +745,15 @@ __global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2
             return ltg_ld4(emb + (size_t)max(id, 0) * h0, k, h0, m < n && id >= 0);
         };
         auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(W + (size_t)min(k, h0 - 1) * N, nn, N, k < h0); };
-        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, true>(n, N, m0, n0, 0, h0, a4, b4, epi);
+        if constexpr (V == 3) ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, 3>(n, N, m0, n0, 0, h0, a4, b4, epi);
+        else ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, 1>(n, N, m0, n0, 0, h0, a4, b, epi);   // h1 / h2 not multiples of 4
     } else {
         ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W>(n, N, m0, n0, 0, h0, a, b, epi);
     }
 }
 
 // fully connected layer (discriminator.py:44, :54)
-template <int MODE, int TS, bool V>
+template <int MODE, int TS, int V>
 __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float* __restrict__ A1,
                                              const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
                                              float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float
     if constexpr (V) {
         auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A1 + (size_t)min(m, n - 1) * h12, k, h12, m < n); };
         auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(k, h12 - 1) * h3, nn, h3, k < h12); };
-        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_ACT, FP8_S_W, true>(n, h3, m0, n0, 0, h12, a4, b4, epi);
+        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_ACT, FP8_S_W, 3>(n, h3, m0, n0, 0, h12, a4, b4, epi);
     } else {
         ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W>(n, h3, m0, n0, 0, h12, a, b, epi);
     }
@@ -832,7 +833,7 @@ constexpr int D_KCHUNK = 256;  // pair rows per split-K slab
 //   job A  dpre1 = (dpre3 . w3^T) * dact(A1)                       [n][h1+h2]     tiles 64x64
 //   job B  slab[z] += A1^T . dpre3 (+ ones row -> db3), split-K     [(h12+1)][h3]  tiles 32x32
 //   job C  slab[z] += A3^T . ds, sum ds (dw4, db4), split-K         column reduce
-template <int MODE, int TS, bool V>
+template <int MODE, int TS, int V>
 __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, int nB, int ks, DLayout L,
                                                const float* __restrict__ A1, const float* __restrict__ A3,
                                                const float* __restrict__ ds, const float* __restrict__ dpre3,
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
         if constexpr (V) {
             auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dpre3 + (size_t)min(m, n - 1) * h3, k, h3, m < n); };
             auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(nn, h12 - 1) * h3, k, h3, nn < h12); };
-            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, false, false, FP8_S_G3, FP8_S_W, true>(n, h12, m0, n0, 0, h3, a4, b4, epi);
+            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, false, false, FP8_S_G3, FP8_S_W, 3>(n, h12, m0, n0, 0, h3, a4, b4, epi);
         } else {
             ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, false, false, FP8_S_G3, FP8_S_W>(n, h12, m0, n0, 0, h3, a, b, epi);
         }
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
                 return v;
             };
             auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre3 + (size_t)min(k, kend - 1) * h3, nn, h3, k < kend); };
-            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3, true>(h12 + 1, h3, m0, n0, kbeg, kend, a4, b4, epi);
+            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3, 3>(h12 + 1, h3, m0, n0, kbeg, kend, a4, b4, epi);
         } else {
             ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
         }
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
 }
 
 // Backward stage 2: dw1/db1 and dw2/db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), split-K.
-template <int MODE, int TS, bool V>
+template <int MODE, int TS, int V>
 __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int h2, int ks, DLayout L,
                                                const float* __restrict__ emb, const float* __restrict__ dpre1,
                                                float* __restrict__ slab) {
@@ -950,7 +951,8 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
             return v;
         };
         auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre1 + (size_t)min(k, kend - 1) * h12 + coff, nn, N, k < kend); };
-        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, true>(h0 + 1, N, m0, n0, kbeg, kend, a4, b4, epi);
+        if constexpr (V == 3) ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, 3>(h0 + 1, N, m0, n0, kbeg, kend, a4, b4, epi);
+        else ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, 1>(h0 + 1, N, m0, n0, kbeg, kend, a4, b, epi);
     } else {
         ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
     }
@@ -1315,7 +1317,7 @@ __global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __r
     if constexpr (V) {
         auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(da2 + (size_t)min(m, B - 1) * H, k, H, m < B); };
         auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp0 + (size_t)min(n, Z - 1) * H, k, H, n < Z); };
-        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, true>(B, Z, m0, n0, 0, H, a4, b4, epi);
+        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, 3>(B, Z, m0, n0, 0, H, a4, b4, epi);
     } else {
         ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
     }
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const 
             return v;
         };
         auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(R + (size_t)min(k, K - 1) * N, n, N, k < K); };
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true, false, 0, 0, true>(Min + 1, N, m0, n0, 0, K, a4, b4, epi);
+        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true, false, 0, 0, 3>(Min + 1, N, m0, n0, 0, K, a4, b4, epi);
     } else {
         ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
     }
@@ -1365,7 +1367,7 @@ __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* _
     if constexpr (V) {
         auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dmlv + (size_t)min(m, B - 1) * Z2, k, Z2, m < B); };
         auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wq1 + (size_t)min(n, H - 1) * Z2, k, Z2, n < H); };
-        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, true>(B, H, m0, n0, 0, Z2, a4, b4, epi);
+        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, 3>(B, H, m0, n0, 0, Z2, a4, b4, epi);
     } else {
         ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
     }
@@ -1892,7 +1894,8 @@ inline int d_tile(const ltg_config* cfg, int which) {
         // default sizes (100/150/250/300): l2 and backward stage 1 only touch h12 = 400 and h3 = 300 wide rows -> 16-B
         // loaders on the 32 x 32 tiles; l1 / stage 2 index columns of width h1 = 150 (8-B aligned only) -> scalar
         const bool v12 = ((cfg->d_h1 + cfg->d_h2) % 4) == 0 && (cfg->d_h3 % 4) == 0;
-        return ((which == 1 || which == 2) && v12) ? -32 : 32;
+        if (which == 1 || which == 2) return v12 ? -32 : 32;
+        return ((cfg->d_h0 % 4) == 0 && (cfg->reserved0 & 32768) == 0) ? -33 : 32;   // embedding rows (operand A) in 16-B pieces
     }
     if (knob == 2) return 64;
     if (knob == 3) return 128;
@@ -1905,13 +1908,14 @@ inline int d_tile(const ltg_config* cfg, int which) {
         else if ((MODE) == 2) hipLaunchKernelGGL((KERNEL<2, TS, V>), GRID, dim3(NT), 0, ST, __VA_ARGS__);            \
         else hipLaunchKernelGGL((KERNEL<0, TS, V>), GRID, dim3(NT), 0, ST, __VA_ARGS__);                             \
     } while (0)
-// TSV: tile size, negative = 32 x 32 tiles with the 16-B vector loaders
+// TSV: tile size; -32 = 32 x 32 tiles with 16-B vector loaders on both operands, -33 = on operand A only
 #define LTG_D_DISPATCH(KERNEL, MODE, TSV, GRID, ST, ...)                                                             \
     do {                                                                                                             \
-        if ((TSV) == 128) LTG_D_DISPATCH3(KERNEL, MODE, 128, true, GRID, ST, __VA_ARGS__);                           \
-        else if ((TSV) == 64) LTG_D_DISPATCH3(KERNEL, MODE, 64, true, GRID, ST, __VA_ARGS__);                        \
-        else if ((TSV) < 0) LTG_D_DISPATCH3(KERNEL, MODE, 32, true, GRID, ST, __VA_ARGS__);                          \
-        else LTG_D_DISPATCH3(KERNEL, MODE, 32, false, GRID, ST, __VA_ARGS__);                                        \
+        if ((TSV) == 128) LTG_D_DISPATCH3(KERNEL, MODE, 128, 3, GRID, ST, __VA_ARGS__);                              \
+        else if ((TSV) == 64) LTG_D_DISPATCH3(KERNEL, MODE, 64, 3, GRID, ST, __VA_ARGS__);                           \
+        else if ((TSV) == -32) LTG_D_DISPATCH3(KERNEL, MODE, 32, 3, GRID, ST, __VA_ARGS__);                          \
+        else if ((TSV) == -33) LTG_D_DISPATCH3(KERNEL, MODE, 32, 1, GRID, ST, __VA_ARGS__);                          \
+        else LTG_D_DISPATCH3(KERNEL, MODE, 32, 0, GRID, ST, __VA_ARGS__);                                            \
     } while (0)
 
 void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
@@ -1919,7 +1923,7 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? -ts : ts, t2 = ts2 < 0 ? -ts2 : ts2;
+    const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? 32 : ts, t2 = ts2 < 0 ? 32 : ts2;
     LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, t1, t1, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                               d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
     LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts2, grid2(h3, n, t2, t2), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
@@ -1986,7 +1990,7 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
-    const int md = d_mode(cfg), ts = d_tile(cfg, 2), tsb = d_tile(cfg, 3), ta = ts < 0 ? -ts : ts, tb = tsb < 0 ? -tsb : tsb;
+    const int md = d_mode(cfg), ts = d_tile(cfg, 2), tsb = d_tile(cfg, 3), ta = ts < 0 ? 32 : ts, tb = tsb < 0 ? 32 : tsb;
     auto tiles = [ta](int x) { return (x + ta - 1) / ta; };
     auto tilesb = [tb](int x) { return (x + tb - 1) / tb; };
     const int nA = tiles(n) * tiles(h12);
