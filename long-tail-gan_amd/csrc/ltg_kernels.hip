@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NT) void k_reparam(int Z, const float* __restrict__
 }
 
 // dec-1 (MultiVAE.py:169): logits[b][i] = h2[b][:] . W_p1t[i][:] + b_p1[i]; the big GEMM.
-template <bool BF16, bool BIG>
+template <bool BF16, bool BIG, bool V = false>
 __global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const float* __restrict__ h2,
                                                  const float* __restrict__ Wp1t, const float* __restrict__ bp1,
                                                  float* __restrict__ logits) {
@@ -220,7 +220,13 @@ __global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const floa
     auto a = [=] __device__(int m, int k) -> float { return h2[(size_t)m * H + k]; };
     auto b = [=] __device__(int k, int n) -> float { return Wp1t[(size_t)n * H + k]; };
     auto epi = [=] __device__(int m, int n, float acc) { logits[(size_t)m * I + n] = acc + bp1[n]; };
-    ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
+    if constexpr (V) {   // 16-B loaders (H % 4 == 0)
+        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(h2 + (size_t)min(m, M - 1) * H, k, H, m < M); };
+        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp1t + (size_t)min(n, I - 1) * H, k, H, n < I); };
+        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false, false, 0, 0, 3>(M, I, m0, n0, 0, H, a4, b4, epi);
+    } else {
+        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
+    }
 }
 
 
@@ -1203,7 +1209,7 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
 }
 
 // dh2 partials: part[z][b][h] = sum_{i in split z} dlog[b][i] * W_p1t[i][h]   (split-K over items)
-template <bool BF16, bool BIG>
+template <bool BF16, bool BIG, bool V = false>
 __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kchunk, const float* __restrict__ dlog,
                                                     const float* __restrict__ Wp1t, float* __restrict__ part) {
     constexpr int BM = BIG ? 128 : 32, BN = BIG ? 64 : 32;
@@ -1213,7 +1219,13 @@ __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kch
     auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)m * I + k]; };
     auto b = [=] __device__(int k, int n) -> float { return Wp1t[(size_t)k * H + n]; };
     auto epi = [=] __device__(int m, int n, float acc) { out[(size_t)m * H + n] = acc; };
-    ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
+    if constexpr (V) {   // 16-B loaders (I % 4 == 0, H % 4 == 0; the K chunks are multiples of 32)
+        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dlog + (size_t)min(m, B - 1) * I, k, kend, m < B); };
+        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp1t + (size_t)min(k, kend - 1) * H, n, H, k < kend); };
+        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, true, false, 0, 0, 3>(B, H, m0, n0, kbeg, kend, a4, b4, epi);
+    } else {
+        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
+    }
 }
 
 // da2 = (sum_z part) * (1 - h2^2)
@@ -1251,7 +1263,7 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
 }
 
 // dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
-template <bool BF16, int VAR>
+template <bool BF16, int VAR, bool V = false>
 __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
                                                       const float* __restrict__ h2, ltg_gen_state st, AdamC ad, int i_begin) {
     // VAR 0: 32x32 tiles, scalar Adam epilogue; 1: 64x128, 2: 64x64, 3: 32x128 tiles with the float4 epilogue
@@ -1293,7 +1305,17 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
                 if (Wb) Wb[(size_t)m * ST_KP + n] = ltg_f2bf(W[(size_t)m * H + n]);
             } else adam_update(bb, mb, vb, m, g, ad);
         };
-        ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+        if constexpr (V) {   // 16-B loaders (I % 4 == 0, H % 4 == 0: the ones column n == H opens its own group)
+            auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dlog + (size_t)min(k, B - 1) * I, m, I, k < B); };
+            auto b4 = [=] __device__(int k, int n) -> float4 {
+                float4 v = ltg_ld4(h2 + (size_t)min(k, B - 1) * H, n, H, k < B);
+                if (n == H && k < B) v.x = 1.f;
+                return v;
+            };
+            ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true, false, 0, 0, 3>(I, H + 1, m0, n0, 0, B, a4, b4, epi);
+        } else {
+            ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
+        }
     }
 }
 
@@ -1844,6 +1866,7 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
             hipLaunchKernelGGL(k_dec1_fwd_stream, dim3(ntiles < 256 ? ntiles : 256), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H,
                                acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits);
         } else if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        else if (bf && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dec1_fwd<true, false, true>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf) hipLaunchKernelGGL((k_dec1_fwd<true, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (big) hipLaunchKernelGGL((k_dec1_fwd<false, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else hipLaunchKernelGGL((k_dec1_fwd<false, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
@@ -2049,6 +2072,7 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     pr.before(LTG_K_DH2);
     if (stream) hipLaunchKernelGGL(k_dh2_stream, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
     else if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else if (bf && (I % 4) == 0 && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dh2_partial<true, false, true>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf) hipLaunchKernelGGL((k_dh2_partial<true, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (big) hipLaunchKernelGGL((k_dh2_partial<false, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else hipLaunchKernelGGL((k_dh2_partial<false, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
@@ -2104,7 +2128,8 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         } else if (!bf) {
             if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
             else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-        } else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        } else if (var == 0 && (I % 4) == 0 && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0, true>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
