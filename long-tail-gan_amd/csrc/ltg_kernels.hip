@@ -1399,6 +1399,7 @@ __global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* _
 // keep * val * row_scale[b] * da1[b][:]; row n_unique = bias gradient sum_b da1[b][:].
 // One workgroup per distinct item: the 4 waves split its entries (a popular item is in dozens of the
 // batch's rows), lanes own float4 column chunks, partials meet in LDS.
+constexpr int ENC0_BIAS_PARTS = 8;  // the bias gradient (column sum of da1 over the batch) is cut into this many partial rows
 __global__ __launch_bounds__(NT) void k_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
                                                   const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
                                                   const int32_t* __restrict__ indices, const float* __restrict__ values,
@@ -1413,7 +1414,10 @@ __global__ __launch_bounds__(NT) void k_enc0_grad(int B, int I, int H, int nu, c
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* d4 = reinterpret_cast<const float4*>(da1);
-    const int q0 = u < nu ? uptr[u] : 0, q1 = u < nu ? uptr[u + 1] : B;
+    // workgroups u < nu: one distinct item each; u >= nu: part (u - nu) of the bias row = batch rows [q0, q1) (one long row
+    // of B entries would be the launch's critical path)
+    const int bp = u - nu, per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+    const int q0 = u < nu ? uptr[u] : min(B, bp * per), q1 = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
     // 4 entries per trip and wave: their (dependent) index chains and da1 row loads overlap
     for (int q = q0 + w; q < q1; q += 4 * (NT / 64)) {
         int b[4];
@@ -1484,6 +1488,13 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int I, int H, int nu, cons
         const int u = i < I ? slot[i] : nu;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (u >= 0) g = G4[(size_t)u * H4 + c];
+        if (i >= I) {   // bias row: the remaining partial rows of k_enc0_grad
+#pragma unroll
+            for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
+                const float4 t = G4[(size_t)(nu + j) * H4 + c];
+                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            }
+        }
 #define LTG_ADAM1(f)                                              \
     mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;                    \
     vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;              \
@@ -1770,7 +1781,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.da2 = take(R * H);
     w.dmlv = take(R * 2 * Z);
     w.da1 = take(R * H);
-    w.gq0 = take((size_t)(gq0_rows(cfg, max_rows) + 1) * H);   // sparse gradient rows of W_q0 (+ bias row)
+    w.gq0 = take((size_t)(gq0_rows(cfg, max_rows) + ENC0_BIAS_PARTS) * H);   // sparse gradient rows of W_q0 (+ partial bias rows)
     w.A1 = take(P * h12);
     w.A3 = take(P * h3);
     w.y = take(P);
@@ -2166,7 +2177,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     const int nu = bt->n_unique;
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_BWD_ADAM);
-    hipLaunchKernelGGL(k_enc0_grad, dim3(nu + 1), dim3(NT), (size_t)4 * H * sizeof(float), s_chain, B, I, H, nu, bt->uptr, bt->rowidx,
+    hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), s_chain, B, I, H, nu, bt->uptr, bt->rowidx,
                        bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
                        acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
     {
