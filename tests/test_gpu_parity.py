@@ -42,7 +42,7 @@ def _upload_batch(eng, X, with_csc=False):
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 1e-3)])
-@pytest.mark.parametrize("I,B", [(1000, 100), (777, 37), (64, 1), (2500, 130), (8200, 100)])
+@pytest.mark.parametrize("I,B", [(1000, 100), (777, 37), (64, 1), (2500, 130), (8200, 100), (8200, 150)])
 def test_forward_parity(precision, tol, I, B):
     import torch
     rng, X, P = _problem(I, B, seed=I + B)
@@ -107,7 +107,7 @@ def _fake_pairs(rng, X, I, per_user=5):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("I,B", [(1000, 100), (333, 17), (8200, 100)])
+@pytest.mark.parametrize("I,B", [(1000, 100), (333, 17), (8200, 100), (8200, 150)])
 def test_g_step_parity(precision, I, B):
     import torch
     from ltgan.engine import Pairs
