@@ -13,6 +13,5 @@ w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=keep); w.writeheader()
 for r in rows: w.writerow({k: r[k] for k in keep})
 PY
   rm -rf $R/gpurun_out/pmc_${name}_SQ
-  python3 $R/profiles/pmc_summary.py_compat "$R/gpurun_out/pmc_${name}_SQ.csv" 2>/dev/null || true
 done
 ls -la $R/gpurun_out/pmc_*_SQ.csv
