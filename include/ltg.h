@@ -57,7 +57,8 @@ typedef struct ltg_config {
     /* kernel tuning knob for A/B measurements, 0 = auto (every setting computes the same function):
      *   bits 0-3   decoder weight-gradient kernel: 1..4 = tile variant 0..3 of the generic kernel, 9 = no streaming kernels
      *   bits 10-12 discriminator tiles: 1 = scalar loaders, 2 = all 64 x 64, 3 = all 128 x 128
-     *   bit 13 / 15 / 16  scalar instead of 16-byte loaders: middle layers / embedding gathers / small-item decoder kernels */
+     *   bit 13 / 15 / 16  scalar instead of 16-byte loaders: middle layers / embedding gathers / small-item decoder kernels
+     *   bit 9  no fake-tower fork onto the aux stream; bit 17  weight-gradient kernels of the G backward on the aux stream */
     int32_t reserved0;
     /* item shard of this rank: it owns global items [item_lo, item_lo + n_items); n_items_global = 0 means
      * unsharded (n_items_global = n_items, item_lo = 0).  W_q0 / W_p1t / b_p1 and their Adam moments hold

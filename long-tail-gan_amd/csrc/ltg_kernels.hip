@@ -2104,13 +2104,14 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
     const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
-    // Small item slabs: the critical path da2 -> dz -> dh1 -> sweep of W_q0 stays on `st`; the three weight-gradient + Adam
-    // kernels only consume it and run on the caller's aux stream, each released by a re-recorded ev_fork after the last
-    // READER of the weights it updates (dz reads W_p0, dh1 reads W_q1) has been enqueued on `st`.
-    // Large item slabs: everything on `st`.  Measured alternatives (I = 200 000): the two HBM sweeps side by side only
-    // contend; the chain of short kernels beside the first sweep does not overlap at all -- the persistent sweep holds
+    // Everything on `st` by default.  Measured alternatives: (a) small item slabs, the three weight-gradient + Adam kernels on
+    // the caller's aux stream beside the critical path da2 -> dz -> dh1 -> sweep of W_q0 (each released by a re-recorded
+    // ev_fork after the last READER of the weights it updates has been enqueued on `st`): paid while the kernels of the chain
+    // took 15-25 us each, costs 3 us per step now that they take 6-18 us (the event pairs cost more than the overlap saves;
+    // still selectable with tuning-knob bit 17); (b) I = 200 000, the two HBM sweeps side by side: they only contend;
+    // (c) I = 200 000, the chain of short kernels beside the first sweep: no overlap at all -- the persistent sweep holds
     // every CU (232 VGPRs x 8 waves + 106 KB LDS per CU), the chain's workgroups are only placed when it drains.
-    const bool have_aux = o->aux_stream && o->ev_fork && o->ev_join && I < 8192;
+    const bool have_aux = o->aux_stream && o->ev_fork && o->ev_join && I < 8192 && (cfg->reserved0 & 131072) != 0;
     const bool small_mode = have_aux;
     hipStream_t aux = (hipStream_t)o->aux_stream;
     hipEvent_t evf = (hipEvent_t)o->ev_fork, evj = (hipEvent_t)o->ev_join;
@@ -2207,7 +2208,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     hipStream_t st = (hipStream_t)stream;
     const Workspace w = carve(cfg, B, nf, (char*)ws);
     // fork: the fake tower (independent of the generator forward) runs on the caller's aux stream
-    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0;
+    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0 && (cfg->reserved0 & 512) == 0;
     if (fork) {
         hipStream_t aux = (hipStream_t)o->aux_stream;
         if (hipEventRecord((hipEvent_t)o->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)o->ev_fork, 0) != hipSuccess)
