@@ -2024,7 +2024,12 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
-    const int md = d_mode(cfg), ts = d_tile(cfg, 2), tsb = d_tile(cfg, 3), ta = ts < 0 ? 32 : ts, tb = tsb < 0 ? 32 : tsb;
+    int ts = d_tile(cfg, 2);
+    {   // backward stage 1 with > 1024 32 x 32 tiles is throughput-bound, not latency-bound: 64 x 64 tiles (measured -5 %)
+        const long t32 = (long)((n + 31) / 32) * ((h12 + 31) / 32) + (long)ks * ((h12 + 32) / 32) * ((h3 + 31) / 32);
+        if (ts == -32 && t32 > 1024 && (cfg->reserved0 & 4096) == 0) ts = 64;
+    }
+    const int md = d_mode(cfg), tsb = d_tile(cfg, 3), ta = ts < 0 ? 32 : ts, tb = tsb < 0 ? 32 : tsb;
     auto tiles = [ta](int x) { return (x + ta - 1) / ta; };
     auto tilesb = [tb](int x) { return (x + tb - 1) / tb; };
     const int nA = tiles(n) * tiles(h12);
