@@ -109,3 +109,40 @@ def test_bf16_round_is_rne():
     assert r[1] == 1.0            # exactly half-way between 1.0 and 1.0078125 -> even (1.0)
     assert r[2] == 1.0078125 and r[3] == -1.0078125
     assert r[4] == 3.140625
+
+
+def test_fp8_e4m3_rounding_model():
+    """OCP e4m3 (bias 7, 3 mantissa bits, max 448, subnormal step 2^-9): known values, idempotence, monotonicity, clamp."""
+    r = O.fp8_e4m3_round
+    known = {0.3: 0.3125, 1.0: 1.0, 17.0: 16.0, 19.0: 20.0, 18.0: 18.0, 447.0: 448.0, 1e6: 448.0, -1e6: -448.0, 2.0 ** -10: 0.0,
+             3 * 2.0 ** -10: 2.0 ** -8, 2.0 ** -9: 2.0 ** -9, 0.0146: 7 * 2.0 ** -9, -0.07: -0.0703125, 464.0: 448.0}
+    for x, want in known.items():
+        assert float(r(np.array([x]))[0]) == want, (x, float(r(np.array([x]))[0]), want)
+    rng = np.random.default_rng(0)
+    x = np.sort(rng.normal(0, 1, 5000) * np.exp2(rng.integers(-12, 9, 5000)))
+    q = r(x)
+    assert np.array_equal(r(q), q)                                  # idempotent
+    assert np.all(np.diff(q) >= 0)                                  # monotone
+    rel = np.abs(q - x)[np.abs(x) > 2.0 ** -6] / np.abs(x)[np.abs(x) > 2.0 ** -6]
+    assert rel[np.abs(x[np.abs(x) > 2.0 ** -6]) < 448].max() <= 2.0 ** -4 + 1e-12   # half an ulp of a 3-bit mantissa
+    assert len(np.unique(np.abs(q))) <= 127                          # 126 positive finite codes + zero
+
+
+def test_discriminator_precision_modes_reduce_to_fp32_on_representable_operands():
+    """With weights / embeddings that are exactly representable after the static scales, only the ACTIVATION and gradient
+    classes are quantised: the first layer's output is identical in all modes; the modes differ afterwards."""
+    rng = np.random.default_rng(5)
+    I, hs = 60, (8, 12, 20, 16)
+    D = O.init_discriminator(I, *hs, seed=2)
+    for k in ("emb", "w1", "w2", "w3"):
+        D[k] = (np.round(np.asarray(D[k], np.float64) * 256 / 16) * 16 / 256).astype(np.float32)    # multiples of 2^-4: exact in bf16 and e4m3 x 2^8
+    pop, nic = rng.integers(0, I, 30), rng.integers(0, I, 30)
+    masks = [np.ones((30, w)) for w in hs[1:]]
+    T = {m: O.d_tower(D, pop, nic, masks, 1.0, dq=m) for m in (None, "bf16", "fp8")}
+    assert np.array_equal(T[None]["tA"], T["bf16"]["tA"]) and np.array_equal(T[None]["tA"], T["fp8"]["tA"])
+    assert not np.array_equal(T[None]["tC"], T["fp8"]["tC"])
+    assert np.abs(T["bf16"]["y"] - T[None]["y"]).max() < 5e-3 and np.abs(T["fp8"]["y"] - T[None]["y"]).max() < 5e-2
+    g = {m: O.d_tower_backward(D, T[m], masks, 1.0, T[m]["y"], dq=m) for m in (None, "bf16", "fp8")}
+    for k in O.D_KEYS:
+        den = np.abs(g[None][k]).max()
+        assert np.abs(g["bf16"][k] - g[None][k]).max() < 2e-2 * den and np.abs(g["fp8"][k] - g[None][k]).max() < 0.3 * den, k
