@@ -107,7 +107,8 @@ typedef struct ltg_batch {
     const int32_t* indptr;  /* [n_rows+1] */
     const int32_t* indices; /* item ids, ascending within a row */
     const float* values;    /* NULL => 1.0f */
-    const int32_t* slot;    /* [n_items] item -> index into uitem / the gradient rows, or -1 */
+    const int32_t* slot;    /* [n_items] item -> index into uitem / the gradient rows, or -1.  May be NULL: the library then builds the
+                             * map of the batch in its workspace each step (no n_batches x n_items cache on the caller's side) */
     const int32_t* uptr;    /* [n_unique+1] offsets into rowidx/csr_pos (relative to 0) */
     const int32_t* rowidx;  /* local row of each transposed entry */
     const int32_t* csr_pos; /* index of that entry in indices[] */

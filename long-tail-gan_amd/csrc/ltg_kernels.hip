@@ -1468,6 +1468,17 @@ __global__ __launch_bounds__(NT) void k_enc0_grad(int B, int I, int H, int nu, c
 // Dense Adam sweep over W_q0 [I][H] (+ bias row I): pure streaming, 16 B per lane, the sparse gradient row
 // (if any) is picked up through slot[i].  TF's Adam touches every row every step (a zero gradient still
 // decays m, v and moves theta), so this sweep is the algorithmic 24 B/parameter.
+// item -> gradient row map of ONE batch, built on the fly when the caller keeps no per-batch slot[] cache (ltg_batch.slot ==
+// NULL): map[] was memset to -1; group u's item id is the column of its first entry
+__global__ __launch_bounds__(NT) void k_fill_i32(int n, int32_t v, int32_t* __restrict__ p) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) p[i] = v;
+}
+__global__ __launch_bounds__(NT) void k_slot_scatter(int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
+                                                     const int32_t* __restrict__ indices, int32_t* __restrict__ map) {
+    const int u = blockIdx.x * NT + threadIdx.x;
+    if (u < nu) map[indices[csr_pos[uptr[u]]]] = u;
+}
+
 __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int I, int H, int nu, const int32_t* __restrict__ slot,
                                                       const float* __restrict__ G, ltg_gen_state st, AdamC ad) {
     const int H4 = H >> 2;  // H % 4 == 0 (checked on the host)
@@ -1749,6 +1760,7 @@ inline size_t gq0_rows(const ltg_config* cfg, int max_rows) {
 struct Workspace {
     // generator backward
     float *rowpart, *segpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
+    int32_t* slotmap;   // [I] item -> gradient row of the current batch (only used when the caller passes no slot[] cache)
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     size_t bytes;
@@ -1782,6 +1794,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.dmlv = take(R * 2 * Z);
     w.da1 = take(R * H);
     w.gq0 = take((size_t)(gq0_rows(cfg, max_rows) + ENC0_BIAS_PARTS) * H);   // sparse gradient rows of W_q0 (+ partial bias rows)
+    w.slotmap = reinterpret_cast<int32_t*>(take(I));
     w.A1 = take(P * h12);
     w.A3 = take(P * h3);
     w.y = take(P);
@@ -2190,7 +2203,13 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
         if (gx > 262144) gx = 262144;
-        hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, I, H, nu, bt->slot, w.gq0, *gen, ad);
+        const int32_t* slot = bt->slot;
+        if (!slot) {   // no per-batch cache (n_batches x I ints at full scale): build the map of this batch in the workspace
+            hipLaunchKernelGGL(k_fill_i32, dim3((I + NT - 1) / NT < 512 ? (I + NT - 1) / NT : 512), dim3(NT), 0, st, I, -1, w.slotmap);
+            if (nu > 0) hipLaunchKernelGGL(k_slot_scatter, dim3((nu + NT - 1) / NT), dim3(NT), 0, st, nu, bt->uptr, bt->csr_pos, bt->indices, w.slotmap);
+            slot = w.slotmap;
+        }
+        hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, I, H, nu, slot, w.gq0, *gen, ad);
     }
     pe.after(LTG_K_ENC0_BWD_ADAM);
     if (small_mode) (void)hipStreamWaitEvent(st, evj, 0);  // join: the caller's stream again orders everything
@@ -2206,7 +2225,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
                size_t ws_bytes, ltg_stream stream) {
     clear_errors();
     if (!cfg_ok(cfg) || !gen || !disc || !bt || !fake || !o || !acts || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
-    if (!bt->slot || !bt->uptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
+    if (!bt->uptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || bt->n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
     if (bt->n_unique < 0 || (size_t)bt->n_unique > gq0_rows(cfg, bt->n_rows)) return LTG_EINVAL;
     const int B = bt->n_rows, nf = fake->n;
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
@@ -2281,7 +2300,7 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                    const ltg_g_opts* o, const ltg_gen_acts* acts, const float* dh2, void* ws, size_t ws_bytes, ltg_stream stream) {
     clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !fake || !o || !dh2 || !ws || o->adam_t < 1) return LTG_EINVAL;
-    if (!bt->slot || !bt->uptr || !bt->rowidx || !bt->csr_pos) return LTG_EINVAL;
+    if (!bt->uptr || !bt->rowidx || !bt->csr_pos) return LTG_EINVAL;
     if (bt->n_unique < 0 || (size_t)bt->n_unique > gq0_rows(cfg, bt->n_rows)) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there

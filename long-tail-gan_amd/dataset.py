@@ -136,10 +136,14 @@ def batch_csc(tr, lo, hi, n_items):
 class DeviceData:
     """IndexData uploaded to HBM + per-batch views (ctypes structs with the right offsets)."""
 
-    def __init__(self, idx: IndexData, batch_size, device, item_lo=0, item_hi=None):
+    def __init__(self, idx: IndexData, batch_size, device, item_lo=0, item_hi=None, slot_cache=None):
         """item_lo/item_hi: this rank's item slab (multi-GPU item sharding).  Only the interaction matrix is
         cut (columns [item_lo, item_hi), re-indexed from 0); pair / candidate / popular lists keep global ids
-        and are identical on every rank."""
+        and are identical on every rank.
+        slot_cache: keep the per-batch item -> gradient-row maps (n_batches x I int32) on the device; None = only for
+        small item slabs (< 8192 items: two launches fewer per step).  Without it the library rebuilds the map of a batch
+        in its workspace each step -- measured FASTER at I = 200 000 (50.3 vs 56.5 ms per 32-step epoch: the one map in
+        the workspace stays in L2, 64 cold 800-KB maps do not) and it removes the n_batches x I memory."""
         self.idx, self.BS, self.device = idx, int(batch_size), torch.device(device)
         N = idx.N
         self.item_lo, self.item_hi = int(item_lo), int(idx.n_items if item_hi is None else item_hi)
@@ -160,16 +164,19 @@ class DeviceData:
         ones = np.all(tr.data == 1.0)
         self.values = None if ones else up(tr.data, np.float32)
         slots, uptrs, rowidx, cpos, ent_off, uptr_off = [], [], [], [], [0], [0]
+        if slot_cache is None:
+            slot_cache = I < 8192
         for b in range(self.n_batches):
             lo, hi = b * self.BS, min(N, (b + 1) * self.BS)
             sl, up_, ri, ps = batch_csc(tr, lo, hi, I)
-            slots.append(sl)
+            if slot_cache:
+                slots.append(sl)
             uptrs.append(up_)
             rowidx.append(ri)
             cpos.append(ps)
             ent_off.append(ent_off[-1] + len(ri))
             uptr_off.append(uptr_off[-1] + len(up_))
-        self.slot = up(np.concatenate(slots))
+        self.slot = up(np.concatenate(slots)) if slot_cache else None
         self.uptr = up(np.concatenate(uptrs))
         self.rowidx = up(np.concatenate(rowidx) if ent_off[-1] else np.zeros(1, np.int32))
         self.csr_pos = up(np.concatenate(cpos) if ent_off[-1] else np.zeros(1, np.int32))

@@ -620,3 +620,31 @@ def test_gemm_block_operand_modes():
                 qa, qb = O.fp8_e4m3_round(A.astype(np.float64) * 16) / 16, O.fp8_e4m3_round(B.astype(np.float64) * 16) / 16
             want = qa @ qb
             assert Hh.rel_err(c.cpu().numpy(), want) < lim, (M, N, K, mode)
+
+
+def test_g_step_without_slot_cache_is_bit_identical():
+    """ltg_batch.slot == NULL: the library builds the item -> gradient-row map of the batch in its workspace; same bits."""
+    import torch
+    from ltgan.engine import CsrRows, Pairs
+    I, B = 1200, 64
+    rng, X, P = _problem(I, B, seed=77)
+    rows, gen, pop = _fake_pairs(rng, X, I)
+    outs = []
+    for with_slot in (True, False):
+        eng = _engine(I, "bf16", lr=1e-3)
+        eng.set_generator(Hh.gen_to_engine(P))
+        dev = eng.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        slot, uptr, rowidx, pos, nu = Hh.csc_view(X)
+        batch = CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, slot=t(slot) if with_slot else None, uptr=t(uptr),
+                        rowidx=t(rowidx), csr_pos=t(pos), n_unique=nu)
+        acts = eng.new_acts(B)
+        fake = Pairs(t(pop), t(gen), t(rows))
+        cnt = torch.tensor([int(((gen >= 0) & (pop >= 0)).sum())], dtype=torch.int32, device=dev)
+        for step in range(3):
+            loss = eng.g_step(batch, fake, acts, cnt, 0.05, rng_step=10 + step, d_rng_step=20 + step).clone()
+        torch.cuda.synchronize()
+        outs.append((loss.cpu(), [p.cpu() for p in eng.g_p], [m.cpu() for m in eng.g_m]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert torch.equal(a, b)
