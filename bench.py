@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- train users/sec at BATCH_SIZE=100 of the Long-Tail-GAN adversarial training path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload askubuntu|ml20m|c4shard]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload askubuntu|ml20m|c4]
+
+N > 1 without a launcher: bench.py starts the N rank processes itself (torch.distributed.run as a child of a parent that never
+touches the GPU) and relays rank 0's JSON line; under `python -m torch.distributed.run --nproc-per-node N` it is a rank.
 
 A "step" is one pass of the hot path over the workload's batch set: phase C (generator forward +
 fake-pair sampling per batch), NUM_SUB_EPOCHS discriminator passes, NUM_SUB_EPOCHS generator passes
@@ -44,6 +47,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event kernel probes (use under rocprofv3 --pmc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the bounded C3 / C4-shaped 1-GPU measurements reported beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -79,9 +83,14 @@ class KernelProfiler:
         self.cabi, self.EventPair = cabi, EventPair
         self.eng, self.tr, self.data, self.a = eng, tr, data, args
         self.samples = []        # (event pair, n_pairs, nnz) recorded in the timed region
+        self.pool = []           # event pairs created BEFORE the timed region (reserve())
+
+    def reserve(self, n):
+        while len(self.pool) < n:
+            self.pool.append(self.EventPair())
 
     def _probe(self, name):
-        ev = self.EventPair()
+        ev = self.pool.pop() if self.pool else self.EventPair()
         p = self.cabi.ltg_probe(self.cabi.KERNEL_IDS[name], 0, ev.start, ev.stop)
         return ev, p
 
@@ -171,7 +180,7 @@ class KernelProfiler:
             if (kind == "d") != (name in self.D_KERNELS):
                 return None
             state["i"] += 1
-            if state["i"] % 8 or len(self.samples) >= 2048:
+            if state["i"] % 8 or not self.pool:
                 return None
             ev, p = self._probe(name)
             sh = self._shapes(b)
@@ -210,6 +219,30 @@ class KernelProfiler:
                 "note": "dominant kernel = largest (avg duration x launches per step) among the probed kernels"}
 
 
+def step_algorithmic_bytes(idx, data, eng, S, active=None):
+    """HBM bytes one step (C + S x D + S x G over the workload's batches) has to move with fp32 master weights,
+    fp32 Adam moments, sparse X / sparse mask, fused Adam and one write + one read of the [B, I] logits:
+      G = 24 P_G + 2 (4 H I) + 4 H min(I, nnz_B) + 8 B I      D = 24 P_D + 8 K h0      C = 4 H I + 4 H min(I, nnz_B) + 4 B I
+    with I = the GLOBAL item count (a sharded job moves the same bytes, spread over its GPUs)."""
+    I, H, Z = eng.I_global, eng.H, eng.Z
+    h0, h1, h2, h3 = eng.h0, eng.h1, eng.h2, eng.h3
+    P_G = (2 * H + 1) * I + H * 2 * Z + Z * H + 2 * H + 2 * Z
+    P_D = h0 * h1 + h1 + h0 * h2 + h2 + (h1 + h2) * h3 + h3 + h3 + 1
+    indptr = idx.train.indptr
+    act = set(range(data.n_batches)) if active is None else set(active)
+    tot = 0.0
+    for b in range(data.n_batches):
+        v = data.view(b)
+        B = v["hi"] - v["lo"]
+        nnz = int(indptr[v["hi"]] - indptr[v["lo"]])
+        K = v["n_real"] + v["n_slots"]
+        tot += 4 * H * I + 4 * H * min(I, nnz) + 4 * B * I
+        if b in act:
+            tot += S * (24 * P_D + 8 * K * h0)
+            tot += S * (24 * P_G + 8 * H * I + 4 * H * min(I, nnz) + 8 * B * I)
+    return tot
+
+
 def copy_ceiling(device, nbytes=1 << 30, reps=5):
     """Device-to-device copy rate of THIS box (read + write bytes / time), the practical HBM ceiling next to the 8 TB/s
     spec the roofline fraction is quoted against: boxes of the pool differ by ~10 % in it, and so do the HBM-bound kernels."""
@@ -230,9 +263,92 @@ def copy_ceiling(device, nbytes=1 << 30, reps=5):
     return {"value": best, "unit": "GB/s", "what": "torch D2D copy of 1 GiB, read + write bytes, best of %d" % reps}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N FRESH rank processes with torch.distributed.run as a
+    CHILD of this process (which has not touched the GPU and never will), relay their output and exit with their code.
+    The reference is a single command without a launcher too (train.py:359-381)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import torch   # device_count() does not initialise the GPU; nothing else of torch.cuda is called in this process
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus and "LTGAN_DIST_BACKEND" not in env:
+        # fewer GPUs than ranks (single-GPU test box): RCCL cannot put two ranks on one device -> gloo, ranks share GPUs
+        env["LTGAN_DIST_BACKEND"] = "gloo"
+        print("bench.py: %d rank(s) on %d visible GPU(s): using the gloo backend (ranks share devices)" % (a.gpus, n_dev), file=sys.stderr, flush=True)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    last_json = None
+    for line in proc.stdout:
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            last_json = line.rstrip()       # rank 0's result line: relayed last, alone
+        else:
+            sys.stdout.write(line)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if rc != 0:
+        print("bench.py: a rank of the %d-rank job failed (exit code %d)" % (a.gpus, rc), file=sys.stderr, flush=True)
+        raise SystemExit(rc)
+    if last_json is None:
+        print("bench.py: the %d-rank job printed no result line" % a.gpus, file=sys.stderr, flush=True)
+        raise SystemExit(1)
+    print(last_json, flush=True)
+    raise SystemExit(0)
+
+
+def other_workloads(a, device, users=6400):
+    """BASELINE configs 3 and 4 (item counts 20 000 / 200 000) on ONE GPU, bounded to 64 batches of 100 users each so the
+    default run stays short: users/s of C + S x D + S x G over those batches, the dominant kernel's HBM fraction (HIP events
+    recorded by the library around that kernel in the timed epochs) and the whole-step fraction."""
+    import torch
+    from ltgan.engine import Engine
+    from ltgan.trainer import Trainer
+    out = {}
+    for key, name in (("c3", "ml20m"), ("c4", "c4")):
+        idx, data, desc = load_workload(name, a.batch_size, device, users)
+        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
+        eng.cfg.reserved0 = a.variant
+        tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
+        tr.epoch()
+        aa = argparse.Namespace(**vars(a))
+        aa.workload = name
+        prof = KernelProfiler(eng, tr, data, aa)
+        kname = "dec1_bwd_adam"
+        if not a.no_probe:
+            prof.reserve(256)
+            tr.probe_hook = prof.hook(kname)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ph = [tr.epoch() for _ in range(2)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        tr.probe_hook = None
+        r = prof.roofline(kname, None) if not a.no_probe else None
+        sb = step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active)
+        nb = max(1, len(tr.active))
+        out[key] = {"workload": name, "users": data.N, "items": data.I, "batches": data.n_batches, "value": data.N / dt, "unit": "users/s",
+                    "ms_per_step": dt * 1e3, "g_step_us": float(np.median([p["t_g"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
+                    "d_step_us": float(np.median([p["t_d"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
+                    "step_frac": sb / dt / PEAK["hbm"],
+                    "dominant_kernel": None if r is None else {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}}
+        del tr, prof, eng, data, idx
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     a.h_sizes = tuple(int(x) for x in a.d_sizes.split(","))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        self_launch(a)                       # never returns
+    if env_world is not None and int(env_world) != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s (run `python bench.py --gpus N` or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (a.gpus, env_world))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -301,6 +417,8 @@ def main():
         calib = prof.calibrate() if rank == 0 else None
         dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
     tr.probe_hook = prof.hook(dominant) if (dominant and rank == 0) else None
+    if tr.probe_hook:
+        prof.reserve(min(2048, a.steps * a.sub_epochs * data.n_batches // 8 + 1))
     barrier()
     t0 = time.perf_counter()
     phases = []
@@ -323,6 +441,7 @@ def main():
         "dtype": a.precision, "data": desc,
         "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
                    "sub_epochs": a.sub_epochs, "batch_size": a.batch_size,
+                   "backend": ("%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "test rig: ranks share GPUs")) if dist.is_initialized() else "none",
                    "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step replicated)" % world)
                    if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
         "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
@@ -332,13 +451,22 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         res["roofline"] = prof.roofline(dominant, calib) if dominant else None
-        if res["roofline"] is not None:
-            res["roofline"]["copy_ceiling_this_box"] = copy_ceiling(device)
+        if res["roofline"] is None:
+            res["roofline"] = {"kernel": None, "note": "kernel probes disabled (--no-probe)"}
+        # whole-step fraction: SURVEY 8/d4 algorithmic bytes of one step / measured step time / (8 TB/s x GPUs)
+        sb = step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active)
+        res["roofline"]["step_algorithmic_bytes"] = sb
+        res["roofline"]["step_frac"] = sb / (dt / a.steps) / (PEAK["hbm"] * (1 if replicas else world))
+        res["roofline"]["copy_ceiling_this_box"] = copy_ceiling(device)
         if calib:
             res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
         if n1_ref:
             res["n1_same_workload"] = {"value": n1_ref, "unit": "users/s", "note": "same workload, unsharded, on rank 0's GPU in this job"}
             res["strong_scaling_vs_1gpu"] = value / n1_ref
+        if world == 1 and workload == "askubuntu" and not a.no_other_workloads:
+            del tr, prof, eng, data
+            torch.cuda.empty_cache()
+            res["other_workloads"] = other_workloads(a, device)
         if not a.no_cpu_baseline and world == 1:
             from oracle.cpu_port import time_cpu_baseline   # oracle/ is only ever the baseline / checker
             res["cpu_baseline"] = time_cpu_baseline(idx, budget_s=a.cpu_seconds, S=a.sub_epochs, batch_size=a.batch_size)

@@ -86,3 +86,12 @@ def test_wrapper_contract_shapes():
     assert vae.q_dims == [1000, 600, 200] and vae.dims == [1000, 600, 200, 600, 1000]
     with pytest.raises(NotImplementedError):
         MultiVAE([200, 600, 1000], lam=0.01)
+
+
+def test_bench_rejects_gpus_launcher_mismatch():
+    """`--gpus N` must agree with the launcher's WORLD_SIZE: a mismatch exits non-zero instead of measuring one GPU and
+    labelling it N (checked before torch is imported, so this runs without a GPU)."""
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
