@@ -1750,12 +1750,9 @@ inline int dh2_kchunk(int I) {
     return chunk;
 }
 
-// upper bound of distinct items in a batch of max_rows rows: min(n_items, max_nnz); the caller states max nnz
-// through ltg_workspace_bytes' max_rows only, so assume the dense worst case capped by the table size.
-inline size_t gq0_rows(const ltg_config* cfg, int max_rows) {
-    const size_t cap = (size_t)max_rows * 2048;   // <= 2048 interactions per user row on average
-    return cap < (size_t)cfg->n_items ? cap : (size_t)cfg->n_items;
-}
+// rows of the sparse W_q0 gradient = distinct items of a batch <= min(n_items, nnz of the batch).  The workspace is sized
+// without knowing nnz, so the table bound is used: one heavy user in a short batch can never overflow it.
+inline size_t gq0_rows(const ltg_config* cfg, int /*max_rows*/) { return (size_t)cfg->n_items; }
 
 struct Workspace {
     // generator backward

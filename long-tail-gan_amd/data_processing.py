@@ -3,8 +3,10 @@ values, restated with array arithmetic (bit-exact integer / float64 outputs; pin
 reference's own module by tests/test_index_path.py and tests/golden/askubuntu_golden.npz).
 
 These run once on the host before training (train.py:56-113); their outputs are uploaded to HBM
-by ltgan.dataset.  The O(I^2) overlap table is a dense float64 matrix here (the reference builds a
-dict of dicts); large-I datasets need the sparse variant (not built yet).
+by ltgan.dataset.  The overlap table is a dense I x I float64 matrix up to SPARSE_OVERLAP_MIN_TAGS tags (the
+reference builds a dict of dicts); above that `load_overlap_coeff` returns the co-occurrence CSR form
+(`SparseOverlap`) and `load_vectors` / `load_items_to_sample` materialise only per-user sub-blocks
+with the dense path's arithmetic -- bit-exact against the dense form (tests/test_index_path.py).
 """
 from __future__ import annotations
 
@@ -85,6 +87,19 @@ def load_item_one_hot_features(item_list_path, SHOW2ID, n_items):
             flen = n_items
     arr = np.array([feat[i] for i in range(len(feat)) if i in feat])
     return feat, flen, arr
+
+
+def load_valid_item_ids(item_list_path, SHOW2ID):
+    """The key set of ITEM_FEATURE_DICT (data_processing.py:54-59) without its O(I^2) one-hot rows: the ids of the
+    item_list.txt lines that appear in SHOW2ID.  It is the only part of load_item_one_hot_features the training path
+    consumes (validity filter of train.py:240-243 and data_processing.py:258-260, Q9)."""
+    ids = set()
+    with open(item_list_path, "r", encoding="utf-8") as f:
+        for line in f:
+            key = line.strip()
+            if key in SHOW2ID:
+                ids.add(int(SHOW2ID[key]))
+    return ids
 
 
 def load_user_items(csv_file_path):
@@ -241,7 +256,7 @@ def load_vectors(user_popular_data, user_niche_data, OVERLAP_COEFFS, ITEM_FEATUR
     oc = None if sp is not None else _matrix(OVERLAP_COEFFS)
     n_ids = sp.n if sp is not None else oc.shape[0]
     valid = np.zeros(n_ids, bool)
-    valid[[k for k in ITEM_FEATURE_DICT if 0 <= k < n_ids]] = True
+    valid[[k for k in ITEM_FEATURE_DICT if 0 <= k < n_ids]] = True      # only the KEYS are used (a dict or a set of ids)
     x_niche, x_pop = {}, {}
     for u in range(N):
         if u not in user_popular_data or u not in user_niche_data:

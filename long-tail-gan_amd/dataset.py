@@ -104,7 +104,8 @@ class IndexData:
         say("Loading Items...")
         show2id, ids_present, niche, _all, _other = dp.load_pop_niche_tags(os.path.join(d, "item2id.txt"), os.path.join(d, "item_list.txt"),
                                                                        os.path.join(d, "niche_items.txt"), n_items)
-        fdict, _flen, _ = dp.load_item_one_hot_features(os.path.join(d, "item_list.txt"), show2id, n_items)
+        # only the key set of ITEM_FEATURE_DICT is live (Q7/Q9): no n_items x n_items one-hot table on the host
+        fdict = dp.load_valid_item_ids(os.path.join(d, "item_list.txt"), show2id)
         say("Loading Training Interaction Matrix...")
         train, uid0 = dp.load_train_data(os.path.join(d, "train_GAN.csv"), n_items)
         upop = dp.load_user_items(os.path.join(d, "train_GAN_popular.csv"))
@@ -115,7 +116,7 @@ class IndexData:
         xn, xp = dp.load_vectors(upop, unic, oc, fdict, N)
         say("Loading Items to Sample....")
         cand = dp.load_items_to_sample(upop, unic, niche, oc, N)
-        return cls(n_items, train, uid0, upop, unic, xn, xp, cand, list(fdict.keys()))
+        return cls(n_items, train, uid0, upop, unic, xn, xp, cand, sorted(fdict))
 
 
 def batch_csc(tr, lo, hi, n_items):

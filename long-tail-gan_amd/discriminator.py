@@ -8,16 +8,22 @@ device tensors (discriminator.py:47).  The item embedding table (discriminator.p
 """
 from __future__ import annotations
 
-from .generator import Fetch, Placeholder
+from .generator import Fetch, Placeholder, current_engine
 
 
 def discriminator(n_items, FEATURE_LEN, h0_size, h1_size, h2_size, h3_size, engine=None):
+    """The reference's six positional arguments (train.py:136, test.py:85).  The discriminator lives in the engine of the
+    preceding generator(...) call (one shared graph, train.py:127-136); when that engine was built for other layer sizes
+    -- generator(pro_dir) only knows ./config.ini -- its discriminator part is re-created with the requested ones."""
     if engine is None:
-        raise ValueError("pass engine=<the Engine created by generator_VAECF> (one shared graph, train.py:127-136)")
-    want = (h0_size, h1_size, h2_size, h3_size)
-    have = (engine.h0, engine.h1, engine.h2, engine.h3)
-    if want != have or engine.feature_len != FEATURE_LEN or engine.I_global != n_items:
-        raise ValueError("engine was built for D sizes %s / feature_len %d / n_items %d" % (have, engine.feature_len, engine.I_global))
+        engine = current_engine()
+    if engine is None:
+        raise ValueError("call generator(pro_dir) first: the discriminator is built into the generator's engine (train.py:130-136)")
+    if engine.I_global != n_items:
+        raise ValueError("the current engine was built for %d items, discriminator() was asked for %d" % (engine.I_global, n_items))
+    want = (int(h0_size), int(h1_size), int(h2_size), int(h3_size))
+    if want != (engine.h0, engine.h1, engine.h2, engine.h3) or engine.feature_len != FEATURE_LEN:
+        engine.resize_discriminator(want, FEATURE_LEN)
     x_generated_id = Placeholder("x_generated")      # discriminator.py:5
     x_popular_n_id = Placeholder("x_popular_n")      # :6
     x_popular_g_id = Placeholder("x_popular_g")      # :7

@@ -36,6 +36,46 @@ def _require_gpu(device):
     return torch.device(device)
 
 
+def init_generator_host(I, H, Z, seed):
+    """Default initialisers of MultiVAE._construct_weights (MultiVAE.py:188-230) in engine layout
+    [W_q0 [I,H], W_q1 [H,2Z], W_p0 [Z,H], W_p1t [I,H], b_q0 [H], b_q1 [2Z], b_p0 [H], b_p1 [I]]: weights
+    tf.contrib.layers.xavier_initializer = uniform(+-sqrt(6 / (fan_in + fan_out))) (:199-202, :219-221), biases
+    tf.truncated_normal_initializer(stddev=0.001) = N(0, 0.001) re-drawn beyond 2 sigma (:204-207, :223-225).  The
+    random STREAM is torch's (TF's cannot be reproduced without TF); the distributions are the reference's."""
+    g = torch.Generator().manual_seed(seed)
+
+    def xavier(fi, fo, shape):
+        lim = math.sqrt(6.0 / (fi + fo))
+        return (torch.rand(shape, generator=g) * 2 - 1) * lim
+
+    def tn(shape, std):
+        t = torch.empty(shape)
+        torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=g)
+        return t
+
+    host = [xavier(I, H, (I, H)), xavier(H, 2 * Z, (H, 2 * Z)), xavier(Z, H, (Z, H)),
+            xavier(H, I, (I, H)),                                # W_p1 [H, I] stored item-major [I][H]
+            tn((H,), 1e-3), tn((2 * Z,), 1e-3), tn((H,), 1e-3), tn((I,), 1e-3)]
+    return [t.numpy() for t in host]
+
+
+def init_discriminator_host(feature_len, h_sizes, seed):
+    """Default initialisers of discriminator.py:14-41: every matrix tf.truncated_normal(stddev=0.1) (the frozen embedding
+    :14, w1 :23, w2 :28, w3 :36, w4 :40), every bias tf.zeros (:24, :29, :37, :41).
+    -> (emb [F,h0], [w1 [h0,h1], b1, w2 [h0,h2], b2, w3 [h1+h2,h3], b3, w4 [h3], b4 [1]])."""
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(shape):
+        t = torch.empty(shape)
+        torch.nn.init.trunc_normal_(t, 0.0, 0.1, -0.2, 0.2, generator=g)
+        return t
+
+    h0, h1, h2, h3 = h_sizes
+    emb = tn((feature_len, h0))
+    host = [tn((h0, h1)), torch.zeros(h1), tn((h0, h2)), torch.zeros(h2), tn((h1 + h2, h3)), torch.zeros(h3), tn((h3,)), torch.zeros(1)]
+    return emb.numpy(), [t.numpy() for t in host]
+
+
 class Acts:
     """Caller-owned activations of one generator forward (ltg_gen_acts)."""
 
@@ -110,22 +150,7 @@ class Engine:
 
     # ------------------------------------------------------------------ parameters
     def _init_generator(self, seed):
-        g = torch.Generator().manual_seed(seed)
-        I, H, Z = self.I_global, self.H, self.Z
-
-        def xavier(fi, fo, shape):                                   # MultiVAE.py:199-202
-            lim = math.sqrt(6.0 / (fi + fo))
-            return (torch.rand(shape, generator=g) * 2 - 1) * lim
-
-        def tn(shape, std):                                          # MultiVAE.py:204-207
-            t = torch.empty(shape)
-            torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=g)
-            return t
-
-        host = [xavier(I, H, (I, H)), xavier(H, 2 * Z, (H, 2 * Z)), xavier(Z, H, (Z, H)),
-                xavier(H, I, (I, H)),                                # W_p1 stored item-major [I][H]
-                tn((H,), 1e-3), tn((2 * Z,), 1e-3), tn((H,), 1e-3), tn((I,), 1e-3)]
-        self.set_generator([t.numpy() for t in host])     # global tables: set_generator keeps this rank's slab
+        self.set_generator(init_generator_host(self.I_global, self.H, self.Z, seed))     # global tables: set_generator keeps this rank's slab
 
     def set_generator(self, arrays, m=None, v=None):
         """arrays in engine layout: [W_q0 [I,H], W_q1 [H,2Z], W_p0 [Z,H], W_p1t [I,H], b_q0, b_q1, b_p0, b_p1] with
@@ -157,18 +182,23 @@ class Engine:
             cabi.check(self.lib.ltg_refresh_shadow(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_refresh_shadow")
 
     def _init_discriminator(self, seed):
-        g = torch.Generator().manual_seed(seed)
+        emb, host = init_discriminator_host(self.feature_len, (self.h0, self.h1, self.h2, self.h3), seed)
+        self.set_discriminator(emb, host)
 
-        def tn(shape):                                               # discriminator.py:14,23,28,36,40
-            t = torch.empty(shape)
-            torch.nn.init.trunc_normal_(t, 0.0, 0.1, -0.2, 0.2, generator=g)
-            return t
+    def resize_discriminator(self, h_sizes, feature_len=None, d_seed=0):
+        """Re-create the discriminator part for other layer sizes (discriminator.py:3: the sizes are arguments of the
+        factory, not of the generator): fresh truncated-normal variables, zero Adam moments, new workspace."""
+        self.h0, self.h1, self.h2, self.h3 = (int(x) for x in h_sizes)
+        if feature_len is not None:
+            self.feature_len = int(feature_len)
+        self.cfg.d_feat, self.cfg.d_h0, self.cfg.d_h1, self.cfg.d_h2, self.cfg.d_h3 = self.feature_len, self.h0, self.h1, self.h2, self.h3
+        self._init_discriminator(d_seed)
+        self._ws, self._ws_key = None, (0, 0)
 
-        h0, h1, h2, h3 = self.h0, self.h1, self.h2, self.h3
-        emb = tn((self.feature_len, h0))
-        host = [tn((h0, h1)), torch.zeros(h1), tn((h0, h2)), torch.zeros(h2), tn((h1 + h2, h3)), torch.zeros(h3),
-                tn((h3,)), torch.zeros(1)]
-        self.set_discriminator(emb.numpy(), [t.numpy() for t in host])
+    def set_learning_rate(self, lr):
+        """tf.train.AdamOptimizer(LEARNING_RATE) (train.py:160): one optimiser, one rate for the D and the G update."""
+        self.lr = float(lr)
+        self.cfg.lr = self.lr
 
     def set_discriminator(self, emb, arrays, m=None, v=None):
         dev = self.device

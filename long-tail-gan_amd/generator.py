@@ -57,15 +57,58 @@ class MultiVAE:
         return Fetch("generator_out"), Fetch("g_vae_loss"), self.engine.generator_params_tf()
 
 
+# The reference builds generator and discriminator into ONE TensorFlow default graph (train.py:127-136): the two factory calls
+# share state without passing anything to each other.  The counterpart here is a process-wide "current engine".
+_CURRENT = {"engine": None}
+
+
+def current_engine():
+    """The Engine of the last generator(...) call (None before the first / after reset_default_graph())."""
+    return _CURRENT["engine"]
+
+
+def reset_default_graph():
+    """tf.reset_default_graph() (train.py:127): forget the current engine."""
+    _CURRENT["engine"] = None
+
+
+def _config_ini_defaults(path="config.ini"):
+    """Discriminator sizes and learning rate of ./config.ini (train.py:359-377 reads it from the CWD) when the file exists;
+    the reference's literal call `generator(pro_dir)` carries neither, they reach the graph through train_GAN's arguments."""
+    import configparser
+    import os
+    cp = configparser.RawConfigParser()
+    if not os.path.isfile(path) or not cp.read(path) or not cp.has_section("Long-Tail-GAN"):
+        return {}
+    out = {}
+    try:
+        out["h_sizes"] = tuple(int(cp.get("Long-Tail-GAN", k)) for k in ("h0_size", "h1_size", "h2_size", "h3_size"))
+    except (configparser.NoOptionError, ValueError):
+        pass
+    try:
+        out["lr"] = float(cp.get("Long-Tail-GAN", "LEARNING_RATE"))
+    except (configparser.NoOptionError, ValueError):
+        pass
+    return out
+
+
 def generator_VAECF(pro_dir, engine=None, **engine_kwargs):
-    """Codes/generator.py:4-22.  `engine` lets the caller share one Engine between the generator and
-    the discriminator factories (the reference shares one TF default graph)."""
+    """Codes/generator.py:4-22 -- works with the reference's literal call `generator(pro_dir)` (train.py:130, test.py:79):
+    discriminator sizes / learning rate default to ./config.ini when present (else config.ini's shipped defaults) and the
+    engine becomes the process-wide current one that `discriminator(n_items, FEATURE_LEN, h0, h1, h2, h3)` finds.
+    `engine` / keyword arguments override (item slab of a rank, precision, device ...)."""
     n_items = count_items(pro_dir)
     p_dims = [200, 600, n_items]          # VAECF recommended values (generator.py:13)
     total_anneal_steps = 20000            # generator.py:15
     anneal_cap = 0.2                      # generator.py:16
     if engine is None:
-        engine = Engine(n_items, p_dims=p_dims, seed=98765, **engine_kwargs)
+        import os
+        kw = _config_ini_defaults()
+        if os.environ.get("LTGAN_PRECISION"):          # decoder GEMM operands: "bf16" (default) or "fp32"
+            kw["precision"] = os.environ["LTGAN_PRECISION"]
+        kw.update(engine_kwargs)
+        engine = Engine(n_items, p_dims=p_dims, seed=98765, **kw)
+    _CURRENT["engine"] = engine
     vae = MultiVAE(p_dims, lam=0.0, random_seed=98765, engine=engine)
     probs_var, loss_var, params = vae.build_graph()
     return vae, probs_var, loss_var, params, p_dims, total_anneal_steps, anneal_cap

@@ -41,7 +41,10 @@ class AdversarialGraph:
         self.g_trainer = Fetch("g_trainer")                          # train.py:163
 
 
-def adversarial_graph(vae, generator_out, g_vae_loss, disc):
+def adversarial_graph(vae, generator_out, g_vae_loss, disc, learning_rate=None):
+    """learning_rate: train.py:160 `tf.train.AdamOptimizer(LEARNING_RATE)` lives in the block this call replaces."""
+    if learning_rate is not None:
+        vae.engine.set_learning_rate(learning_rate)
     return AdversarialGraph(vae, generator_out, g_vae_loss, disc)
 
 

@@ -17,13 +17,16 @@ import torch
 import torch.distributed as dist
 
 from .engine import _ptr
-from .trainer import Trainer
+from .trainer import Trainer, eval_chunk_rows
 
 
 def item_slab(n_items, rank, world):
     """contiguous slab boundaries, multiples of 64 items except the last"""
     per = -(-n_items // world)
     per = -(-per // 64) * 64
+    if (world - 1) * per >= n_items:
+        raise ValueError("%d items cannot be cut into %d slabs of 64-item multiples (the last rank would own nothing): "
+                         "use at most %d ranks" % (n_items, world, -(-n_items // 64)))
     lo = min(n_items, rank * per)
     return lo, min(n_items, lo + per)
 
@@ -119,7 +122,7 @@ class ShardedEvaluator:
 
     def __init__(self, engine, ev, group=None, chunk=20000):
         self.eng, self.ev, self.group = engine, ev, group
-        self.chunk = int(min(chunk, max(1, ev.n)))
+        self.chunk = int(min(chunk, max(1, ev.n), eval_chunk_rows(engine.I)))
         self.acts = engine.new_acts(self.chunk)
         dev = engine.device
         n_te = max(1, int(ev.te_indices.numel()))

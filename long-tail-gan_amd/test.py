@@ -38,6 +38,10 @@ class _Counters:
     update_count = 0.0
     rng_step = 0
 
+    def __init__(self):
+        import numpy as np
+        self.np_rng = np.random.RandomState(0)
+
 
 def test_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BATCH_SIZE, DISPLAY_ITER, LEARNING_RATE, to_restore,
              model_name, dataset, GANLAMBDA, output_path, precision="bf16", device=None, batch_size_test=20000):
@@ -61,7 +65,7 @@ def test_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BATC
     gen_net, *_ = generator(DATA_DIR, h_sizes=(h0_size, h1_size, h2_size, h3_size), lr=LEARNING_RATE, precision=precision,
                             device=device, item_lo=lo, item_hi=hi)
     eng = gen_net.engine
-    discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size, engine=eng)
+    discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size)   # the reference's six arguments (train.py:136)
     load_checkpoint(output_path, eng, _Counters())
     print("Model Loaded")
     if world > 1:

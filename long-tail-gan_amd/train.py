@@ -62,21 +62,38 @@ def _full(ts, eng, world):
     return out
 
 
+CKPT_FORMAT = 2      # 2: every tensor in the reference variable's TF shape (weight_p_1to2 = [600, n_items]); shuffle RNG state saved
+
+
 def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
+    """All variables + Adam slots under the reference's variable names in their TF shapes (MultiVAE.py:196-197,216-217:
+    weight_p_1to2 is [600, n_items]; the engine keeps it item-major and transposes here), the shared Adam step, the anneal
+    counter, the device RNG counter and the state of the batch-shuffle RNG (train.py:285), so that a resumed run continues
+    exactly like an uninterrupted one.  Written to a temporary file and renamed into place: a kill mid-write never leaves
+    a truncated model_<i>.pt for `to_restore` to pick up."""
     import torch
-    st = {"epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step, "d_w1": eng.d_emb.cpu()}
+    st = {"format": CKPT_FORMAT, "epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step,
+          "shuffle_rng_state": tr.np_rng.get_state(), "d_w1": eng.d_emb.cpu()}
     gp, gm, gv = _full(eng.g_p, eng, world), _full(eng.g_m, eng, world), _full(eng.g_v, eng, world)     # collective: every rank
     for i, n in enumerate(G_NAMES):
-        st[n], st[n + "/Adam"], st[n + "/Adam_1"] = gp[i], gm[i], gv[i]
+        tf = (lambda t: t.t().contiguous()) if i == 3 else (lambda t: t)
+        st[n], st[n + "/Adam"], st[n + "/Adam_1"] = tf(gp[i]), tf(gm[i]), tf(gv[i])
     for i, n in enumerate(D_NAMES):
         st[n], st[n + "/Adam"], st[n + "/Adam_1"] = eng.d_p[i].cpu(), eng.d_m[i].cpu(), eng.d_v[i].cpu()
     if rank == 0:
-        torch.save(st, path)
+        tmp = path + ".tmp.%d" % os.getpid()
+        torch.save(st, tmp)
+        os.replace(tmp, path)
 
 
 def load_checkpoint(path, eng, tr):
     import torch
-    st = torch.load(path, map_location="cpu")
+    st = torch.load(path, map_location="cpu", weights_only=False)
+    if st.get("format", 1) >= 2:                     # TF shape [H, I] -> the engine's item-major [I, H]
+        for k in ("weight_p_1to2", "weight_p_1to2/Adam", "weight_p_1to2/Adam_1"):
+            st[k] = st[k].t().contiguous()
+    if "shuffle_rng_state" in st:
+        tr.np_rng.set_state(st["shuffle_rng_state"])
     eng.set_generator([st[n].numpy() for n in G_NAMES], [st[n + "/Adam"].numpy() for n in G_NAMES],
                       [st[n + "/Adam_1"].numpy() for n in G_NAMES])
     eng.set_discriminator(st["d_w1"].numpy(), [st[n].numpy() for n in D_NAMES], [st[n + "/Adam"].numpy() for n in D_NAMES],
@@ -112,7 +129,7 @@ def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BAT
         DATA_DIR, h_sizes=(h0_size, h1_size, h2_size, h3_size), lr=LEARNING_RATE, precision=precision, device=device,
         item_lo=lo, item_hi=hi)
     eng = gen_net.engine
-    discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size, engine=eng)
+    discriminator(n_items, n_items, h0_size, h1_size, h2_size, h3_size)   # the reference's six arguments (train.py:136)
     data = DeviceData(idx, BATCH_SIZE, eng.device, item_lo=lo, item_hi=hi)
     kw = dict(num_sub_epochs=NUM_SUB_EPOCHS, gan_lambda=GANLAMBDA, total_anneal_steps=total_anneal_steps, anneal_cap=anneal_cap)
     if world > 1:

@@ -110,13 +110,22 @@ class Trainer:
         return dict(user_err_cnt=err, t_create=t1 - t0, t_d=t2 - t1, t_g=t3 - t2, t_total=t3 - t0)
 
 
+EVAL_LOGITS_BYTES = 2 << 30
+
+
+def eval_chunk_rows(n_items_local, budget=EVAL_LOGITS_BYTES):
+    """users per scoring chunk so that the [chunk, I] fp32 logits stay within `budget` bytes (test.py:76 scores 20 000
+    users at a time: 16 GB at I = 200 000)."""
+    return max(1, int(budget // (4 * max(1, n_items_local))))
+
+
 class Evaluator:
     """Validation / test scoring (train.py:333-348, test.py:138-173): forward with dropout ON (Q3),
     fold-in items masked to -inf, NDCG@100 / Recall@20 / Recall@50, in chunks of `chunk` users
-    (test.py:76 uses 20000)."""
+    (test.py:76 uses 20000), capped so that a chunk's logits stay within EVAL_LOGITS_BYTES."""
 
     def __init__(self, engine: Engine, ev: EvalData, chunk=20000):
-        self.eng, self.ev, self.chunk = engine, ev, int(min(chunk, max(1, ev.n)))
+        self.eng, self.ev, self.chunk = engine, ev, int(min(chunk, max(1, ev.n), eval_chunk_rows(engine.I)))
         self.acts = engine.new_acts(self.chunk)
         self.out = torch.zeros(ev.n, 4, dtype=torch.float32, device=engine.device)
 

@@ -95,3 +95,41 @@ def test_bench_rejects_gpus_launcher_mismatch():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_default_initialisers_match_the_reference_distributions():
+    """a3: MultiVAE.py:199-207,219-225 (Xavier-uniform weights, truncated-normal sigma = 1e-3 biases) and
+    discriminator.py:14-41 (truncated-normal sigma = 0.1 matrices, zero biases): shapes, hard bounds and moments."""
+    import numpy as np
+    from ltgan.engine import init_discriminator_host, init_generator_host
+    I, H, Z = 1000, 600, 200
+    g = init_generator_host(I, H, Z, seed=98765)
+    assert [a.shape for a in g] == [(I, H), (H, 2 * Z), (Z, H), (I, H), (H,), (2 * Z,), (H,), (I,)]
+    for a, (fi, fo) in zip(g[:4], [(I, H), (H, 2 * Z), (Z, H), (H, I)]):
+        lim = np.sqrt(6.0 / (fi + fo))
+        assert np.abs(a).max() <= lim and np.abs(a).max() > 0.98 * lim                       # uniform on [-lim, lim]
+        assert abs(a.mean()) < 0.02 * lim and abs(a.std() - lim / np.sqrt(3.0)) < 0.01 * lim   # std of U(-l, l) = l / sqrt(3)
+    for b in g[4:]:
+        assert np.abs(b).max() <= 2e-3 and abs(b.mean()) < 3e-4 and abs(b.std() - 0.88e-3) < 1.5e-4   # N(0, s) cut at 2 s: std 0.88 s
+    emb, d = init_discriminator_host(1000, (100, 150, 250, 300), seed=0)
+    assert emb.shape == (1000, 100) and [a.shape for a in d] == [(100, 150), (150,), (100, 250), (250,), (400, 300), (300,), (300,), (1,)]
+    for a in [emb, d[0], d[2], d[4], d[6]]:
+        assert np.abs(a).max() <= 0.2 and abs(a.std() - 0.088) < (0.02 if a.size < 1000 else 0.004) and abs(a.mean()) < 0.02
+    for b in (d[1], d[3], d[5], d[7]):
+        assert not b.any()
+    g2 = init_generator_host(I, H, Z, seed=98765)
+    assert all(np.array_equal(x, y) for x, y in zip(g, g2))                                  # seeded: reproducible
+
+
+def test_factory_registry_and_config_ini_defaults(tmp_path, monkeypatch):
+    """b2 without a device: discriminator() before generator() fails with a clear error; ./config.ini supplies the
+    discriminator sizes and the learning rate of a bare generator(pro_dir) call."""
+    from ltgan import generator as G
+    from ltgan.discriminator import discriminator
+    G.reset_default_graph()
+    with pytest.raises(ValueError, match="generator"):
+        discriminator(1000, 1000, 100, 150, 250, 300)
+    monkeypatch.chdir(tmp_path)
+    assert G._config_ini_defaults() == {}
+    (tmp_path / "config.ini").write_text("[Long-Tail-GAN]\nh0_size = 64\nh1_size = 96\nh2_size = 160\nh3_size = 128\nLEARNING_RATE = 0.0003\n")
+    assert G._config_ini_defaults() == {"h_sizes": (64, 96, 160, 128), "lr": 0.0003}

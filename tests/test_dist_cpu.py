@@ -1,5 +1,6 @@
 """N>1 path on CPU: world_size-2 gloo run of the item-sharded exchange steps (tests/dist_cpu_worker.py),
 plus the host-side sharding of the data."""
+import pytest
 import os
 import subprocess
 import sys
@@ -58,3 +59,17 @@ def test_item_slabs_partition_and_shard_data():
 def torch_equal(a, b):
     import torch
     return torch.equal(a, b)
+
+
+def test_item_slab_rejects_empty_slabs_and_covers_the_items():
+    from ltgan.sharded import item_slab
+    for n, w in ((1000, 2), (1000, 8), (200000, 8), (100032, 2), (1000, 16)):
+        cuts = [item_slab(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(hi > lo for lo, hi in cuts)
+    with pytest.raises(ValueError, match="slabs"):
+        item_slab(1000, 0, 17)          # ceil(1000/17) -> 64-item multiples leave the last rank with nothing
+
+
+def test_eval_chunk_is_bounded_by_the_logits_budget():
+    from ltgan.trainer import eval_chunk_rows
+    assert eval_chunk_rows(1000) >= 20000 and eval_chunk_rows(200000) == (2 << 30) // (4 * 200000) and eval_chunk_rows(10 ** 10) == 1

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_reference_loop_over_session(tmp_path):
+def test_reference_loop_over_session(tmp_path, monkeypatch):
     import torch
     from ltgan.data_processing import (load_train_data, load_tr_te_data, load_user_items, load_overlap_coeff, load_pop_niche_tags,
                                        load_items_to_sample, load_vectors)
@@ -40,15 +40,18 @@ def test_reference_loop_over_session(tmp_path):
     N = train_data.shape[0]
     user_x_niche_vectors, user_x_popular_n_vectors = load_vectors(user_popular_data, user_niche_data, OVERLAP_COEFFS, ITEM_FEATURE_DICT, N)
     USER_TAGS_TO_SAMPLE = load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP_COEFFS, N)
-    h = (100, 150, 250, 300)
+    h = h0_size, h1_size, h2_size, h3_size = (100, 150, 250, 300)
+    LEARNING_RATE = 1e-4
     BATCH_SIZE, NB = 100, 3
 
-    # --- graph (train.py:127-164)
-    generator_network, generator_out, g_vae_loss, g_params, p_dims, total_anneal_steps, anneal_cap = generator(
-        pro_dir, h_sizes=h, lr=1e-4, feature_len=FEATURE_LEN, precision="fp32")
-    disc = discriminator(n_items, FEATURE_LEN, *h, engine=generator_network.engine)
+    # --- graph (train.py:127-164): the reference's LITERAL argument lists -- `generator(pro_dir)` (train.py:130) and the six
+    # positional arguments of `discriminator(...)` (train.py:136); precision is the only thing set from outside the call
+    monkeypatch.setenv("LTGAN_PRECISION", "fp32")
+    monkeypatch.chdir(tmp_path)              # no config.ini here: the shipped defaults apply
+    generator_network, generator_out, g_vae_loss, g_params, p_dims, total_anneal_steps, anneal_cap = generator(pro_dir)
+    disc = discriminator(n_items, FEATURE_LEN, h0_size, h1_size, h2_size, h3_size)
     y_data, y_generated, d_params, x_generated_id, x_popular_n_id, x_popular_g_id, x_niche_id, item_feature_arr, keep_prob = disc
-    G = adversarial_graph(generator_network, generator_out, g_vae_loss, disc)
+    G = adversarial_graph(generator_network, generator_out, g_vae_loss, disc, learning_rate=LEARNING_RATE)
     generated_tags, sampled_cnt, gen_lambda = G.generated_tags, G.sampled_cnt, G.gen_lambda
     sess = Session(generator_network.engine)
     assert [tuple(p.shape) for p in g_params] == [(n_items, 600), (600, 400), (200, 600), (600, n_items), (600,), (400,), (600,), (n_items,)]
@@ -141,3 +144,42 @@ def test_reference_loop_over_session(tmp_path):
 
     with pytest.raises(NotImplementedError):
         sess.run([y_data], feed_dict={})
+
+
+def test_factories_with_reference_argument_lists_and_non_default_config(tmp_path, monkeypatch):
+    """train.py:130,136 / test.py:79,85: `generator(pro_dir)` + `discriminator(n_items, FEATURE_LEN, h0, h1, h2, h3)` with
+    nothing else passed.  A non-default ./config.ini is picked up by generator(); sizes that differ from it re-create the
+    discriminator part; a D step then runs with those sizes."""
+    import torch
+    from ltgan.dataset import materialize_askubuntu
+    from ltgan.discriminator import discriminator
+    from ltgan.engine import Pairs
+    from ltgan.generator import current_engine, generator, reset_default_graph
+
+    pro_dir = str(tmp_path / "Askubuntu_Sample") + "/"
+    materialize_askubuntu(os.path.join(ROOT, "tests", "golden", "askubuntu_raw.npz"), pro_dir)
+    (tmp_path / "config.ini").write_text("[Long-Tail-GAN]\nh0_size = 64\nh1_size = 96\nh2_size = 160\nh3_size = 128\nNUM_EPOCH = 8\n"
+                                         "BATCH_SIZE = 100\nDISPLAY_ITER = 10\nLEARNING_RATE = 0.0003\nto_restore = 0\nmodel_name = LTG\nGANLAMBDA = 1.0\n")
+    monkeypatch.chdir(tmp_path)
+    reset_default_graph()
+    with pytest.raises(ValueError):
+        discriminator(1000, 1000, 64, 96, 160, 128)          # no graph yet
+    net, probs, loss, g_params, p_dims, tas, cap = generator(pro_dir)
+    eng = current_engine()
+    assert eng is net.engine and (eng.h0, eng.h1, eng.h2, eng.h3) == (64, 96, 160, 128) and abs(eng.cfg.lr - 3e-4) < 1e-9
+    assert p_dims == [200, 600, 1000] and tas == 20000 and cap == 0.2
+    out = discriminator(1000, 1000, 64, 96, 160, 128)        # same sizes: the engine's discriminator is used as is
+    assert len(out) == 9 and [tuple(p.shape) for p in out[2]] == [(64, 96), (96,), (64, 160), (160,), (256, 128), (128,), (128, 1), (1,)]
+    w_before = eng.d_p[0].clone()
+    out = discriminator(1000, 1000, 32, 48, 80, 64)          # other sizes: re-created
+    assert (eng.h0, eng.h1, eng.h2, eng.h3) == (32, 48, 80, 64) and eng.cfg.d_h3 == 64 and tuple(eng.d_emb.shape) == (1000, 32)
+    assert [tuple(p.shape) for p in out[2]] == [(32, 48), (48,), (32, 80), (80,), (128, 64), (64,), (64, 1), (1,)]
+    assert tuple(w_before.shape) == (64, 96)
+    rng = np.random.default_rng(0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(eng.device)
+    real = Pairs(t(rng.integers(0, 1000, 300)), t(rng.integers(0, 1000, 300)))
+    fake = Pairs(t(rng.integers(0, 1000, 280)), t(rng.integers(0, 1000, 280)))
+    l = float(eng.d_step(real, fake, 0.7, rng_step=1)[0].item())
+    assert np.isfinite(l) and abs(l - 580 * np.log(2.0)) < 0.25 * 580 * np.log(2.0)      # y ~ 0.5 at initialisation
+    with pytest.raises(ValueError):
+        discriminator(999, 1000, 32, 48, 80, 64)             # another item count than the generator's

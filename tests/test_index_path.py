@@ -131,3 +131,16 @@ def test_sparse_overlap_form_is_bit_exact(ds, loaded, gold):
     ptr, idx = _ragged(cand, keys)
     assert np.array_equal(np.array(keys), gold["cand_users"])
     assert np.array_equal(ptr, gold["cand_ptr"]) and np.array_equal(idx, gold["cand_idx"])
+
+
+def test_valid_item_ids_equal_the_one_hot_dict_keys(tmp_path):
+    """IndexData.from_dir no longer builds the I x I one-hot table: load_valid_item_ids must give exactly the key set of
+    load_item_one_hot_features (data_processing.py:54-59), 997 ids with 418 / 447 / 595 missing (Q9)."""
+    from ltgan import data_processing as dp
+    from ltgan.dataset import materialize_askubuntu
+    d = str(tmp_path / "ds")
+    materialize_askubuntu(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "askubuntu_raw.npz"), d)
+    show2id, *_ = dp.load_pop_niche_tags(os.path.join(d, "item2id.txt"), os.path.join(d, "item_list.txt"), os.path.join(d, "niche_items.txt"), 1000)
+    fdict, flen, _ = dp.load_item_one_hot_features(os.path.join(d, "item_list.txt"), show2id, 1000)
+    ids = dp.load_valid_item_ids(os.path.join(d, "item_list.txt"), show2id)
+    assert ids == set(fdict.keys()) and len(ids) == 997 and not ({418, 447, 595} & ids) and flen == 1000
