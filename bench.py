@@ -74,8 +74,9 @@ class KernelProfiler:
     (ltg_probe) and prices them against the roofline with ALGORITHMIC flops / bytes."""
 
     D_KERNELS = ["d_l1", "d_l2", "d_bwd1", "d_bwd2", "d_adam"]
-    G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "wgrad_p0", "dh1", "wgrad_q1",
-                 "enc0_bwd_adam"]
+    # (a kernel that the active code path does not launch records no events and is skipped)
+    G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "row_dlogits", "dh2", "dec1_bwd_adam", "dz", "wgrad_p0", "dh1", "wgrad_q1",
+                 "enc0_grad", "enc0_bwd_adam", "g_tail"]
 
     def __init__(self, eng, tr, data, args):
         from ltgan import _cabi as cabi
@@ -134,6 +135,11 @@ class KernelProfiler:
             "dh1": (2 * B * 2 * Z * H, 4 * (B * 2 * Z + H * 2 * Z + 2 * B * H)),
             "wgrad_q1": (2 * B * (H + 1) * 2 * Z, 24 * (H + 1) * 2 * Z + 4 * (B * H + B * 2 * Z)),
             "enc0_bwd_adam": (2 * sh["nnz"] * H, 24 * (I + 1) * H + 4 * B * H),
+            "row_dlogits": (0, 8 * B * I),
+            "enc0_grad": (2 * sh["nnz"] * H, 4 * (sh["nnz"] * H + min(I, sh["nnz"]) * H)),
+            # one launch = every Adam update of the generator: 24 B per parameter + the operands of the three gradient products
+            "g_tail": (2 * B * ((I if I <= 4096 else 0) * (H + 1) + (Z + 1) * H + (H + 1) * 2 * Z),
+                       24 * (((2 * H + 1) * I if I <= 4096 else (H + 1) * I) + H * 2 * Z + Z * H + 2 * H + 2 * Z) + 4 * B * (I + 3 * H + 3 * Z)),
         }
         return w[name]
 
@@ -165,7 +171,9 @@ class KernelProfiler:
                 evs.append((ev, sh, p))
             torch.cuda.synchronize()
             ms = [e.elapsed_ms() for e, _, _ in evs]
-            ms = [m for m in ms if m is not None]
+            ms = [m for m in ms if m is not None and m > 0]
+            if not ms:
+                continue
             fl = np.mean([self.work(name, sh)[0] for _, sh, _ in evs])
             by = np.mean([self.work(name, sh)[1] for _, sh, _ in evs])
             launches = S * nb * (2 if name in ("d_l1", "d_l2") else 1) + (nb if name in ("enc0_fwd", "enc1", "dec0", "dec1_fwd") else 0)

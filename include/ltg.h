@@ -146,7 +146,10 @@ typedef struct ltg_gen_acts {
 #define LTG_K_DH1 14
 #define LTG_K_WGRAD_P0 15
 #define LTG_K_WGRAD_Q1 16
-#define LTG_K_COUNT 17
+#define LTG_K_ROW_DLOGITS 17 /* softmax statistics + losses + dlogits of a row (small item slabs) */
+#define LTG_K_ENC0_GRAD 18   /* sparse gradient rows of W_q0 */
+#define LTG_K_G_TAIL 19      /* the generator's Adam updates as jobs of one launch */
+#define LTG_K_COUNT 20
 typedef struct ltg_probe {
     int32_t kernel_id;
     int32_t reserved0;

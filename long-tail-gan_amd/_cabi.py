@@ -53,7 +53,8 @@ class ltg_probe(C.Structure):
 
 
 KERNEL_IDS = {"enc0_fwd": 1, "enc1": 2, "dec0": 3, "dec1_fwd": 4, "d_l1": 5, "d_l2": 6, "d_bwd1": 7, "d_bwd2": 8, "d_adam": 9,
-              "dh2": 10, "dec1_bwd_adam": 11, "enc0_bwd_adam": 12, "dz": 13, "dh1": 14, "wgrad_p0": 15, "wgrad_q1": 16}
+              "dh2": 10, "dec1_bwd_adam": 11, "enc0_bwd_adam": 12, "dz": 13, "dh1": 14, "wgrad_p0": 15, "wgrad_q1": 16,
+              "row_dlogits": 17, "enc0_grad": 18, "g_tail": 19}
 
 
 class ltg_fwd_opts(C.Structure):

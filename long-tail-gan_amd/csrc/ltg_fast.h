@@ -1,0 +1,897 @@
+// Latency-bound kernels of the path rebuilt on the register-resident MFMA block (ltg_rgemm.h): one memory round trip per
+// workgroup instead of one per K tile.  Included by ltg_kernels.hip inside its anonymous namespace (after AdamC, PairView,
+// DropView, DLayout, dact, Workspace, Probe).  Reference citations are relative to /root/reference/.
+//
+//   generator middle layers   fk_enc1, fk_dec0 (reparameterisation + KL folded into its operand loader), fk_dz, fk_dh1
+//   encoder layer 0           fk_enc0_fwd / fk_enc0_grad: column-blocked, 8 gathered rows in flight per wave
+//   discriminator             fk_d_l1, fk_d_l2 (output unit folded in: per-tile partial dot products), fk_d_y,
+//                             fk_d_bwd1 / fk_d_bwd2 (gradient slabs), fk_d_adam (flat float4 sweep)
+//   small item counts         fk_dec1, fk_row_dlogits (softmax statistics + losses + dlogits of a row in one pass),
+//                             fk_dh2, fk_g_tail (the Adam updates of the generator as jobs of ONE launch)
+#pragma once
+
+#include "ltg_rgemm.h"
+
+typedef LtgRg<1, 1, 1, 1, 4> Rg16;    // 16 x 16 tile, four K slices
+typedef LtgRg<2, 2, 1, 1, 4> Rg32k;   // 32 x 32 tile, four K slices (each wave the whole tile)
+typedef LtgRg<1, 2, 1, 1, 4> Rg16x32; // 16 x 32 tile, four K slices
+typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over the whole K
+
+// ---------------------------------------------------------------------------------------------------------------------
+// generator middle layers (MultiVAE.py:152-172)
+// ---------------------------------------------------------------------------------------------------------------------
+
+// enc-1 (MultiVAE.py:152,157-158): mulv = h1 . W_q1 + b_q1        [B][2Z]
+__global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z2, const float* __restrict__ h1, const float* __restrict__ Wq1,
+                                              const float* __restrict__ bq1, float* __restrict__ mulv) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(h1 + (size_t)m * H + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wq1 + (size_t)k * Z2 + n, Z2); };
+    auto epi = [=] __device__(int m, int n, float v, bool ok) {
+        if (ok) mulv[(size_t)m * Z2 + n] = v + bq1[n];
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, Z2, H, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+}
+
+// reparameterisation + KL + dec-0 (MultiVAE.py:160-162, :178-181, :168-172): z = mu + is_training * eps * exp(logvar / 2)
+// is built by the A-operand loader (every column tile rebuilds the z of its 16 rows: 200 values per row); the
+// column-tile-0 workgroups also store z (the weight gradient of W_p0 reads it) and the per-row KL;
+// h2 = tanh(z . W_p0 + b_p0).  The product is the TM = TN = 1, WK = 4 form of ltg_rgemm_product written out, because the
+// loader's side effects (z store, KL sum) must know whether a visit is a real one or a clamped duplicate.
+__global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* __restrict__ mulv, const float* __restrict__ eps_in,
+                                              float is_training, uint64_t seed, uint64_t step, const float* __restrict__ Wp0,
+                                              const float* __restrict__ bp0, float* __restrict__ z, float* __restrict__ kl_rows,
+                                              float* __restrict__ h2) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    __shared__ float klp[4][16];
+    constexpr int NB = 4, LDC = Rg16::LDC;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const bool writer = blockIdx.x == 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const bool myrow = m0 + r < B;
+    const int nblk = (Z + 15) >> 4, per = (nblk + 3) / 4, Kc = (Z - 1) & ~3;
+    const int am = min(m0 + r, B - 1), bn = min(n0 + r, H - 1);
+    const float* mrow = mulv + (size_t)am * 2 * Z;
+    float kl = 0.f;
+    ltg_f32x4 acc = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < per; base += NB) {
+        ltg_f32x4 rmu[NB], rlv[NB], re[NB], bv[NB];
+        // phase 1: requests only
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int kc = min(16 * (w * per + base + i) + 4 * q, Kc);
+            rmu[i] = ltg_ld4(mrow + kc);
+            rlv[i] = ltg_ld4(mrow + Z + kc);
+            bv[i] = ltg_ld4s(Wp0 + (size_t)kc * H + bn, H);
+            re[i] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (is_training != 0.f && eps_in) re[i] = ltg_ld4(eps_in + (size_t)am * Z + kc);   // uniform
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: z, KL, MFMAs
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = 16 * (w * per + base + i) + 4 * q;
+            const bool o = base + i < per && k < Z && myrow;
+            const int kc = min(k, Kc);
+            ltg_f32x4 e = re[i];
+            if (is_training != 0.f && !eps_in) {   // uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)am * Z + kc + j);
+            }
+            ltg_f32x4 zz;
+            float kk = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                zz[j] = rmu[i][j] + is_training * e[j] * expf(0.5f * rlv[i][j]);
+                kk += 0.5f * (-rlv[i][j] + expf(rlv[i][j]) + rmu[i][j] * rmu[i][j] - 1.f);
+            }
+            if (writer && o) *reinterpret_cast<ltg_f32x4*>(z + (size_t)am * Z + kc) = zz;
+            kl += o ? kk : 0.f;
+            const ltg_f32x4 av = ltg_f32x4{o ? zz[0] : 0.f, o ? zz[1] : 0.f, o ? zz[2] : 0.f, o ? zz[3] : 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[i][j], acc, 0, 0, 0);
+        }
+    }
+    float* mine = lds + w * (16 * LDC);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) mine[(4 * q + x) * LDC + r] = acc[x];
+    // KL of row r: the four q-lanes of a wave, then the four waves (fixed order: reproducible)
+    kl += __shfl_xor(kl, 16);
+    kl += __shfl_xor(kl, 32);
+    if (q == 0) klp[w][r] = kl;
+    __syncthreads();
+    {
+        const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
+        const float v = lds[mm * LDC + nn] + lds[16 * LDC + mm * LDC + nn] + lds[32 * LDC + mm * LDC + nn] + lds[48 * LDC + mm * LDC + nn];
+        const int m = m0 + mm, n = n0 + nn;
+        if (m < B && n < H) h2[(size_t)m * H + n] = tanhf(v + bp0[n]);
+    }
+    if (writer && threadIdx.x < 16 && m0 + threadIdx.x < B)
+        kl_rows[m0 + threadIdx.x] = klp[0][threadIdx.x] + klp[1][threadIdx.x] + klp[2][threadIdx.x] + klp[3][threadIdx.x];
+}
+
+// dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)          [B][2Z]
+__global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
+                                            const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
+                                            float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const float invB = 1.f / (float)B;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(da2 + (size_t)m * H + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wp0 + (size_t)n * H + k); };
+    auto epi = [=] __device__(int m, int n, float dz, bool ok) {
+        if (!ok) return;
+        const float mu = mulv[(size_t)m * 2 * Z + n], lv = mulv[(size_t)m * 2 * Z + Z + n];
+        float e = 0.f;
+        if (is_training != 0.f)
+            e = eps_in ? eps_in[(size_t)m * Z + n] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)m * Z + n);
+        dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
+        dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, Z, H, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+}
+
+// dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)                                      [B][H]
+__global__ __launch_bounds__(NT) void fk_dh1(int B, int H, int Z2, const float* __restrict__ dmlv, const float* __restrict__ Wq1,
+                                             const float* __restrict__ h1, float* __restrict__ da1) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dmlv + (size_t)m * Z2 + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wq1 + (size_t)n * Z2 + k); };
+    auto epi = [=] __device__(int m, int n, float v, bool ok) {
+        if (!ok) return;
+        const float t = h1[(size_t)m * H + n];
+        da1[(size_t)m * H + n] = v * (1.f - t * t);
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 7>(B, H, Z2, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// encoder layer 0: sparse row gather-sum and its sparse gradient (MultiVAE.py:148-155)
+// ---------------------------------------------------------------------------------------------------------------------
+// One 1024-thread workgroup per (block of 256 columns, user row): a lane owns ONE float4 column chunk, so eight gathered
+// W_q0 rows are in flight per wave and 128 per workgroup and trip -- a 900-item history takes 8 dependent trips instead of
+// 15, a median row one.  (l2_normalize eps, dropout convention, item-shard conventions: see k_enc0_fwd.)
+constexpr int E0_U = 8;
+__global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                      const float* __restrict__ values, const uint8_t* __restrict__ drop_keep, float keep,
+                                                      uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
+                                                      const float* __restrict__ bq0, float* __restrict__ h1, float* __restrict__ row_scale,
+                                                      const float* __restrict__ row_norm2, int item_lo, int Ig, int pre_only) {
+    __shared__ __attribute__((aligned(16))) float4 s_part[ENC_NW][64];
+    __shared__ int s_idx[ENC_NT];
+    __shared__ float s_val[ENC_NT];
+    __shared__ float red[ENC_NW];
+    const int b = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int beg = indptr[b], end = indptr[b + 1];
+    float ss = 0.f;
+    for (int e = beg + tid; e < end; e += ENC_NT) {
+        const float v = values ? values[e] : 1.f;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) red[w] = ss;
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < ENC_NW; ++i) ss += red[i];
+    if (row_norm2) ss = row_norm2[b];
+    const float scale = 1.f / (keep * sqrtf(fmaxf(ss, 1e-12f)));
+    if (tid == 0 && cb == 0) row_scale[b] = scale;
+    const int H4 = H >> 2;
+    const int c4 = min(64 * cb + lane, H4 - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = beg; c0 < end; c0 += ENC_NT) {
+        __syncthreads();
+        const int e = c0 + tid;
+        if (e < end) {
+            const int it = indices[e];
+            const float v = values ? values[e] : 1.f;
+            const bool kp = drop_keep ? (drop_keep[e] != 0)
+                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
+            s_idx[tid] = it;
+            s_val[tid] = kp ? v : 0.f;
+        }
+        __syncthreads();
+        const int cnt = min(ENC_NT, end - c0);
+        for (int j = w; j < cnt; j += E0_U * ENC_NW) {
+            float v[E0_U];
+            float4 x[E0_U];
+#pragma unroll
+            for (int u = 0; u < E0_U; ++u) {
+                const int ju = j + u * ENC_NW;
+                const bool ok = ju < cnt;
+                v[u] = ok ? s_val[ju] : 0.f;
+                x[u] = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[ok ? ju : j] * H)[c4];
+            }
+#pragma unroll
+            for (int u = 0; u < E0_U; ++u) {
+                acc.x += v[u] * x[u].x;
+                acc.y += v[u] * x[u].y;
+                acc.z += v[u] * x[u].z;
+                acc.w += v[u] * x[u].w;
+            }
+        }
+    }
+    s_part[w][lane] = acc;
+    __syncthreads();
+    if (tid < 64 && 64 * cb + tid < H4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < ENC_NW; ++i) {
+            const float4 p = s_part[i][tid];
+            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        const int c = 4 * (64 * cb + tid);
+        float4 o;
+        if (pre_only) o = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
+        else {
+            const float4 bb = *reinterpret_cast<const float4*>(bq0 + c);
+            o = make_float4(tanhf(t.x * scale + bb.x), tanhf(t.y * scale + bb.y), tanhf(t.z * scale + bb.z), tanhf(t.w * scale + bb.w));
+        }
+        *reinterpret_cast<float4*>(h1 + (size_t)b * H + c) = o;
+    }
+}
+
+// Sparse gradient rows of W_q0 (see k_enc0_grad): one 512-thread workgroup per (block of 256 columns, distinct item | bias
+// part), 8 entries in flight per wave.
+constexpr int G0_NT = 512, G0_NW = 8, G0_U = 8;
+__global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
+                                                      const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
+                                                      const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                      const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
+                                                      const float* __restrict__ row_scale, const float* __restrict__ da1,
+                                                      float* __restrict__ G, int item_lo, int Ig) {
+    __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][64];
+    const int u = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H4 = H >> 2;
+    const int c4 = min(64 * cb + lane, H4 - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* d4 = reinterpret_cast<const float4*>(da1);
+    const int bp = u - nu, per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+    const int q0 = u < nu ? uptr[u] : min(B, bp * per), q1 = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
+    for (int q = q0 + w; q < q1; q += G0_U * G0_NW) {
+        int b[G0_U];
+        float sc[G0_U];
+#pragma unroll
+        for (int t = 0; t < G0_U; ++t) {
+            const int qt = q + t * G0_NW;
+            const bool ok = qt < q1;
+            const int qc = ok ? qt : q;
+            if (u < nu) {   // uniform
+                b[t] = rowidx[qc];
+                const int pos = csr_pos[qc];
+                const int it = indices[pos];
+                const bool kp = drop_keep ? (drop_keep[pos] != 0)
+                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b[t] * (uint64_t)Ig + item_lo + it, keep);
+                sc[t] = (ok && kp) ? (values ? values[pos] : 1.f) * row_scale[b[t]] : 0.f;
+            } else {
+                b[t] = qc;
+                sc[t] = ok ? 1.f : 0.f;
+            }
+        }
+        float4 d[G0_U];
+#pragma unroll
+        for (int t = 0; t < G0_U; ++t) d[t] = d4[(size_t)b[t] * H4 + c4];
+#pragma unroll
+        for (int t = 0; t < G0_U; ++t) {
+            acc.x += sc[t] * d[t].x;
+            acc.y += sc[t] * d[t].y;
+            acc.z += sc[t] * d[t].z;
+            acc.w += sc[t] * d[t].w;
+        }
+    }
+    s_g[w][lane] = acc;
+    __syncthreads();
+    if (tid < 64 && 64 * cb + tid < H4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < G0_NW; ++i) {
+            const float4 p = s_g[i][tid];
+            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        reinterpret_cast<float4*>(G)[(size_t)u * H4 + 64 * cb + tid] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// discriminator (discriminator.py:3-58), fp32 operands, default-sized layers
+// ---------------------------------------------------------------------------------------------------------------------
+
+// branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular -> h1, 1 niche -> h2.  32 x 32 tiles, each wave
+// a 16 x 16 product over the whole K = h0 (7 blocks in flight).
+__global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
+                                              const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                              const float* __restrict__ b2, DropView dA, DropView dB, float keep, uint64_t seed,
+                                              uint64_t step, float* __restrict__ A1) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg32::LDS_FLOATS];
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    const bool br = blockIdx.z != 0;
+    const int N = br ? h2 : h1;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (n0 >= N) return;
+    const float* W = br ? w2 : w1;
+    const float* bias = br ? b2 : b1;
+    const int coff = br ? h1 : 0;
+    // the embedding row of this lane's operand row (one id load, not one per k block)
+    const int myrow = min(Rg32::row(m0, 0), n - 1);
+    const int id = br ? pv.nic(myrow) : pv.pop(myrow);
+    const float* erow = emb + (size_t)max(id, 0) * h0;
+    auto a_ld = [=] __device__(int, int, int k) { return ltg_ld4(erow + k); };
+    auto a_xf = [=] __device__(ltg_f32x4 v, int, int, int) { return id >= 0 ? v : ltg_f32x4{0.f, 0.f, 0.f, 0.f}; };
+    auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4s(W + (size_t)k * N + nn, N); };
+    auto epi = [=] __device__(int m, int nn, float v, bool ok) {
+        if (!ok) return;
+        const float t = tanhf(v + bias[nn]);
+        const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
+        A1[(size_t)m * h12 + coff + nn] = kp ? t / keep : 0.f;
+    };
+    ltg_rgemm<1, 1, 2, 2, 1, 7>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+}
+
+// fully connected layer + the output unit's dot product (discriminator.py:44-45, :54-55): A3 = dropout(tanh(A1 . w3 + b3));
+// G3 = w4 * d A3 / d pre (the factor the backward needs, so that dpre3 = ds[row] * G3); spart[tile_n][row] = this column
+// tile's share of A3[row] . w4 -- the consumers add the tiles up in a fixed order (no atomics: reproducible).
+__global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const float* __restrict__ A1, const float* __restrict__ w3,
+                                              const float* __restrict__ b3, const float* __restrict__ w4, DropView dC, float keep,
+                                              uint64_t seed, uint64_t step, float* __restrict__ A3, float* __restrict__ G3,
+                                              float* __restrict__ spart) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(A1 + (size_t)m * h12 + k); };
+    auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4s(w3 + (size_t)k * h3 + nn, h3); };
+    const int tile = blockIdx.x;
+    auto epi = [=] __device__(int m, int nn, float v, bool ok) {
+        const int nc = min(nn, h3 - 1), mc = min(m, n - 1);
+        const float t = tanhf(v + b3[nc]);
+        const bool kp = ok && dC.keep(mc, nc, h3, seed, LTG_STREAM_D_DROP_C, step, keep);
+        const float a3 = kp ? t / keep : 0.f;
+        const float wv = w4[nc];
+        if (ok) {
+            A3[(size_t)m * h3 + nn] = a3;
+            if (G3) G3[(size_t)m * h3 + nn] = wv * dact(a3, keep);
+        }
+        float pd = a3 * wv;   // the 32 columns of a tile row sit in 32 consecutive lanes
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
+        if ((threadIdx.x & 31) == 0 && m < n) spart[(size_t)tile * n + m] = pd;
+    };
+    ltg_rgemm<2, 2, 1, 1, 4, 7>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+}
+
+// output unit from the tile partials (discriminator.py:45,55; train.py:142): y, d loss / d s, loss term of one pair row
+__device__ __forceinline__ void d_row_terms(const PairView& pv, int r, int n, int ntile, const float* __restrict__ spart, float b4v,
+                                            float& yv, float& ds, float& lrow) {
+    float s = b4v;
+    for (int t = 0; t < ntile; ++t) s += spart[(size_t)t * n + r];
+    const float yy = 1.f / (1.f + expf(-s));
+    const bool ok = pv.valid(r), real = r < pv.nr;
+    yv = ok ? yy : 0.f;
+    ds = ok ? (real ? -(1.f - yy) : yy) : 0.f;
+    lrow = ok ? (real ? -logf(yy) : -logf(1.f - yy)) : 0.f;
+}
+
+// y of every pair row (the generator step only needs sum_j y_j of the fake tower, train.py:155)
+__global__ __launch_bounds__(NT) void fk_d_y(PairView pv, int ntile, const float* __restrict__ spart, const float* __restrict__ b4,
+                                             float* __restrict__ y) {
+    const int n = pv.nr + pv.nf;
+    const int r = blockIdx.x * NT + threadIdx.x;
+    if (r >= n) return;
+    float yv, ds, lr;
+    d_row_terms(pv, r, n, ntile, spart, b4[0], yv, ds, lr);
+    y[r] = yv;
+}
+
+// Backward stage 1, ONE launch, three jobs by block index (gradient slabs are summed by the Adam sweep):
+//   job A  dpre1 = ((ds G3) . w3^T) * dact(A1)                               [n][h1+h2]   32 x 32 tiles
+//   job B  slab[z] = A1^T . (ds G3) (+ ones row -> db3), split over row chunks [h12+1][h3]  32 x 32 tiles
+//   job C  slab[z]: dw4 = A3^T . ds, db4 = sum ds, and the chunk's share of d_loss (slot P of the slab)
+// Every job first rebuilds ds (and the loss terms) of the pair rows it touches from the tile partials of fk_d_l2.
+__global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, int nA, int nB, int ntile, DLayout L, int SP,
+                                                const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
+                                                const float* __restrict__ spart, const float* __restrict__ b4p,
+                                                const float* __restrict__ w3, float keep, float* __restrict__ dpre1,
+                                                float* __restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
+    __shared__ float s_ds[D_KCHUNK], s_lr[D_KCHUNK];
+    const int n = pv.nr + pv.nf, tid = threadIdx.x;
+    const float b4v = b4p[0];
+    int bid = blockIdx.x;
+    if (bid < nA) {
+        const int tn = (h12 + 31) / 32;
+        const int m0 = (bid / tn) * 32, n0 = (bid % tn) * 32;
+        if (tid < 32) {
+            float yv, ds, lr;
+            d_row_terms(pv, min(m0 + tid, n - 1), n, ntile, spart, b4v, yv, ds, lr);
+            s_ds[tid] = ds;
+        }
+        __syncthreads();
+        auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(G3 + (size_t)m * h3 + k); };
+        auto a_xf = [=] __device__(ltg_f32x4 v, int, int m, int) { return v * s_ds[m - m0]; };
+        auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4(w3 + (size_t)nn * h3 + k); };
+        auto epi = [=] __device__(int m, int nn, float v, bool ok) {
+            if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(A1[(size_t)m * h12 + nn], keep);
+        };
+        ltg_rgemm<2, 2, 1, 1, 4, 5>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+        return;
+    }
+    bid -= nA;
+    const int tmB = (h12 + 1 + 31) / 32, tnB = (h3 + 31) / 32;
+    const int z = bid < nB ? bid / (tmB * tnB) : (bid - nB) / ((h3 + 2 + 31) / 32);
+    const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK), K = kend - kbeg;
+    {
+        float yv, ds, lr;
+        d_row_terms(pv, min(kbeg + tid, n - 1), n, ntile, spart, b4v, yv, ds, lr);
+        s_ds[tid] = kbeg + tid < kend ? ds : 0.f;
+        s_lr[tid] = kbeg + tid < kend ? lr : 0.f;
+    }
+    __syncthreads();
+    float* out = slab + (size_t)z * SP;
+    if (bid < nB) {
+        const int t = bid % (tmB * tnB);
+        const int m0 = (t / tnB) * 32, n0 = (t % tnB) * 32;
+        const int ow = L.off[4], ob = L.off[5];
+        auto a_ld = [=] __device__(int, int m, int k) {
+            ltg_f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = A1[(size_t)(kbeg + min(k + j, K - 1)) * h12 + min(m, h12 - 1)];
+            return v;
+        };
+        auto a_xf = [=] __device__(ltg_f32x4 x, int, int m, int k) {
+            ltg_f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = k + j < K ? (m < h12 ? x[j] : 1.f) : 0.f;
+            return v;
+        };
+        auto b_ld = [=] __device__(int, int k, int nn) {
+            ltg_f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = G3[(size_t)(kbeg + min(k + j, K - 1)) * h3 + nn];
+            return v;
+        };
+        auto b_xf = [=] __device__(ltg_f32x4 x, int, int k, int) {
+            ltg_f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = s_ds[min(k + j, K - 1)] * x[j];
+            return v;
+        };
+        auto epi = [=] __device__(int m, int nn, float g, bool ok) {
+            if (!ok) return;
+            if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
+            else out[ob + nn] = g;
+        };
+        ltg_rgemm<2, 2, 1, 1, 4, 4>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds);
+        return;
+    }
+    bid -= nB;
+    {
+        // columns c < h3: dw4[c]; c == h3: db4; c == h3 + 1: the chunk's loss sum
+        float (*part)[33] = reinterpret_cast<float (*)[33]>(lds);
+        const int tc = (h3 + 2 + 31) / 32;
+        const int tn = tid & 31, tr = tid >> 5;
+        const int c = (bid % tc) * 32 + tn;
+        float acc = 0.f;
+        if (c <= h3 + 1) {
+#pragma unroll 8
+            for (int r = tr; r < K; r += 8) acc += (c < h3 ? A3[(size_t)(kbeg + r) * h3 + c] : 1.f) * (c == h3 + 1 ? s_lr[r] : s_ds[r]);
+        }
+        part[tr][tn] = acc;
+        __syncthreads();
+        if (tr == 0 && c <= h3 + 1) {
+            float g = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g += part[i][tn];
+            out[c < h3 ? L.off[6] + c : (c == h3 ? L.off[7] : L.off[8])] = g;
+        }
+    }
+}
+
+// Backward stage 2: dw1 / db1 and dw2 / db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), 16 x 32 tiles.
+__global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
+                                                const float* __restrict__ dpre1, float* __restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    const int tm = (h0 + 1 + 15) / 16;
+    const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
+    const int per_z = tm * (tn1 + tn2);
+    const int z = blockIdx.x / per_z, t = blockIdx.x % per_z;
+    const int m0 = (t / (tn1 + tn2)) * 16;
+    const int tcol = t % (tn1 + tn2);
+    const bool br = tcol >= tn1;
+    const int n0 = (br ? tcol - tn1 : tcol) * 32;
+    const int N = br ? h2 : h1;
+    const int coff = br ? h1 : 0;
+    const int ow = L.off[br ? 2 : 0], ob = L.off[br ? 3 : 1];
+    const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK), K = kend - kbeg;
+    float* out = slab + (size_t)z * SP;
+    // phase 0: the pair ids of the 16 pair rows this lane multiplies (4 blocks x 4): their embedding rows are the dependent
+    // second round trip
+    int ids[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kc = Rg16x32::kc(K, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = kbeg + min(kc + j, K - 1);
+            ids[i][j] = br ? pv.nic(row) : pv.pop(row);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto a_ld = [=] __device__(int i, int m, int) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = emb[(size_t)max(ids[i][j], 0) * h0 + min(m, h0 - 1)];
+        return v;
+    };
+    auto a_xf = [=] __device__(ltg_f32x4 x, int i, int m, int k) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = k + j < K ? (m < h0 ? (ids[i][j] >= 0 ? x[j] : 0.f) : 1.f) : 0.f;
+        return v;
+    };
+    auto b_ld = [=] __device__(int, int k, int nn) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = dpre1[(size_t)(kbeg + min(k + j, K - 1)) * h12 + coff + nn];
+        return v;
+    };
+    auto epi = [=] __device__(int m, int nn, float g, bool ok) {
+        if (!ok) return;
+        if (m < h0) out[ow + (size_t)m * N + nn] = g;
+        else out[ob + nn] = g;
+    };
+    ltg_rgemm<1, 2, 1, 1, 4, 4>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+}
+
+// One Adam sweep over the discriminator's trainable tensors laid out back to back (train.py:163): g = sum of the chunk
+// slabs; 16 bytes per lane.  Block 0 also adds up d_loss (train.py:142) from slot P of the slabs.
+__global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const float* __restrict__ slab, float* __restrict__ p,
+                                                float* __restrict__ m, float* __restrict__ v, AdamC ad, float* __restrict__ loss_out) {
+    const int P4 = P >> 2;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < P4; e += gridDim.x * NT) {
+        ltg_f32x4 g = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < ks; ++z) g += *reinterpret_cast<const ltg_f32x4*>(slab + (size_t)z * SP + 4 * e);
+        ltg_f32x4 pp = ltg_ld4(p + 4 * e), mm = ltg_ld4(m + 4 * e), vv = ltg_ld4(v + 4 * e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mm[j] = ad.b1 * mm[j] + (1.f - ad.b1) * g[j];
+            vv[j] = ad.b2 * vv[j] + (1.f - ad.b2) * g[j] * g[j];
+            pp[j] = pp[j] - ad.lr_t * mm[j] / (sqrtf(vv[j]) + ad.eps);
+        }
+        *reinterpret_cast<ltg_f32x4*>(p + 4 * e) = pp;
+        *reinterpret_cast<ltg_f32x4*>(m + 4 * e) = mm;
+        *reinterpret_cast<ltg_f32x4*>(v + 4 * e) = vv;
+    }
+    if (blockIdx.x == 0) {
+        const int e = 4 * P4 + threadIdx.x;
+        if (e < P) {   // ragged tail (P % 4 elements)
+            float g = 0.f;
+            for (int z = 0; z < ks; ++z) g += slab[(size_t)z * SP + e];
+            adam_update(p, m, v, (size_t)e, g, ad);
+        }
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int z = 0; z < ks; ++z) s += slab[(size_t)z * SP + P];
+            loss_out[0] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small item slabs (I <= 4096): decoder layer 1, the row softmax + losses + dlogits, dh2, and the Adam tail
+// ---------------------------------------------------------------------------------------------------------------------
+
+// dec-1 (MultiVAE.py:169): logits = h2 . W_p1t^T + b_p1; operands rounded to bf16 when BF (LTG_PREC_BF16)
+template <bool BF>
+__global__ __launch_bounds__(NT) void fk_dec1(int B, int I, int H, const float* __restrict__ h2, const float* __restrict__ Wp1t,
+                                              const float* __restrict__ bp1, float* __restrict__ logits) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(h2 + (size_t)m * H + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wp1t + (size_t)n * H + k); };
+    auto xf = [=] __device__(ltg_f32x4 v, int, int, int) { return BF ? ltg_bf16r4(v) : v; };
+    auto epi = [=] __device__(int m, int n, float v, bool ok) {
+        if (ok) logits[(size_t)m * I + n] = v + bp1[n];
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, I, H, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+}
+
+// One workgroup per user row: log-softmax statistics, the row's loss terms and dlogits in ONE pass (the row lives in
+// registers).  train.py:145-157 + the closed form of SURVEY 8/a10:
+//   dlogits[b][i] = p * (n_b / B + c * P_b) - x_bi / B - c * p * [(b, i) in S],  c = lambda / cnt * sum_j y_j
+// rowout[b] = {neg_ll of the row, P_b = sum_{S_b} p, KL of the row, sum_j y_j}; the step's scalars are added up by the
+// tail launch.  Needs no other row's statistics, so nothing has to meet between the forward and the backward.
+constexpr int RD_MAXI = 4096;
+__global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                     const float* __restrict__ values, const float* __restrict__ logits,
+                                                     const float* __restrict__ kl_rows, const float* __restrict__ y, int nf,
+                                                     const int32_t* __restrict__ cnt, float lam, const int32_t* __restrict__ f_row,
+                                                     const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
+                                                     float* __restrict__ dlog, float* __restrict__ lse, float* __restrict__ rowout) {
+    __shared__ float s_x[RD_MAXI];
+    __shared__ uint8_t s_s[RD_MAXI];
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (size_t)b * I;
+    constexpr int PER = RD_MAXI / NT;
+    float v[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + NT * j;
+        v[j] = i < I ? row[min(i, I - 1)] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    for (int j = tid; j < I; j += NT) {
+        s_x[j] = 0.f;
+        s_s[j] = 0;
+    }
+    float sy = 0.f;
+    for (int q = tid; q < nf; q += NT) sy += y[q];
+    __syncthreads();
+    float xl = 0.f, nx = 0.f;
+    for (int e = indptr[b] + tid; e < indptr[b + 1]; e += NT) {
+        const int it = indices[e];
+        const float x = values ? values[e] : 1.f;
+        s_x[it] = x;
+        xl += x * row[it];
+        nx += x;
+    }
+    for (int q = tid; q < nf; q += NT) {
+        const int it = f_gen[q];
+        if (f_row[q] == b && it >= 0 && it < I && f_pop[q] >= 0) s_s[it] = 1;
+    }
+    mx = block_max(mx, red);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s += expf(v[j] - mx);   // exp(-inf) = 0 beyond I
+    s = block_sum(s, red);
+    const float l = mx + logf(s);
+    xl = block_sum(xl, red);
+    nx = block_sum(nx, red);
+    sy = block_sum(sy, red);     // (the barriers inside also publish s_x / s_s)
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + NT * j;
+        if (i < I && s_s[i]) ps += expf(v[j] - l);
+    }
+    ps = block_sum(ps, red);
+    const float invB = 1.f / (float)B;
+    const float c = cnt[0] > 0 ? lam / (float)cnt[0] * sy : 0.f;
+    const float alpha = nx * invB + c * ps;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + NT * j;
+        if (i < I) {
+            const float p = expf(v[j] - l);
+            dlog[(size_t)b * I + i] = p * alpha - s_x[i] * invB - (s_s[i] ? c * p : 0.f);
+        }
+    }
+    if (tid == 0) {
+        lse[b] = l;
+        float* o = rowout + (size_t)b * 4;
+        o[0] = -xl + nx * l;
+        o[1] = ps;
+        o[2] = kl_rows[b];
+        o[3] = sy;
+    }
+}
+
+// da2 = (dlog . W_p1t) * (1 - h2^2)          [B][H], K = I
+template <bool BF>
+__global__ __launch_bounds__(NT) void fk_dh2(int B, int I, int H, const float* __restrict__ dlog, const float* __restrict__ Wp1t,
+                                             const float* __restrict__ h2, float* __restrict__ da2) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dlog + (size_t)m * I + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wp1t + (size_t)k * H + n, H); };
+    auto xf = [=] __device__(ltg_f32x4 v, int, int, int) { return BF ? ltg_bf16r4(v) : v; };
+    auto epi = [=] __device__(int m, int n, float v, bool ok) {
+        if (!ok) return;
+        const float t = h2[(size_t)m * H + n];
+        da2[(size_t)m * H + n] = v * (1.f - t * t);
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 16>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+}
+
+// "weight gradient + Adam" tile: G[m][n] = sum_k Lm(k, m) * Rm(k, n) over the K batch rows, fused with the TF-Adam update
+// of W[m][n] (row stride ldw) -- theta / m / v of the tile are requested BEFORE the product.  ONES_L: an extra row m == Min
+// of ones on the left (bias over n: MultiVAE.py b_q1, b_p0); otherwise an extra column n == Nin of ones on the right
+// (bias over m: b_p1).  RND: operands rounded to bf16 (decoder layer 1 under LTG_PREC_BF16).  Nin % 4 == 0.
+struct WgTensors {
+    float *W, *mW, *vW, *b, *mb, *vb;
+};
+struct WgWhere {
+    float *p, *m, *v;
+    bool vec;
+};
+struct WgRegs {
+    ltg_f32x4 p, m, v;
+};
+template <bool RND, bool ONES_L>
+__device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const float* __restrict__ Lm, int ldl, const float* __restrict__ Rm,
+                                                int ldr, WgTensors T, int ldw, AdamC ad, int m0, int n0, float* __restrict__ lds) {
+    const int M = ONES_L ? Min + 1 : Min, N = ONES_L ? Nin : Nin + 1;
+    auto a_ld = [=] __device__(int, int m, int k) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Lm[(size_t)min(k + j, K - 1) * ldl + min(m, Min - 1)];
+        return v;
+    };
+    auto a_xf = [=] __device__(ltg_f32x4 x, int, int m, int k) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = k + j < K ? ((ONES_L && m == Min) ? 1.f : (RND ? ltg_bf16r(x[j]) : x[j])) : 0.f;
+        return v;
+    };
+    auto b_ld = [=] __device__(int, int k, int n) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Rm[(size_t)min(k + j, K - 1) * ldr + min(n, Nin - 1)];
+        return v;
+    };
+    auto b_xf = [=] __device__(ltg_f32x4 x, int, int, int n) {
+        ltg_f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (!ONES_L && n == Nin) ? 1.f : (RND ? ltg_bf16r(x[j]) : x[j]);
+        return v;
+    };
+    // where the float4 group (m, n .. n+3) lives: a weight row, or the bias vector (ONES_L: row Min), or -- for the ones
+    // column n == Nin -- the single bias element of row m
+    // (one base pointer + a per-lane offset: a per-lane select between two uniform pointers becomes a table in scratch)
+    const ptrdiff_t dp = T.b - T.W, dm = T.mb - T.mW, dv = T.vb - T.vW;
+    auto where = [=] __device__(int m, int n) {
+        const bool wrow = ONES_L ? m < Min : n < Nin;
+        const ptrdiff_t o = wrow ? (ptrdiff_t)m * ldw + n : (ONES_L ? (ptrdiff_t)n : (ptrdiff_t)m);
+        WgWhere x;
+        x.p = T.W + (wrow ? o : o + dp);
+        x.m = T.mW + (wrow ? o : o + dm);
+        x.v = T.vW + (wrow ? o : o + dv);
+        x.vec = ONES_L || wrow;
+        return x;
+    };
+    auto prefetch = [=] __device__(int m, int n, bool ok) {
+        WgRegs r;
+        r.p = r.m = r.v = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+        const WgWhere x = where(min(m, M - 1), ok ? n : 0);
+        if (ok && x.vec) {
+            r.p = ltg_ld4(x.p);
+            r.m = ltg_ld4(x.m);
+            r.v = ltg_ld4(x.v);
+        } else if (ok) {
+            r.p[0] = x.p[0];
+            r.m[0] = x.m[0];
+            r.v[0] = x.v[0];
+        }
+        return r;
+    };
+    auto epi4 = [=] __device__(WgRegs r, int m, int n, ltg_f32x4 g, bool ok) {
+        if (!ok) return;
+        const WgWhere x = where(m, n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r.m[j] = ad.b1 * r.m[j] + (1.f - ad.b1) * g[j];
+            r.v[j] = ad.b2 * r.v[j] + (1.f - ad.b2) * g[j] * g[j];
+            r.p[j] = r.p[j] - ad.lr_t * r.m[j] / (sqrtf(r.v[j]) + ad.eps);
+        }
+        if (x.vec) {
+            *reinterpret_cast<ltg_f32x4*>(x.p) = r.p;
+            *reinterpret_cast<ltg_f32x4*>(x.m) = r.m;
+            *reinterpret_cast<ltg_f32x4*>(x.v) = r.v;
+        } else {
+            x.p[0] = r.p[0];
+            x.m[0] = r.m[0];
+            x.v[0] = r.v[0];
+        }
+    };
+    ltg_rgemm_v4<1, 1, 2, 2, 1, 7>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
+}
+
+// The Adam updates of the generator step as jobs of ONE launch (train.py:164; all are independent once every reader of the
+// old weights has run):
+//   job 1  dW_p1t + b_p1   (items x (H + 1), bf16-rounded operands under LTG_PREC_BF16)        -- small item slabs only
+//   job 2  dW_p0 + b_p0    ((Z + 1) x H)          job 3  dW_q1 + b_q1   ((H + 1) x 2Z)
+//   job 4  W_q0 + b_q0     dense float4 sweep, sparse gradient rows through slot[] (see k_enc0_bwd_adam)
+//   job 5  the step's scalars from the per-row terms of fk_row_dlogits (train.py:154-157)         -- small item slabs only
+struct TailArgs {
+    int B, I, H, Z, nu;
+    int n1, n2, n3, n4, n5;       // blocks per job
+    const float *dlog, *h2, *z, *da2, *h1, *dmlv, *G;
+    const int32_t* slot;
+    const float* rowout;
+    const int32_t* cnt;
+    float anneal, lam;
+    float *loss_out, *loss_out2;
+};
+template <bool BF>
+__global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, AdamC ad) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg32::LDS_FLOATS];
+    int bid = blockIdx.x;
+    const int B = a.B, I = a.I, H = a.H, Z = a.Z;
+    if (bid < a.n1) {
+        const int tn = (H + 1 + 31) / 32;
+        const WgTensors T{st.p[3], st.m[3], st.v[3], st.p[7], st.m[7], st.v[7]};
+        wgrad_adam_tile<BF, false>(B, I, H, a.dlog, I, a.h2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        return;
+    }
+    bid -= a.n1;
+    if (bid < a.n2) {
+        const int tn = (H + 31) / 32;
+        const WgTensors T{st.p[2], st.m[2], st.v[2], st.p[6], st.m[6], st.v[6]};
+        wgrad_adam_tile<false, true>(B, Z, H, a.z, Z, a.da2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        return;
+    }
+    bid -= a.n2;
+    if (bid < a.n3) {
+        const int tn = (2 * Z + 31) / 32;
+        const WgTensors T{st.p[1], st.m[1], st.v[1], st.p[5], st.m[5], st.v[5]};
+        wgrad_adam_tile<false, true>(B, H, 2 * Z, a.h1, H, a.dmlv, 2 * Z, T, 2 * Z, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        return;
+    }
+    bid -= a.n3;
+    if (bid < a.n4) {
+        const int H4 = H >> 2;
+        const size_t total = (size_t)(I + 1) * H4;
+        float4* W4 = reinterpret_cast<float4*>(st.p[0]);
+        float4* m4 = reinterpret_cast<float4*>(st.m[0]);
+        float4* v4 = reinterpret_cast<float4*>(st.v[0]);
+        float4* b4 = reinterpret_cast<float4*>(st.p[4]);
+        float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
+        float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
+        const float4* G4 = reinterpret_cast<const float4*>(a.G);
+        for (size_t e = (size_t)bid * NT + threadIdx.x; e < total; e += (size_t)a.n4 * NT) {
+            const int i = (int)(e / H4), c = (int)(e % H4);
+            float4* P = i < I ? W4 + e : b4 + c;
+            float4* Mm = i < I ? m4 + e : mb4 + c;
+            float4* Vv = i < I ? v4 + e : vb4 + c;
+            float4 p = *P, mm = *Mm, vv = *Vv;
+            const int u = i < I ? a.slot[i] : a.nu;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u >= 0) g = G4[(size_t)u * H4 + c];
+            if (i >= I) {
+#pragma unroll
+                for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
+                    const float4 t = G4[(size_t)(a.nu + j) * H4 + c];
+                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                }
+            }
+#define LTG_ADAM1(f)                                              \
+    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;                    \
+    vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;              \
+    p.f = p.f - ad.lr_t * mm.f / (sqrtf(vv.f) + ad.eps);
+            LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
+#undef LTG_ADAM1
+            *P = p;
+            *Mm = mm;
+            *Vv = vv;
+        }
+        return;
+    }
+    {
+        float* red = lds;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        for (int b = threadIdx.x; b < B; b += NT) {
+            x0 += a.rowout[(size_t)b * 4];
+            x1 += a.rowout[(size_t)b * 4 + 1];
+            x2 += a.rowout[(size_t)b * 4 + 2];
+        }
+        x0 = block_sum(x0, red);
+        x1 = block_sum(x1, red);
+        x2 = block_sum(x2, red);
+        if (threadIdx.x == 0) {
+            const float sy = a.rowout[3];
+            const float negll = x0 / (float)B, KL = x2 / (float)B;
+            const float c = a.cnt[0] > 0 ? a.lam / (float)a.cnt[0] * sy : 0.f;
+            const float vae = negll + a.anneal * KL, gan = -c * x1;
+            const float r[6] = {vae + gan, vae, gan, x1, sy, c};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                a.loss_out[i] = r[i];
+                if (a.loss_out2) a.loss_out2[i] = r[i];
+            }
+        }
+    }
+}

@@ -966,13 +966,13 @@ __global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int 
 
 // One Adam sweep over all 8 discriminator tensors (train.py:163): g = sum of the split-K slabs.
 // Block 0 additionally reduces the per-row loss terms into loss_out[0] (d_loss, train.py:142).
-__global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, const float* __restrict__ slab, ltg_disc_state st, AdamC ad,
+__global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, int SP, const float* __restrict__ slab, ltg_disc_state st, AdamC ad,
                                                int n, const float* __restrict__ lrow, float* __restrict__ loss_out) {
     __shared__ float red[NT / 64];
-    const int P = L.off[8];
+    const int P = L.off[8];     // SP = stride of a slab (>= P); lrow == nullptr: the loss sum sits in slot P of every slab
     for (int e = blockIdx.x * NT + threadIdx.x; e < P; e += gridDim.x * NT) {
         float g = 0.f;
-        for (int z = 0; z < ks; ++z) g += slab[(size_t)z * P + e];
+        for (int z = 0; z < ks; ++z) g += slab[(size_t)z * SP + e];
         int t = 0;
 #pragma unroll
         for (int i = 1; i < 8; ++i) t += e >= L.off[i] ? 1 : 0;
@@ -980,7 +980,8 @@ __global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, const float* _
     }
     if (blockIdx.x == 0) {
         float s = 0.f;
-        for (int i = threadIdx.x; i < n; i += NT) s += lrow[i];
+        if (lrow) for (int i = threadIdx.x; i < n; i += NT) s += lrow[i];
+        else for (int z = threadIdx.x; z < ks; z += NT) s += slab[(size_t)z * SP + P];
         s = block_sum(s, red);
         if (threadIdx.x == 0) loss_out[0] = s;
     }
@@ -1760,8 +1761,12 @@ struct Workspace {
     int32_t* slotmap;   // [I] item -> gradient row of the current batch (only used when the caller passes no slot[] cache)
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
+    // fast path: per-column-tile partial dot products of the output unit, w4 * dA3/dpre, per-row loss terms of the G step
+    float *spart, *G3, *rowout;
     size_t bytes;
 };
+// stride of one discriminator gradient slab: the P gradients + one slot for the chunk's loss sum, padded to whole float4
+inline int d_slab_stride(int P) { return (P + 1 + 3) & ~3; }
 
 Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) {
     Workspace w;
@@ -1802,8 +1807,11 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     {
         const DLayout L = d_layout(cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3);
         const size_t ks = (P + D_KCHUNK - 1) / D_KCHUNK;
-        w.slab = take(ks * (size_t)L.off[8]);
+        w.slab = take(ks * (size_t)d_slab_stride(L.off[8]));
     }
+    w.spart = take(((h3 + 31) / 32) * P);
+    w.G3 = take(P * h3);
+    w.rowout = take(R * 4);
     w.bytes = off;
     return w;
 }
@@ -1841,6 +1849,25 @@ inline void clear_errors() { (void)hipGetLastError(); }
 
 inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return dim3((N + bn - 1) / bn, (M + bm - 1) / bm, z); }
 
+}  // namespace
+namespace {
+#include "ltg_fast.h"
+}
+namespace {
+
+// Which of the round-2 latency-path kernels (ltg_fast.h) apply.  Tuning-knob bit 18 of ltg_config.reserved0 switches all of
+// them off (the round-1 kernels compute the same function; kept for A/B measurements and as the path of unusual sizes).
+inline bool fast_on(const ltg_config* c) { return (c->reserved0 & 262144) == 0; }
+inline bool mid_fast(const ltg_config* c, int rows) { return fast_on(c) && (c->z_dim % 4) == 0 && rows <= 256; }
+inline bool d_wide(const ltg_config* c) { return c->d_h0 >= 512 && c->d_h1 + c->d_h2 >= 512 && c->d_h3 >= 128; }
+inline bool d_fast(const ltg_config* c) {
+    return fast_on(c) && c->d_precision == LTG_PREC_FP32 && !d_wide(c) && (c->d_h0 % 4) == 0 && ((c->d_h1 + c->d_h2) % 4) == 0 && (c->d_h3 % 4) == 0;
+}
+inline bool unsharded(const ltg_config* c) { return c->item_lo == 0 && (c->n_items_global == 0 || c->n_items_global == c->n_items); }
+inline bool small_fast(const ltg_config* c, int rows) {
+    return fast_on(c) && unsharded(c) && c->n_items <= RD_MAXI && (c->n_items % 4) == 0 && (c->z_dim % 4) == 0 && rows <= 256;
+}
+
 bool cfg_ok(const ltg_config* c) {
     return c && c->n_items > 0 && c->h_enc > 0 && c->h_enc <= 768 && (c->h_enc % 4) == 0 && c->z_dim > 0 &&
            (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32) && c->d_precision >= 0 && c->d_precision <= LTG_PREC_FP8;
@@ -1853,6 +1880,13 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                    const ltg_gen_acts* acts, int pre_only, hipStream_t st) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc;
     const Probe pr{o->probe, st};
+    if (fast_on(cfg)) {
+        LTG_PROBED(pr, LTG_K_ENC0_FWD,
+                   hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), 0, st, H, I, bt->indptr, bt->indices, bt->values,
+                                      o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale,
+                                      bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only));
+        return;
+    }
     LTG_PROBED(pr, LTG_K_ENC0_FWD,
                hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices,
                                   bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
@@ -1869,6 +1903,11 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
         const int n = R * H;
         hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
     }
+    if (mid_fast(cfg, R)) {
+        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1, grid2(2 * Z, R, 16, 16), dim3(NT), 0, st, R, H, 2 * Z, acts->h1, gen->p[1], gen->p[5], acts->mulv));
+        LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->mulv, o->eps, o->is_training, cfg->seed,
+                                                      o->rng_step, gen->p[2], gen->p[6], acts->z, acts->kl_rows, acts->h2));
+    } else {
     pr.before(LTG_K_ENC1);
     if (vz) hipLaunchKernelGGL((k_dense_fwd<0, true>), grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
     else hipLaunchKernelGGL((k_dense_fwd<0, false>), grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
@@ -1879,10 +1918,14 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     if (vz) hipLaunchKernelGGL((k_dense_fwd<1, true>), grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
     else hipLaunchKernelGGL((k_dense_fwd<1, false>), grid2(H, R, 32, 32), dim3(NT), 0, st, R, H, Z, acts->z, gen->p[2], gen->p[6], acts->h2);
     pr.after(LTG_K_DEC0);
+    }
     {
         const bool bf = cfg->precision == LTG_PREC_BF16, big = I >= 8192;
         pr.before(LTG_K_DEC1_FWD);
-        if (stream_ok(cfg, gen, R)) {
+        if (fast_on(cfg) && I <= RD_MAXI && R <= 256) {
+            if (bf) hipLaunchKernelGGL(fk_dec1<true>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+            else hipLaunchKernelGGL(fk_dec1<false>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        } else if (stream_ok(cfg, gen, R)) {
             const int ntiles = (I + ST_BN - 1) / ST_BN;
             hipLaunchKernelGGL(k_dec1_fwd_stream, dim3(ntiles < 256 ? ntiles : 256), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H,
                                acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits);
@@ -1967,6 +2010,15 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
+    if (d_fast(cfg)) {
+        // A3, G3 (backward only) and the per-tile partial dot products of the output unit; y only when nothing else follows
+        LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+                                                      d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
+        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk_d_l2, grid2(h3, n, 32, 32), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
+                                                      cfg->seed, step, w.A3, with_bwd ? w.G3 : (float*)nullptr, w.spart));
+        if (!with_bwd) hipLaunchKernelGGL(fk_d_y, dim3((n + NT - 1) / NT), dim3(NT), 0, st, pv, (h3 + 31) / 32, w.spart, d->p[7], w.y);
+        return;
+    }
     const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? 32 : ts, t2 = ts2 < 0 ? 32 : ts2;
     LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, t1, t1, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                               d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
@@ -2033,6 +2085,31 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     const AdamC ad = make_adam(cfg, o->adam_t);
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
+    if (d_fast(cfg)) {
+        const int P = L.off[8], SP = d_slab_stride(P), ntile = (h3 + 31) / 32;
+        const int nA = ((n + 31) / 32) * ((h12 + 31) / 32);
+        const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
+        const int nC = ks * ((h3 + 2 + 31) / 32);
+        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
+                                                        w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab));
+        const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
+        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab));
+        // one flat float4 sweep when the caller laid the eight tensors (and their moments) out back to back
+        bool flat = true;
+        for (int i = 0; i < 7; ++i) {
+            const size_t sz = (size_t)(L.off[i + 1] - L.off[i]);
+            flat = flat && disc->p[i + 1] == disc->p[i] + sz && disc->m[i + 1] == disc->m[i] + sz && disc->v[i + 1] == disc->v[i] + sz;
+        }
+        flat = flat && ((uintptr_t)disc->p[0] % 16) == 0 && ((uintptr_t)disc->m[0] % 16) == 0 && ((uintptr_t)disc->v[0] % 16) == 0;
+        int ga = (P / 4 + NT - 1) / NT;
+        if (ga > 1024) ga = 1024;
+        if (ga < 1) ga = 1;
+        pr.before(LTG_K_D_ADAM);
+        if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, SP, w.slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out);
+        else hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, SP, w.slab, *disc, ad, 0, (const float*)nullptr, loss_out);
+        pr.after(LTG_K_D_ADAM);
+        return check_launch();
+    }
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
     int ts = d_tile(cfg, 2);
     {   // backward stage 1 with > 1024 32 x 32 tiles is throughput-bound, not latency-bound: 64 x 64 tiles (measured -5 %)
@@ -2051,7 +2128,7 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
     LTG_PROBED(pr, LTG_K_D_BWD2, LTG_D_DISPATCH(k_d_bwd2, md, tsb, dim3(n2), st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
     int ga = (L.off[8] + NT - 1) / NT;
     if (ga > 1024) ga = 1024;
-    LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, w.slab, *disc, ad, n, w.lrow, loss_out));
+    LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, L.off[8], w.slab, *disc, ad, n, w.lrow, loss_out));
     return check_launch();
 }
 
@@ -2112,6 +2189,60 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     return check_launch();
 }
 
+// item -> gradient-row map of the batch: the caller's cache, or rebuilt in the workspace (ltg_batch.slot == NULL)
+static const int32_t* g_slot_map(const ltg_config* cfg, const ltg_batch* bt, const Workspace& w, hipStream_t st) {
+    if (bt->slot) return bt->slot;
+    const int I = cfg->n_items, nu = bt->n_unique;
+    hipLaunchKernelGGL(k_fill_i32, dim3((I + NT - 1) / NT < 512 ? (I + NT - 1) / NT : 512), dim3(NT), 0, st, I, -1, w.slotmap);
+    if (nu > 0) hipLaunchKernelGGL(k_slot_scatter, dim3((nu + NT - 1) / NT), dim3(NT), 0, st, nu, bt->uptr, bt->csr_pos, bt->indices, w.slotmap);
+    return w.slotmap;
+}
+
+// sparse gradient rows of W_q0 (+ partial bias rows) into w.gq0
+static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts, const Workspace& w,
+                        hipStream_t st) {
+    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique;
+    const Probe pe{o->probe, st};
+    pe.before(LTG_K_ENC0_GRAD);
+    if (fast_on(cfg))
+        hipLaunchKernelGGL(fk_enc0_grad, dim3((H / 4 + 63) / 64, nu + ENC0_BIAS_PARTS), dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos,
+                           bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0,
+                           cfg->item_lo, Ig_of(cfg));
+    else
+        hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), st, B, I, H, nu, bt->uptr, bt->rowidx,
+                           bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
+                           acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
+    pe.after(LTG_K_ENC0_GRAD);
+}
+
+// The Adam updates of the step as jobs of one launch (fk_g_tail).  with_dec1: include decoder layer 1 (small item slabs;
+// large ones ran the streaming kernel before) and the step's scalars.
+static void g_tail(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
+                   const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st) {
+    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
+    TailArgs a;
+    a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
+    a.n1 = with_dec1 ? ((I + 31) / 32) * ((H + 1 + 31) / 32) : 0;
+    a.n2 = ((Z + 1 + 31) / 32) * ((H + 31) / 32);
+    a.n3 = ((H + 1 + 31) / 32) * ((2 * Z + 31) / 32);
+    {
+        const size_t total = (size_t)(I + 1) * (H / 4);
+        size_t gx = (total + NT - 1) / NT;
+        if (gx > 262144) gx = 262144;
+        a.n4 = (int)gx;
+    }
+    a.n5 = with_dec1 ? 1 : 0;
+    a.dlog = w.dlog; a.h2 = acts->h2; a.z = acts->z; a.da2 = w.da2; a.h1 = acts->h1; a.dmlv = w.dmlv; a.G = w.gq0;
+    a.slot = slot; a.rowout = w.rowout; a.cnt = o->cnt; a.anneal = o->anneal; a.lam = o->gan_lambda;
+    a.loss_out = w.scal; a.loss_out2 = loss_out;
+    const Probe pr{o->probe, st};
+    pr.before(LTG_K_G_TAIL);
+    const dim3 g(a.n1 + a.n2 + a.n3 + a.n4 + a.n5);
+    if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_g_tail<true>, g, dim3(NT), 0, st, a, *gen, ad);
+    else hipLaunchKernelGGL(fk_g_tail<false>, g, dim3(NT), 0, st, a, *gen, ad);
+    pr.after(LTG_K_G_TAIL);
+}
+
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
                             const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
@@ -2163,6 +2294,16 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         prs.after(LTG_K_DEC1_BWD_ADAM);
     };
     launch_dw();
+    if (mid_fast(cfg, B)) {
+        // dz -> dh1 -> sparse W_q0 gradient, then every remaining Adam update (W_p0, W_q1, W_q0 + biases) in ONE launch
+        const Probe pf{o->probe, st};
+        LTG_PROBED(pf, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
+                                                    o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
+        LTG_PROBED(pf, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
+        g_enc0_grad(cfg, bt, o, acts, w, st);
+        g_tail(cfg, gen, bt, o, acts, w, ad, g_slot_map(cfg, bt, w, st), false, nullptr, st);
+        return check_launch();
+    }
     const Probe pc{o->probe, s_chain}, pw{o->probe, s_wg};
     pc.before(LTG_K_DZ);
 #define LTG_V2(KERNEL, ...)                                       \
@@ -2241,6 +2382,31 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     }
     fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st);
     fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
+    if (small_fast(cfg, B)) {
+        // small item slab: a row's softmax statistics, loss terms and dlogits need no other row -> one launch per stage,
+        // ten launches per step: enc0, enc1, dec0, dec1 | row softmax + dlogits, dh2, dz, dh1, sparse W_q0 gradient, Adam tail
+        const int I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
+        const Probe pr{o->probe, st};
+        if (nf > 0 && !fork) {
+            PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
+            DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
+            disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
+        }
+        if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
+        LTG_PROBED(pr, LTG_K_ROW_DLOGITS, hipLaunchKernelGGL(fk_row_dlogits, dim3(B), dim3(NT), 0, st, B, I, bt->indptr, bt->indices, bt->values, acts->logits,
+                                                             acts->kl_rows, w.y, nf, o->cnt, o->gan_lambda, fake->row, fake->niche, fake->pop, w.dlog,
+                                                             acts->lse, w.rowout));
+        pr.before(LTG_K_DH2);
+        if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_dh2<true>, grid2(H, B, 16, 16), dim3(NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
+        else hipLaunchKernelGGL(fk_dh2<false>, grid2(H, B, 16, 16), dim3(NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
+        pr.after(LTG_K_DH2);
+        LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
+                                                    o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
+        LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
+        g_enc0_grad(cfg, bt, o, acts, w, st);
+        g_tail(cfg, gen, bt, o, acts, w, make_adam(cfg, o->adam_t), g_slot_map(cfg, bt, w, st), true, loss_out, st);
+        return check_launch();
+    }
     g_row_partial(cfg, bt, fake, acts, w.rowpart, st, w.segpart);
     if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
     // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)

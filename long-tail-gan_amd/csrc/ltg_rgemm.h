@@ -1,0 +1,193 @@
+// Register-resident MFMA GEMM block for the latency-bound shapes of the path (gfx950, wave64).
+//
+// The middle layers of the generator (100 x 600 x 400 ...), the discriminator layers (1 800 x 400 x 300 ...) and every
+// weight-gradient product of a 100-user batch are far too small to be bandwidth- or MFMA-bound: a launch lasts as long
+// as its longest chain of DEPENDENT memory round trips.  The LDS-staged template of ltg_gemm.h pays one round trip per
+// K tile (load -> barrier -> LDS -> MFMA, 3-5 times per workgroup); this block pays ONE: every operand element a wave
+// needs is requested up front, straight into registers in MFMA fragment order, the MFMAs run as the data lands, and the
+// only barrier is the final meeting of the K slices.
+//
+//   C[m][n] = sum_k A(m, k) * B(k, n),   v_mfma_f32_16x16x4_f32 (exact fp32 fma chain; operands that the decoder GEMMs
+//   round to bf16 are rounded by their loaders: bf16 x bf16 products are exact in fp32, so this equals the bf16 MFMA with
+//   fp32 accumulation up to summation order)
+//
+// Geometry: a 256-thread workgroup = 4 waves arranged WM x WN x WK; a wave owns (16 TM) x (16 TN) outputs and one of WK
+// slices of K; the WK partial tiles meet in LDS and the epilogue walks the (16 TM WM) x (16 TN WN) tile row-major.
+// K is cut into blocks of 16: lane (r = l & 15, q = l >> 4) fetches k = 16 jb + 4 q .. + 3 of its row (A) / column (B),
+// and step j = 0..3 of the block feeds element j of both fragments to one MFMA -- the k -> (lane, step) map is a
+// permutation both operands share, so 16 bytes per lane and access serve four MFMAs.
+//
+// Operand functors come in pairs (no branches; the block clamps indices into range, mirrors rows / columns beyond M / N onto
+// the last one -- the epilogue skips them -- and zeroes the A fragment of k blocks beyond K):
+//   a_ld(i, m, k) -> RAW {A(m,k), A(m,k+1), A(m,k+2), A(m,k+3)}: memory requests only, no arithmetic on what they return
+//   a_xf(raw, i, m, k) -> the operand values (rounding, scaling, masks, ones-augmentation)           same for b_ld(i, k, n) / b_xf
+//   with k % 4 == 0 and i = the index of the k block within the pass.  The split is what makes "one round trip" real:
+//   phase 1 of a pass holds nothing but address arithmetic and loads, a scheduling barrier closes it, and only then do the
+//   transforms and MFMAs consume the registers.  (With the arithmetic next to its load the compiler waits after every
+//   load -- vmcnt(0) fourteen times per pass in the first version of the discriminator's second layer.)
+//   When K % 4 != 0 (K = pair rows / batch rows) the functors clamp the addresses of elements with k + j >= K and a_xf
+//   zeroes them.
+//   epi(m, n, value, in_range) is called by every thread the same number of times (in_range = m < M && n < N), so it may
+//   use wave shuffles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ltg_gemm.h"
+
+__device__ __forceinline__ ltg_f32x4 ltg_ld4(const float* __restrict__ p) { return *reinterpret_cast<const ltg_f32x4*>(p); }
+// four elements of a strided column: p[0], p[s], p[2s], p[3s]
+__device__ __forceinline__ ltg_f32x4 ltg_ld4s(const float* __restrict__ p, size_t s) { return ltg_f32x4{p[0], p[s], p[2 * s], p[3 * s]}; }
+__device__ __forceinline__ float ltg_bf16r(float x) { return __uint_as_float((unsigned)ltg_f2bf(x) << 16); }
+__device__ __forceinline__ ltg_f32x4 ltg_bf16r4(ltg_f32x4 v) { return ltg_f32x4{ltg_bf16r(v[0]), ltg_bf16r(v[1]), ltg_bf16r(v[2]), ltg_bf16r(v[3])}; }
+
+template <int TM, int TN, int WM, int WN, int WK>
+struct LtgRg {
+    static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+    static constexpr int LDC = BN + 4;
+    static constexpr int LDS_FLOATS = WK * BM * LDC;
+    // row of tile tm this lane loads for operand A (unclamped)
+    static __device__ __forceinline__ int row(int m0, int tm) {
+        const int w = threadIdx.x >> 6, wm = w / (WK * WN);
+        return m0 + (wm * TM + tm) * 16 + (threadIdx.x & 15);
+    }
+    // first k of block i of this lane's K slice (single pass), clamped like the block clamps it
+    static __device__ __forceinline__ int kc(int K, int i) {
+        const int w = threadIdx.x >> 6, wk = w % WK, q = (threadIdx.x & 63) >> 4;
+        const int per = (((K + 15) >> 4) + WK - 1) / WK;
+        return min(16 * (wk * per + i) + 4 * q, K >= 4 ? ((K - 1) & ~3) : 0);
+    }
+    static __device__ __forceinline__ int col(int n0, int tn) {
+        const int w = threadIdx.x >> 6, wn = (w / WK) % WN;
+        return n0 + (wn * TN + tn) * 16 + (threadIdx.x & 15);
+    }
+};
+
+// NBLK: 16-deep k blocks a wave keeps in flight at once (registers: NBLK * (TM + TN) * 4).  K slices longer than NBLK
+// blocks take several passes (one memory round trip each).
+// Product phase: leaves the WK partial tiles in LDS ([WK][BM][LDC]) behind a barrier.
+struct LtgXfId {
+    __device__ __forceinline__ ltg_f32x4 operator()(ltg_f32x4 v, int, int, int) const { return v; }
+};
+
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF>
+__device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds) {
+    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+    typedef LtgRg<TM, TN, WM, WN, WK> G;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
+    const int nblk = (K + 15) >> 4;
+    const int per = (nblk + WK - 1) / WK;
+    const int Kc = K >= 4 ? ((K - 1) & ~3) : 0;   // start of the last (possibly partial) group of 4
+    int am[TM], bn[TN];
+    bool aok[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + (wm * TM + tm) * 16 + r;
+        aok[tm] = m < M;
+        am[tm] = min(m, M - 1);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bn[tn] = min(n0 + (wn * TN + tn) * 16 + r, N - 1);
+    ltg_f32x4 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < per; base += NBLK) {
+        ltg_f32x4 ra[NBLK][TM], rb[NBLK][TN];
+        // phase 1: requests only
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int kc = min(16 * (wk * per + base + i) + 4 * q, Kc);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) ra[i][tm] = a_ld(i, am[tm], kc);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) rb[i][tn] = b_ld(i, kc, bn[tn]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: transforms and MFMAs, block by block as the data lands
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int k = 16 * (wk * per + base + i) + 4 * q;
+            const bool ok = base + i < per && k < K;
+            const int kc = min(k, Kc);
+            ltg_f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const ltg_f32x4 v = a_xf(ra[i][tm], i, am[tm], kc);
+                const bool o = ok && aok[tm];
+                av[tm] = ltg_f32x4{o ? v[0] : 0.f, o ? v[1] : 0.f, o ? v[2] : 0.f, o ? v[3] : 0.f};
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[tn] = b_xf(rb[i][tn], i, kc, bn[tn]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    float* mine = lds + wk * (G::BM * G::LDC);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                mine[((wm * TM + tm) * 16 + 4 * q + x) * G::LDC + (wn * TN + tn) * 16 + r] = acc[tm][tn][x];
+    __syncthreads();
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class EF>
+__device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds) {
+    typedef LtgRg<TM, TN, WM, WN, WK> G;
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
+    const int tid = threadIdx.x;
+    constexpr int NE = G::BM * G::BN;
+    static_assert(NE % 256 == 0, "tile must divide over 256 threads");
+#pragma unroll
+    for (int e = 0; e < NE / 256; ++e) {
+        const int id = tid + 256 * e;
+        const int mm = id / G::BN, nn = id % G::BN;
+        float v = lds[mm * G::LDC + nn];
+#pragma unroll
+        for (int s = 1; s < WK; ++s) v += lds[s * (G::BM * G::LDC) + mm * G::LDC + nn];
+        const int m = m0 + mm, n = n0 + nn;
+        epi(m, n, v, m < M && n < N);
+    }
+}
+
+// The same block with a float4 epilogue: epi4(pre, m, n, value4, in_range) with n % 4 == 0; in_range = m < M && n < N (a
+// ragged last group -- N % 4 != 0 -- is the caller's business).  pre = prefetch(m, n, in_range) is evaluated for the same
+// (m, n) BEFORE the product: the epilogue's own operands (theta / m / v of an Adam update) are requested first, so the
+// whole workgroup costs one memory round trip.
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class PF, class EF>
+__device__ __forceinline__ void ltg_rgemm_v4(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, PF prefetch, EF epi4,
+                                             float* __restrict__ lds) {
+    typedef LtgRg<TM, TN, WM, WN, WK> G;
+    const int tid = threadIdx.x;
+    constexpr int NE4 = G::BM * G::BN / 4;
+    constexpr int NP = (NE4 + 255) / 256;
+    static_assert(NE4 % 256 == 0, "tile must divide over 256 threads in float4");
+    decltype(prefetch(0, 0, false)) pre[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+        const int id = tid + 256 * e;
+        const int mm = id / (G::BN / 4), nn = (id % (G::BN / 4)) * 4;
+        pre[e] = prefetch(m0 + mm, n0 + nn, m0 + mm < M && n0 + nn < N);
+    }
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+        const int id = tid + 256 * e;
+        const int mm = id / (G::BN / 4), nn = (id % (G::BN / 4)) * 4;
+        ltg_f32x4 v = *reinterpret_cast<const ltg_f32x4*>(&lds[mm * G::LDC + nn]);
+#pragma unroll
+        for (int s = 1; s < WK; ++s) v += *reinterpret_cast<const ltg_f32x4*>(&lds[s * (G::BM * G::LDC) + mm * G::LDC + nn]);
+        epi4(pre[e], m0 + mm, n0 + nn, v, m0 + mm < M && n0 + nn < N);
+    }
+}

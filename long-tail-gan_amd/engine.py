@@ -206,11 +206,24 @@ class Engine:
         host = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
         host[6] = host[6].reshape(-1)                                # w4 [h3,1] -> [h3]
         host[7] = host[7].reshape(-1)
-        self.d_p = [torch.from_numpy(a).to(dev).contiguous() for a in host]
-        self.d_m = [torch.zeros_like(t) if m is None else torch.as_tensor(m[i], dtype=torch.float32).reshape(t.shape).to(dev)
-                    for i, t in enumerate(self.d_p)]
-        self.d_v = [torch.zeros_like(t) if v is None else torch.as_tensor(v[i], dtype=torch.float32).reshape(t.shape).to(dev)
-                    for i, t in enumerate(self.d_p)]
+        # the eight trainable tensors (and each of their Adam moments) live back to back in ONE buffer, padded to whole float4:
+        # the library then runs the optimiser as a single flat 16-byte-per-lane sweep; d_p / d_m / d_v are views into it
+        sizes = [a.size for a in host]
+        total = (sum(sizes) + 3) // 4 * 4
+
+        def flat(arrs):
+            buf = torch.zeros(total, dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for a, ref in zip(arrs, host):
+                n = ref.size
+                if a is not None:
+                    buf[off:off + n] = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).reshape(-1).to(dev)
+                views.append(buf[off:off + n].view(ref.shape))
+                off += n
+            return buf, views
+        self.d_flat_p, self.d_p = flat(host)
+        self.d_flat_m, self.d_m = flat([None] * 8 if m is None else list(m))
+        self.d_flat_v, self.d_v = flat([None] * 8 if v is None else list(v))
         arr = lambda ts: (cabi.vp * 8)(*[_ptr(t) for t in ts])
         self.disc_c = cabi.ltg_disc_state(_ptr(self.d_emb), arr(self.d_p), arr(self.d_m), arr(self.d_v))
 

@@ -59,12 +59,25 @@ class TfAdam:
 
 
 class CpuPort:
-    def __init__(self, idx, h=(100, 150, 250, 300), lr=1e-4, batch_size=100, seed=0, threads=None):
+    def __init__(self, idx, h=(100, 150, 250, 300), lr=1e-4, batch_size=100, seed=0, threads=None, init=None):
+        """init: optional (generator arrays in TF shapes [W_q0 [I,600], W_q1, W_p0, W_p1 [600,I], b_q0, b_q1, b_p0, b_p1],
+        emb [I,h0], discriminator arrays [w1, b1, w2, b2, w3, b3, w4 [h3,1], b4]) -- so that a device run can start from the
+        very same variables (tests/golden/make_ndcg_gate.py)."""
         if threads:
             torch.set_num_threads(threads)
         self.idx, self.BS = idx, batch_size
         I = idx.n_items
         g = torch.Generator().manual_seed(seed)
+        if init is not None:
+            ga, emb, da = init
+            f = lambda a: torch.tensor(np.asarray(a, dtype=np.float32)).requires_grad_()
+            self.g_params = [f(a) for a in ga]
+            self.emb = torch.tensor(np.asarray(emb, dtype=np.float32))
+            self.d_params = [f(a) for a in da]
+            self.opt = TfAdam(lr)
+            self.update_count = 0.0
+            self.valid = set(np.nonzero(idx.valid_item)[0].tolist())
+            return
         xav = lambda a, b: ((torch.rand(a, b, generator=g) * 2 - 1) * np.sqrt(6.0 / (a + b))).requires_grad_()
         tn = lambda *s, std: (torch.randn(*s, generator=g).clamp_(-2, 2) * std).requires_grad_()
         self.g_params = [xav(I, 600), xav(600, 400), xav(200, 600), xav(600, I), tn(600, std=1e-3), tn(400, std=1e-3),
@@ -100,6 +113,23 @@ class CpuPort:
         b = dr(torch.tanh(self.emb[nic] @ w2 + b2))
         c = dr(torch.tanh(torch.cat([a, b], 1) @ w3 + b3))
         return torch.sigmoid(c @ w4 + b4)
+
+    @torch.no_grad()
+    def validate(self, tr_csr, te_csr, chunk=2000):
+        """train.py:333-348: forward with dropout ON (keep_prob_ph is never fed, Q3), fold-in items -> -inf, NDCG@100 /
+        Recall@20 / Recall@50 (eval_functions.py:11-62 restated in oracle/ltg_oracle.py)."""
+        from . import ltg_oracle as O
+        nd, r20, r50 = [], [], []
+        for lo in range(0, tr_csr.shape[0], chunk):
+            Xn = np.asarray(tr_csr[lo:lo + chunk].toarray(), dtype=np.float32)
+            probs, _ = self.vae(torch.from_numpy(Xn), 0.75, 0.0, 1.0)
+            pred = probs.numpy().astype(np.float64)
+            pred[Xn > 0] = -np.inf
+            held = np.asarray(te_csr[lo:lo + chunk].toarray())
+            nd.append(O.ndcg_binary_at_k(pred, held, 100))
+            r20.append(O.recall_at_k(pred, held, 20))
+            r50.append(O.recall_at_k(pred, held, 50))
+        return float(np.mean(np.concatenate(nd))), float(np.mean(np.concatenate(r20))), float(np.mean(np.concatenate(r50)))
 
     # --- one "mini epoch" over batches [b0, b1): phases C, D x S, G x S (train.py:192-329)
     def run(self, b0, b1, S):

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ndcg_gate.npz -- the NDCG@100 parity gate of SURVEY 8/d6: the faithful CPU restatement of the
+reference's training loop (oracle/cpu_port.py: torch-CPU fp32, dense feeds, autograd, np.random sampling exactly like
+sample.py:40-67 / train.py:212-251) trained on Askubuntu_Sample with config.ini's defaults (BATCH_SIZE 100, lr 1e-4,
+GANLAMBDA 1, h = 100/150/250/300, S = NUM_EPOCH/8 = 10 sub-epochs) for EPOCHS global epochs from SEEDS different
+initialisations; validation NDCG@100 / Recall@20 / Recall@50 after every global epoch (train.py:333-348).
+
+The device test (tests/test_gpu_ndcg_gate.py) starts from the same initial variables (ltgan.engine.init_*_host(seed)),
+runs the same schedule and compares the mean over the seeds of the final NDCG@100 within +-0.002.  The random streams
+differ by construction (np.random / torch on the CPU, the counter RNG on the device; the reference itself is unseeded, Q13),
+so the gate is statistical, as SURVEY 8/d6 defines it.
+
+Pure restatement output: no reference source is read, no GPU is used.
+usage: python tests/golden/make_ndcg_gate.py [threads]     (about 1 minute per global epoch on 8 cores)
+"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from ltgan import data_processing as dp  # noqa: E402
+from ltgan.dataset import IndexData, materialize_askubuntu  # noqa: E402
+from ltgan.engine import init_discriminator_host, init_generator_host  # noqa: E402
+from oracle.cpu_port import CpuPort  # noqa: E402
+
+SEEDS, EPOCHS, S, HS, LR, BS = (11, 12, 13, 14), 10, 10, (100, 150, 250, 300), 1e-4, 100
+
+
+def initial_variables(n_items, seed):
+    """engine layout -> the TF shapes CpuPort trains in"""
+    g = init_generator_host(n_items, 600, 200, seed)
+    emb, d = init_discriminator_host(n_items, HS, seed + 1000)
+    g_tf = [g[0], g[1], g[2], np.ascontiguousarray(g[3].T), g[4], g[5], g[6], g[7]]
+    d_tf = [d[0], d[1], d[2], d[3], d[4], d[5], d[6].reshape(-1, 1), d[7]]
+    return g_tf, emb, d_tf
+
+
+if __name__ == "__main__":
+    threads = int(sys.argv[1]) if len(sys.argv) > 1 else None
+    d = tempfile.mkdtemp()
+    materialize_askubuntu(os.path.join(ROOT, "tests", "golden", "askubuntu_raw.npz"), d)
+    idx = IndexData.from_dir(d)
+    vtr, vte, _ = dp.load_tr_te_data(os.path.join(d, "validation_tr.csv"), os.path.join(d, "validation_te.csv"), idx.n_items)
+    nb = (idx.N + BS - 1) // BS
+    curves = np.zeros((len(SEEDS), EPOCHS, 3))
+    t0 = time.time()
+    for si, seed in enumerate(SEEDS):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        port = CpuPort(idx, h=HS, lr=LR, batch_size=BS, threads=threads, init=initial_variables(idx.n_items, seed))
+        for e in range(EPOCHS):
+            port.run(0, nb, S)
+            curves[si, e] = port.validate(vtr, vte)
+            print("seed", seed, "epoch", e, "ndcg/r20/r50", curves[si, e], "%.0fs" % (time.time() - t0), flush=True)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ndcg_gate.npz"), seeds=np.array(SEEDS[:si + 1]), epochs=EPOCHS, S=S,
+                            hs=np.array(HS), lr=LR, batch_size=BS, curves=curves[:si + 1], d_seed_offset=1000)
