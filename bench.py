@@ -83,6 +83,15 @@ class KernelProfiler:
         from ltgan._hip import EventPair
         self.cabi, self.EventPair = cabi, EventPair
         self.eng, self.tr, self.data, self.a = eng, tr, data, args
+        # the kernels the active code path launches (csrc/ltg_kernels.hip: fast_on / small_fast / mid_fast)
+        fast = (args.variant & 262144) == 0
+        small = fast and not eng.sharded and eng.I <= 4096 and eng.I % 4 == 0
+        if small:
+            self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "row_dlogits", "dh2", "dz", "dh1", "g_tail"]
+        elif fast:
+            self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "dh1", "enc0_grad", "g_tail"]
+        else:
+            self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "wgrad_p0", "dh1", "wgrad_q1", "enc0_bwd_adam"]
         self.samples = []        # (event pair, n_pairs, nnz) recorded in the timed region
         self.pool = []           # event pairs created BEFORE the timed region (reserve())
 
@@ -138,8 +147,8 @@ class KernelProfiler:
             "row_dlogits": (0, 8 * B * I),
             "enc0_grad": (2 * sh["nnz"] * H, 4 * (sh["nnz"] * H + min(I, sh["nnz"]) * H)),
             # one launch = every Adam update of the generator: 24 B per parameter + the operands of the three gradient products
-            "g_tail": (2 * B * ((I if I <= 4096 else 0) * (H + 1) + (Z + 1) * H + (H + 1) * 2 * Z),
-                       24 * (((2 * H + 1) * I if I <= 4096 else (H + 1) * I) + H * 2 * Z + Z * H + 2 * H + 2 * Z) + 4 * B * (I + 3 * H + 3 * Z)),
+            "g_tail": (2 * B * ((2 * I if I <= 4096 else 0) * (H + 1) + (Z + 1) * H + (H + 1) * 2 * Z),
+                       24 * (((2 * H + 1) * I if I <= 4096 else (H + 1) * I) + H * 2 * Z + Z * H + 2 * H + 2 * Z) + 4 * B * (2 * I + 3 * H + 3 * Z)),
         }
         return w[name]
 

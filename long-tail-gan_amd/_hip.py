@@ -39,9 +39,8 @@ class EventPair:
     def elapsed_ms(self):
         h = _lib()
         ms = C.c_float()
-        if h.hipEventSynchronize(self.stop) != 0:
-            return None
-        if h.hipEventElapsedTime(C.byref(ms), self.start, self.stop) != 0:
+        if h.hipEventSynchronize(self.stop) != 0 or h.hipEventElapsedTime(C.byref(ms), self.start, self.stop) != 0:
+            h.hipGetLastError()      # an event that was never recorded: clear the (sticky) error, report "no sample"
             return None
         return float(ms.value)
 

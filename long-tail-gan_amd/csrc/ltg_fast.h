@@ -14,118 +14,97 @@
 
 typedef LtgRg<1, 1, 1, 1, 4> Rg16;    // 16 x 16 tile, four K slices
 typedef LtgRg<2, 2, 1, 1, 4> Rg32k;   // 32 x 32 tile, four K slices (each wave the whole tile)
-typedef LtgRg<1, 2, 1, 1, 4> Rg16x32; // 16 x 32 tile, four K slices
 typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over the whole K
 
 // ---------------------------------------------------------------------------------------------------------------------
 // generator middle layers (MultiVAE.py:152-172)
 // ---------------------------------------------------------------------------------------------------------------------
 
-// enc-1 (MultiVAE.py:152,157-158): mulv = h1 . W_q1 + b_q1        [B][2Z]
-__global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z2, const float* __restrict__ h1, const float* __restrict__ Wq1,
-                                              const float* __restrict__ bq1, float* __restrict__ mulv) {
-    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+// enc-1 + reparameterisation (MultiVAE.py:152,157-162, :178-181): mulv = h1 . W_q1 + b_q1 [B][2Z] and
+// z = mu + is_training * eps * exp(logvar / 2) [B][Z].  A workgroup owns 16 rows x (16 columns of mu AND the same 16 columns
+// of logvar): logical tile column c < 16 is column n0 + c, c >= 16 is column Z + n0 + (c - 16), so the epilogue holds both
+// halves of a z value in two lanes 16 apart -- z is computed once per element, eps is drawn once per element.
+typedef LtgRg<1, 2, 1, 1, 4> Rg16x32;   // 16 x 32 tile, four K slices
+__global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* __restrict__ h1, const float* __restrict__ Wq1,
+                                              const float* __restrict__ bq1, const float* __restrict__ eps_in, float is_training,
+                                              uint64_t seed, uint64_t step, float* __restrict__ mulv, float* __restrict__ z) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, Z2 = 2 * Z;
+    auto col = [=] __device__(int c) { return min(n0 + (c & 15), Z - 1) + (c >> 4) * Z; };   // logical tile column -> column of mulv
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(h1 + (size_t)m * H + k); };
-    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wq1 + (size_t)k * Z2 + n, Z2); };
-    auto epi = [=] __device__(int m, int n, float v, bool ok) {
-        if (ok) mulv[(size_t)m * Z2 + n] = v + bq1[n];
+    auto b_ld = [=] __device__(int, int k, int c) { return ltg_ld4s(Wq1 + (size_t)k * Z2 + col(c), Z2); };
+    // the epilogue's own operands are requested BEFORE the product (thread -> output map of ltg_rgemm: id = tid + 256 e,
+    // row id / 32, logical column id % 32 = tid % 32), so the epilogue adds no round trip
+    const float biasv = bq1[col(threadIdx.x & 31)];
+    float epsv[2] = {0.f, 0.f};
+    if (is_training != 0.f && eps_in) {   // uniform
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            epsv[e] = eps_in[(size_t)min(m0 + (int)(threadIdx.x + 256 * e) / 32, B - 1) * Z + min(n0 + (int)(threadIdx.x & 15), Z - 1)];
+    }
+    auto epi = [=] __device__(int ei, int m, int c, float v, bool) {
+        const int j = n0 + (c & 15);
+        const bool ok = m < B && j < Z;
+        const bool islv = c >= 16;
+        const float mine = v + biasv;
+        const float other = __shfl_xor(mine, 16);      // mu <-> logvar of the same z column
+        if (ok) mulv[(size_t)m * Z2 + (islv ? Z : 0) + j] = mine;
+        if (ok && !islv) {
+            float e = 0.f;
+            if (is_training != 0.f)   // uniform
+                e = eps_in ? epsv[ei] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)m * Z + j);
+            z[(size_t)m * Z + j] = mine + is_training * e * expf(0.5f * other);
+        }
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, Z2, H, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    // the block sees logical columns [0, 32) of this tile (all "in range"; the real bounds are the functors' business)
+    ltg_rgemm<1, 2, 1, 1, 4, 10>(B, 32, H, m0, 0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
 }
 
-// reparameterisation + KL + dec-0 (MultiVAE.py:160-162, :178-181, :168-172): z = mu + is_training * eps * exp(logvar / 2)
-// is built by the A-operand loader (every column tile rebuilds the z of its 16 rows: 200 values per row); the
-// column-tile-0 workgroups also store z (the weight gradient of W_p0 reads it) and the per-row KL;
-// h2 = tanh(z . W_p0 + b_p0).  The product is the TM = TN = 1, WK = 4 form of ltg_rgemm_product written out, because the
-// loader's side effects (z store, KL sum) must know whether a visit is a real one or a clamped duplicate.
-__global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* __restrict__ mulv, const float* __restrict__ eps_in,
-                                              float is_training, uint64_t seed, uint64_t step, const float* __restrict__ Wp0,
-                                              const float* __restrict__ bp0, float* __restrict__ z, float* __restrict__ kl_rows,
+// dec-0 (MultiVAE.py:168-172): h2 = tanh(z . W_p0 + b_p0); the column-tile-0 workgroups also add up the per-row KL
+// (MultiVAE.py:161) from mulv.
+__global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* __restrict__ z, const float* __restrict__ mulv,
+                                              const float* __restrict__ Wp0, const float* __restrict__ bp0, float* __restrict__ kl_rows,
                                               float* __restrict__ h2) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    __shared__ float klp[4][16];
-    constexpr int NB = 4, LDC = Rg16::LDC;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-    const bool writer = blockIdx.x == 0;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-    const bool myrow = m0 + r < B;
-    const int nblk = (Z + 15) >> 4, per = (nblk + 3) / 4, Kc = (Z - 1) & ~3;
-    const int am = min(m0 + r, B - 1), bn = min(n0 + r, H - 1);
-    const float* mrow = mulv + (size_t)am * 2 * Z;
     float kl = 0.f;
-    ltg_f32x4 acc = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < per; base += NB) {
-        ltg_f32x4 rmu[NB], rlv[NB], re[NB], bv[NB];
-        // phase 1: requests only
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int kc = min(16 * (w * per + base + i) + 4 * q, Kc);
-            rmu[i] = ltg_ld4(mrow + kc);
-            rlv[i] = ltg_ld4(mrow + Z + kc);
-            bv[i] = ltg_ld4s(Wp0 + (size_t)kc * H + bn, H);
-            re[i] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (is_training != 0.f && eps_in) re[i] = ltg_ld4(eps_in + (size_t)am * Z + kc);   // uniform
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 2: z, KL, MFMAs
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int k = 16 * (w * per + base + i) + 4 * q;
-            const bool o = base + i < per && k < Z && myrow;
-            const int kc = min(k, Kc);
-            ltg_f32x4 e = re[i];
-            if (is_training != 0.f && !eps_in) {   // uniform
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)am * Z + kc + j);
-            }
-            ltg_f32x4 zz;
-            float kk = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                zz[j] = rmu[i][j] + is_training * e[j] * expf(0.5f * rlv[i][j]);
-                kk += 0.5f * (-rlv[i][j] + expf(rlv[i][j]) + rmu[i][j] * rmu[i][j] - 1.f);
-            }
-            if (writer && o) *reinterpret_cast<ltg_f32x4*>(z + (size_t)am * Z + kc) = zz;
-            kl += o ? kk : 0.f;
-            const ltg_f32x4 av = ltg_f32x4{o ? zz[0] : 0.f, o ? zz[1] : 0.f, o ? zz[2] : 0.f, o ? zz[3] : 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[i][j], acc, 0, 0, 0);
+    if (blockIdx.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns
+        const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        const float* mrow = mulv + (size_t)min(m0 + rr, B - 1) * 2 * Z;
+        for (int j = cc; j < Z; j += 16) {
+            const float mu = mrow[j], lv = mrow[Z + j];
+            kl += 0.5f * (-lv + expf(lv) + mu * mu - 1.f);
         }
     }
-    float* mine = lds + w * (16 * LDC);
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(z + (size_t)m * Z + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wp0 + (size_t)k * H + n, H); };
+    const float biasv = bp0[min(n0 + (int)(threadIdx.x & 15), H - 1)];
+    auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
+        if (ok) h2[(size_t)m * H + n] = tanhf(v + biasv);
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 4>(B, H, Z, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    if (blockIdx.x == 0) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) mine[(4 * q + x) * LDC + r] = acc[x];
-    // KL of row r: the four q-lanes of a wave, then the four waves (fixed order: reproducible)
-    kl += __shfl_xor(kl, 16);
-    kl += __shfl_xor(kl, 32);
-    if (q == 0) klp[w][r] = kl;
-    __syncthreads();
-    {
-        const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
-        const float v = lds[mm * LDC + nn] + lds[16 * LDC + mm * LDC + nn] + lds[32 * LDC + mm * LDC + nn] + lds[48 * LDC + mm * LDC + nn];
-        const int m = m0 + mm, n = n0 + nn;
-        if (m < B && n < H) h2[(size_t)m * H + n] = tanhf(v + bp0[n]);
+        for (int o = 8; o > 0; o >>= 1) kl += __shfl_xor(kl, o);    // the 16 lanes of a row are consecutive
+        if ((threadIdx.x & 15) == 0 && m0 + (threadIdx.x >> 4) < B) kl_rows[m0 + (threadIdx.x >> 4)] = kl;
     }
-    if (writer && threadIdx.x < 16 && m0 + threadIdx.x < B)
-        kl_rows[m0 + threadIdx.x] = klp[0][threadIdx.x] + klp[1][threadIdx.x] + klp[2][threadIdx.x] + klp[3][threadIdx.x];
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)          [B][2Z]
-__global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
-                                            const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
-                                            float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
-    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+__device__ __forceinline__ void dz_tile(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
+                                        const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training, float anneal,
+                                        uint64_t seed, uint64_t step, float* __restrict__ dmlv, int m0, int n0, float* __restrict__ lds) {
     const float invB = 1.f / (float)B;
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(da2 + (size_t)m * H + k); };
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wp0 + (size_t)n * H + k); };
-    auto epi = [=] __device__(int m, int n, float dz, bool ok) {
+    const int pm = min(m0 + (int)(threadIdx.x >> 4), B - 1), pn = min(n0 + (int)(threadIdx.x & 15), Z - 1);   // this thread's output
+    const float mu = mulv[(size_t)pm * 2 * Z + pn], lv = mulv[(size_t)pm * 2 * Z + Z + pn];
+    const float epsv = (is_training != 0.f && eps_in) ? eps_in[(size_t)pm * Z + pn] : 0.f;
+    auto epi = [=] __device__(int, int m, int n, float dz, bool ok) {
         if (!ok) return;
-        const float mu = mulv[(size_t)m * 2 * Z + n], lv = mulv[(size_t)m * 2 * Z + Z + n];
         float e = 0.f;
         if (is_training != 0.f)
-            e = eps_in ? eps_in[(size_t)m * Z + n] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)m * Z + n);
+            e = eps_in ? epsv : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)m * Z + n);
         dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
         dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
     };
@@ -133,18 +112,27 @@ __global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __
 }
 
 // dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)                                      [B][H]
+__device__ __forceinline__ void dh1_tile(int B, int H, int Z2, const float* __restrict__ dmlv, const float* __restrict__ Wq1,
+                                         const float* __restrict__ h1, float* __restrict__ da1, int m0, int n0, float* __restrict__ lds) {
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dmlv + (size_t)m * Z2 + k); };
+    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wq1 + (size_t)n * Z2 + k); };
+    const float t = h1[(size_t)min(m0 + (int)(threadIdx.x >> 4), B - 1) * H + min(n0 + (int)(threadIdx.x & 15), H - 1)];
+    auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
+        if (ok) da1[(size_t)m * H + n] = v * (1.f - t * t);
+    };
+    ltg_rgemm<1, 1, 1, 1, 4, 7>(B, H, Z2, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+}
+
+__global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
+                                            const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
+                                            float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    dz_tile(B, Z, H, da2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, blockIdx.y * 16, blockIdx.x * 16, lds);
+}
 __global__ __launch_bounds__(NT) void fk_dh1(int B, int H, int Z2, const float* __restrict__ dmlv, const float* __restrict__ Wq1,
                                              const float* __restrict__ h1, float* __restrict__ da1) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dmlv + (size_t)m * Z2 + k); };
-    auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wq1 + (size_t)n * Z2 + k); };
-    auto epi = [=] __device__(int m, int n, float v, bool ok) {
-        if (!ok) return;
-        const float t = h1[(size_t)m * H + n];
-        da1[(size_t)m * H + n] = v * (1.f - t * t);
-    };
-    ltg_rgemm<1, 1, 1, 1, 4, 7>(B, H, Z2, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    dh1_tile(B, H, Z2, dmlv, Wq1, h1, da1, blockIdx.y * 16, blockIdx.x * 16, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -158,7 +146,11 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
                                                       const float* __restrict__ values, const uint8_t* __restrict__ drop_keep, float keep,
                                                       uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
                                                       const float* __restrict__ bq0, float* __restrict__ h1, float* __restrict__ row_scale,
-                                                      const float* __restrict__ row_norm2, int item_lo, int Ig, int pre_only) {
+                                                      const float* __restrict__ row_norm2, int item_lo, int Ig, int pre_only,
+                                                      float* __restrict__ xd) {
+    // xd (optional, small item slabs): the dense row  xd[b][i] = keep_bi * x_bi / (keep * ||x_b||)  of the operand this
+    // layer multiplies -- the backward forms dW_q0 = xd^T . da1 as a dense MFMA product with the very same dropout draw
+    extern __shared__ __attribute__((aligned(16))) float s_row[];   // [I] when xd, else nothing
     __shared__ __attribute__((aligned(16))) float4 s_part[ENC_NW][64];
     __shared__ int s_idx[ENC_NT];
     __shared__ float s_val[ENC_NT];
@@ -182,6 +174,9 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
     if (tid == 0 && cb == 0) row_scale[b] = scale;
     const int H4 = H >> 2;
     const int c4 = min(64 * cb + lane, H4 - 1);
+    const bool dense = xd != nullptr && cb == 0;   // uniform
+    if (dense)
+        for (int i = tid; i < I; i += ENC_NT) s_row[i] = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c0 = beg; c0 < end; c0 += ENC_NT) {
         __syncthreads();
@@ -193,6 +188,7 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
                                       : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
             s_idx[tid] = it;
             s_val[tid] = kp ? v : 0.f;
+            if (dense) s_row[it] = kp ? v * scale : 0.f;
         }
         __syncthreads();
         const int cnt = min(ENC_NT, end - c0);
@@ -232,6 +228,10 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
             o = make_float4(tanhf(t.x * scale + bb.x), tanhf(t.y * scale + bb.y), tanhf(t.z * scale + bb.z), tanhf(t.w * scale + bb.w));
         }
         *reinterpret_cast<float4*>(h1 + (size_t)b * H + c) = o;
+    }
+    if (dense) {   // (the barrier before the partial sums also ordered the scatter into s_row)
+        float* dst = xd + (size_t)b * I;
+        for (int i = 4 * tid; i < I; i += 4 * ENC_NT) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(s_row + i);   // I % 4 == 0
     }
 }
 
@@ -322,9 +322,10 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
     auto a_ld = [=] __device__(int, int, int k) { return ltg_ld4(erow + k); };
     auto a_xf = [=] __device__(ltg_f32x4 v, int, int, int) { return id >= 0 ? v : ltg_f32x4{0.f, 0.f, 0.f, 0.f}; };
     auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4s(W + (size_t)k * N + nn, N); };
-    auto epi = [=] __device__(int m, int nn, float v, bool ok) {
+    const float biasv = bias[min(n0 + (int)(threadIdx.x & 31), N - 1)];
+    auto epi = [=] __device__(int, int m, int nn, float v, bool ok) {
         if (!ok) return;
-        const float t = tanhf(v + bias[nn]);
+        const float t = tanhf(v + biasv);
         const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + coff + nn] = kp ? t / keep : 0.f;
     };
@@ -343,12 +344,13 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(A1 + (size_t)m * h12 + k); };
     auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4s(w3 + (size_t)k * h3 + nn, h3); };
     const int tile = blockIdx.x;
-    auto epi = [=] __device__(int m, int nn, float v, bool ok) {
+    const int pcol = min(n0 + (int)(threadIdx.x & 31), h3 - 1);
+    const float b3v = b3[pcol], wv = w4[pcol];
+    auto epi = [=] __device__(int, int m, int nn, float v, bool ok) {
         const int nc = min(nn, h3 - 1), mc = min(m, n - 1);
-        const float t = tanhf(v + b3[nc]);
+        const float t = tanhf(v + b3v);
         const bool kp = ok && dC.keep(mc, nc, h3, seed, LTG_STREAM_D_DROP_C, step, keep);
         const float a3 = kp ? t / keep : 0.f;
-        const float wv = w4[nc];
         if (ok) {
             A3[(size_t)m * h3 + nn] = a3;
             if (G3) G3[(size_t)m * h3 + nn] = wv * dact(a3, keep);
@@ -402,32 +404,58 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
     if (bid < nA) {
         const int tn = (h12 + 31) / 32;
         const int m0 = (bid / tn) * 32, n0 = (bid % tn) * 32;
-        if (tid < 32) {
-            float yv, ds, lr;
-            d_row_terms(pv, min(m0 + tid, n - 1), n, ntile, spart, b4v, yv, ds, lr);
-            s_ds[tid] = ds;
+        // requested up front, consumed later: the tile partials of this thread's pair row (threads 0..31) and the A1 values of
+        // the four outputs this thread finishes -- neither costs a round trip of its own
+        const int prow = min(m0 + (tid & 31), n - 1), pt = tid >> 5;            // thread -> (pair row, tile pt and pt + 8)
+        const float sp0 = spart[(size_t)min(pt, ntile - 1) * n + prow], sp1 = spart[(size_t)min(pt + 8, ntile - 1) * n + prow];
+        float a1v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int id = tid + 256 * e;
+            a1v[e] = A1[(size_t)min(m0 + id / 32, n - 1) * h12 + min(n0 + id % 32, h12 - 1)];
         }
-        __syncthreads();
+        const bool pvalid = pv.valid(prow), preal = prow < pv.nr;
+        auto mid = [=] __device__() {
+            s_lr[tid] = (pt < ntile ? sp0 : 0.f) + (pt + 8 < ntile ? sp1 : 0.f);       // ntile <= 16 (d_fast)
+            __syncthreads();
+            if (tid < 32) {
+                float sv = b4v;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sv += s_lr[32 * t + tid];
+                const float yy = 1.f / (1.f + expf(-sv));
+                s_ds[tid] = pvalid ? (preal ? -(1.f - yy) : yy) : 0.f;
+            }
+            __syncthreads();
+        };
         auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(G3 + (size_t)m * h3 + k); };
         auto a_xf = [=] __device__(ltg_f32x4 v, int, int m, int) { return v * s_ds[m - m0]; };
         auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4(w3 + (size_t)nn * h3 + k); };
-        auto epi = [=] __device__(int m, int nn, float v, bool ok) {
-            if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(A1[(size_t)m * h12 + nn], keep);
+        auto epi = [=] __device__(int e, int m, int nn, float v, bool ok) {
+            if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(a1v[e], keep);
         };
-        ltg_rgemm<2, 2, 1, 1, 4, 5>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+        ltg_rgemm<2, 2, 1, 1, 4, 5>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
         return;
     }
     bid -= nA;
     const int tmB = (h12 + 1 + 31) / 32, tnB = (h3 + 31) / 32;
     const int z = bid < nB ? bid / (tmB * tnB) : (bid - nB) / ((h3 + 2 + 31) / 32);
     const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK), K = kend - kbeg;
-    {
-        float yv, ds, lr;
-        d_row_terms(pv, min(kbeg + tid, n - 1), n, ntile, spart, b4v, yv, ds, lr);
-        s_ds[tid] = kbeg + tid < kend ? ds : 0.f;
-        s_lr[tid] = kbeg + tid < kend ? lr : 0.f;
-    }
-    __syncthreads();
+    // ds / loss term of pair row kbeg + tid: the tile partials are requested here and consumed in the product's mid hook
+    // (job B) -- after the operand requests have been issued, so the prologue costs no round trip of its own
+    const int prow = min(kbeg + tid, n - 1);
+    float sp[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sp[t] = spart[(size_t)min(t, ntile - 1) * n + prow];
+    const bool pvalid = pv.valid(prow) && kbeg + tid < kend, preal = prow < pv.nr;
+    auto rows_to_lds = [=] __device__() {
+        float sv = b4v;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sv += t < ntile ? sp[t] : 0.f;     // ntile <= 16 (d_fast)
+        const float yy = 1.f / (1.f + expf(-sv));
+        s_ds[tid] = pvalid ? (preal ? -(1.f - yy) : yy) : 0.f;
+        s_lr[tid] = pvalid ? (preal ? -logf(yy) : -logf(1.f - yy)) : 0.f;
+        __syncthreads();
+    };
     float* out = slab + (size_t)z * SP;
     if (bid < nB) {
         const int t = bid % (tmB * tnB);
@@ -457,15 +485,16 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
             for (int j = 0; j < 4; ++j) v[j] = s_ds[min(k + j, K - 1)] * x[j];
             return v;
         };
-        auto epi = [=] __device__(int m, int nn, float g, bool ok) {
+        auto epi = [=] __device__(int, int m, int nn, float g, bool ok) {
             if (!ok) return;
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_rgemm<2, 2, 1, 1, 4, 4>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds);
+        ltg_rgemm<2, 2, 1, 1, 4, 4>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
         return;
     }
     bid -= nB;
+    rows_to_lds();
     {
         // columns c < h3: dw4[c]; c == h3: db4; c == h3 + 1: the chunk's loss sum
         float (*part)[33] = reinterpret_cast<float (*)[33]>(lds);
@@ -537,7 +566,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
         for (int j = 0; j < 4; ++j) v[j] = dpre1[(size_t)(kbeg + min(k + j, K - 1)) * h12 + coff + nn];
         return v;
     };
-    auto epi = [=] __device__(int m, int nn, float g, bool ok) {
+    auto epi = [=] __device__(int, int m, int nn, float g, bool ok) {
         if (!ok) return;
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
@@ -592,8 +621,9 @@ __global__ __launch_bounds__(NT) void fk_dec1(int B, int I, int H, const float* 
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(h2 + (size_t)m * H + k); };
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wp1t + (size_t)n * H + k); };
     auto xf = [=] __device__(ltg_f32x4 v, int, int, int) { return BF ? ltg_bf16r4(v) : v; };
-    auto epi = [=] __device__(int m, int n, float v, bool ok) {
-        if (ok) logits[(size_t)m * I + n] = v + bp1[n];
+    const float biasv = bp1[min(n0 + (int)(threadIdx.x & 15), I - 1)];
+    auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
+        if (ok) logits[(size_t)m * I + n] = v + biasv;
     };
     ltg_rgemm<1, 1, 1, 1, 4, 10>(B, I, H, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
 }
@@ -603,70 +633,98 @@ __global__ __launch_bounds__(NT) void fk_dec1(int B, int I, int H, const float* 
 //   dlogits[b][i] = p * (n_b / B + c * P_b) - x_bi / B - c * p * [(b, i) in S],  c = lambda / cnt * sum_j y_j
 // rowout[b] = {neg_ll of the row, P_b = sum_{S_b} p, KL of the row, sum_j y_j}; the step's scalars are added up by the
 // tail launch.  Needs no other row's statistics, so nothing has to meet between the forward and the backward.
-constexpr int RD_MAXI = 4096;
+// three sums and a maximum over the workgroup in one exchange (two barriers)
+__device__ __forceinline__ void block_red4(float& a, float& b, float& c, float& mx, float (*red)[NT / 64]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        c += __shfl_xor(c, o);
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w] = a;
+        red[1][w] = b;
+        red[2][w] = c;
+        red[3][w] = mx;
+    }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    mx = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                      const float* __restrict__ values, const float* __restrict__ logits,
                                                      const float* __restrict__ kl_rows, const float* __restrict__ y, int nf,
                                                      const int32_t* __restrict__ cnt, float lam, const int32_t* __restrict__ f_row,
                                                      const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
                                                      float* __restrict__ dlog, float* __restrict__ lse, float* __restrict__ rowout) {
+    __shared__ float s_l[RD_MAXI];      // the row's logits (the x . logit sum gathers from here)
     __shared__ float s_x[RD_MAXI];
     __shared__ uint8_t s_s[RD_MAXI];
-    __shared__ float red[NT / 64];
+    __shared__ float red[4][NT / 64];
+    static_assert(NT / 64 == 4, "block_red4 adds four wave partials");
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = logits + (size_t)b * I;
     constexpr int PER = RD_MAXI / NT;
+    const int e0 = indptr[b], e1 = indptr[b + 1];
+    // every independent request first: the row, the fake tower's y, this thread's share of the fake-pair list
     float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + NT * j;
+        v[j] = row[min(i, I - 1)];
+    }
+    float sy = 0.f;
+    for (int q = tid; q < nf; q += NT) sy += y[q];
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = tid + NT * j;
-        v[j] = i < I ? row[min(i, I - 1)] : -INFINITY;
-        mx = fmaxf(mx, v[j]);
+        if (i < I) {
+            s_l[i] = v[j];
+            s_x[i] = 0.f;
+            s_s[i] = 0;
+            mx = fmaxf(mx, v[j]);
+        } else v[j] = -INFINITY;
     }
-    for (int j = tid; j < I; j += NT) {
-        s_x[j] = 0.f;
-        s_s[j] = 0;
-    }
-    float sy = 0.f;
-    for (int q = tid; q < nf; q += NT) sy += y[q];
     __syncthreads();
     float xl = 0.f, nx = 0.f;
-    for (int e = indptr[b] + tid; e < indptr[b + 1]; e += NT) {
+    for (int e = e0 + tid; e < e1; e += NT) {
         const int it = indices[e];
         const float x = values ? values[e] : 1.f;
         s_x[it] = x;
-        xl += x * row[it];
+        xl += x * s_l[it];
         nx += x;
     }
     for (int q = tid; q < nf; q += NT) {
         const int it = f_gen[q];
         if (f_row[q] == b && it >= 0 && it < I && f_pop[q] >= 0) s_s[it] = 1;
     }
-    mx = block_max(mx, red);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) s += expf(v[j] - mx);   // exp(-inf) = 0 beyond I
-    s = block_sum(s, red);
-    const float l = mx + logf(s);
-    xl = block_sum(xl, red);
-    nx = block_sum(nx, red);
-    sy = block_sum(sy, red);     // (the barriers inside also publish s_x / s_s)
-    float ps = 0.f;
+    block_red4(xl, nx, sy, mx, red);           // (its barrier also publishes s_x / s_s)
+    float s = 0.f, psu = 0.f, zero = 0.f, m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = tid + NT * j;
-        if (i < I && s_s[i]) ps += expf(v[j] - l);
+        const float ex = expf(v[j] - mx);      // exp(-inf) = 0 beyond I
+        s += ex;
+        psu += (i < I && s_s[i]) ? ex : 0.f;
     }
-    ps = block_sum(ps, red);
-    const float invB = 1.f / (float)B;
+    block_red4(s, psu, zero, m2, red);
+    const float l = mx + logf(s);
+    const float ps = psu / s;                  // sum_{S_b} exp(logit - lse)
+    const float invB = 1.f / (float)B, invs = 1.f / s;
     const float c = cnt[0] > 0 ? lam / (float)cnt[0] * sy : 0.f;
     const float alpha = nx * invB + c * ps;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = tid + NT * j;
         if (i < I) {
-            const float p = expf(v[j] - l);
+            const float p = expf(v[j] - mx) * invs;
             dlog[(size_t)b * I + i] = p * alpha - s_x[i] * invB - (s_s[i] ? c * p : 0.f);
         }
     }
@@ -689,10 +747,9 @@ __global__ __launch_bounds__(NT) void fk_dh2(int B, int I, int H, const float* _
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dlog + (size_t)m * I + k); };
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wp1t + (size_t)k * H + n, H); };
     auto xf = [=] __device__(ltg_f32x4 v, int, int, int) { return BF ? ltg_bf16r4(v) : v; };
-    auto epi = [=] __device__(int m, int n, float v, bool ok) {
-        if (!ok) return;
-        const float t = h2[(size_t)m * H + n];
-        da2[(size_t)m * H + n] = v * (1.f - t * t);
+    const float t = h2[(size_t)min(m0 + (int)(threadIdx.x >> 4), B - 1) * H + min(n0 + (int)(threadIdx.x & 15), H - 1)];
+    auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
+        if (ok) da2[(size_t)m * H + n] = v * (1.f - t * t);
     };
     ltg_rgemm<1, 1, 1, 1, 4, 16>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
 }
@@ -790,16 +847,25 @@ __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const f
     ltg_rgemm_v4<1, 1, 2, 2, 1, 7>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
 }
 
-// The Adam updates of the generator step as jobs of ONE launch (train.py:164; all are independent once every reader of the
-// old weights has run):
+// The Adam updates of the generator step as jobs riding with the backward chain (train.py:164; each is independent once
+// every reader of its old weights has run).  One kernel, launched three times per step with different job sets:
+//   launch A  dz tiles        + job 1 (W_p1t: dh2, the last reader of the old W_p1t, ran before)
+//   launch B  dh1 tiles       + job 2 (W_p0: dz was its last reader)
+//   launch C  jobs 3, 4, 5    (W_q1: dh1 was its last reader; W_q0 needs da1; the step's scalars)
 //   job 1  dW_p1t + b_p1   (items x (H + 1), bf16-rounded operands under LTG_PREC_BF16)        -- small item slabs only
 //   job 2  dW_p0 + b_p0    ((Z + 1) x H)          job 3  dW_q1 + b_q1   ((H + 1) x 2Z)
 //   job 4  W_q0 + b_q0     dense float4 sweep, sparse gradient rows through slot[] (see k_enc0_bwd_adam)
 //   job 5  the step's scalars from the per-row terms of fk_row_dlogits (train.py:154-157)         -- small item slabs only
 struct TailArgs {
     int B, I, H, Z, nu;
+    int nz, nh;                   // blocks of the dz / dh1 products riding in front (0 = not in this launch)
     int n1, n2, n3, n4, n5;       // blocks per job
+    const float *Wp0, *Wq1, *mulv, *eps;
+    float is_training;
+    uint64_t seed, step;
+    float *dmlv_out, *da1_out;
     const float *dlog, *h2, *z, *da2, *h1, *dmlv, *G;
+    const float *xd, *da1;        // xd != NULL: job 4 = the dense product xd^T . da1 + Adam (no sparse rows, no slot map)
     const int32_t* slot;
     const float* rowout;
     const int32_t* cnt;
@@ -808,9 +874,21 @@ struct TailArgs {
 };
 template <bool BF>
 __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, AdamC ad) {
-    __shared__ __attribute__((aligned(16))) float lds[Rg32::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS > Rg32::LDS_FLOATS ? Rg16::LDS_FLOATS : Rg32::LDS_FLOATS];
     int bid = blockIdx.x;
     const int B = a.B, I = a.I, H = a.H, Z = a.Z;
+    if (bid < a.nz) {       // the critical path of the step rides in front: its tiles are placed first
+        const int tn = (Z + 15) / 16;
+        dz_tile(B, Z, H, a.da2, a.Wp0, a.mulv, a.eps, a.is_training, a.anneal, a.seed, a.step, a.dmlv_out, (bid / tn) * 16, (bid % tn) * 16, lds);
+        return;
+    }
+    bid -= a.nz;
+    if (bid < a.nh) {
+        const int tn = (H + 15) / 16;
+        dh1_tile(B, H, 2 * Z, a.dmlv, a.Wq1, a.h1, a.da1_out, (bid / tn) * 16, (bid % tn) * 16, lds);
+        return;
+    }
+    bid -= a.nh;
     if (bid < a.n1) {
         const int tn = (H + 1 + 31) / 32;
         const WgTensors T{st.p[3], st.m[3], st.v[3], st.p[7], st.m[7], st.v[7]};
@@ -832,6 +910,12 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         return;
     }
     bid -= a.n3;
+    if (bid < a.n4 && a.xd) {
+        const int tn = (H + 31) / 32;
+        const WgTensors T{st.p[0], st.m[0], st.v[0], st.p[4], st.m[4], st.v[4]};
+        wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        return;
+    }
     if (bid < a.n4) {
         const int H4 = H >> 2;
         const size_t total = (size_t)(I + 1) * H4;

@@ -1755,6 +1755,7 @@ inline int dh2_kchunk(int I) {
 // without knowing nnz, so the table bound is used: one heavy user in a short batch can never overflow it.
 inline size_t gq0_rows(const ltg_config* cfg, int /*max_rows*/) { return (size_t)cfg->n_items; }
 
+constexpr int RD_MAXI = 4096;   // "small item slab": a row of logits fits the registers of one workgroup (ltg_fast.h)
 struct Workspace {
     // generator backward
     float *rowpart, *segpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
@@ -1762,7 +1763,7 @@ struct Workspace {
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     // fast path: per-column-tile partial dot products of the output unit, w4 * dA3/dpre, per-row loss terms of the G step
-    float *spart, *G3, *rowout;
+    float *spart, *G3, *rowout, *xd;
     size_t bytes;
 };
 // stride of one discriminator gradient slab: the P gradients + one slot for the chunk's loss sum, padded to whole float4
@@ -1812,6 +1813,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.spart = take(((h3 + 31) / 32) * P);
     w.G3 = take(P * h3);
     w.rowout = take(R * 4);
+    w.xd = take(I <= (size_t)RD_MAXI ? R * I : 1);   // dense operand rows of enc-0 (small item slabs)
     w.bytes = off;
     return w;
 }
@@ -1861,7 +1863,7 @@ inline bool fast_on(const ltg_config* c) { return (c->reserved0 & 262144) == 0; 
 inline bool mid_fast(const ltg_config* c, int rows) { return fast_on(c) && (c->z_dim % 4) == 0 && rows <= 256; }
 inline bool d_wide(const ltg_config* c) { return c->d_h0 >= 512 && c->d_h1 + c->d_h2 >= 512 && c->d_h3 >= 128; }
 inline bool d_fast(const ltg_config* c) {
-    return fast_on(c) && c->d_precision == LTG_PREC_FP32 && !d_wide(c) && (c->d_h0 % 4) == 0 && ((c->d_h1 + c->d_h2) % 4) == 0 && (c->d_h3 % 4) == 0;
+    return fast_on(c) && c->d_precision == LTG_PREC_FP32 && !d_wide(c) && c->d_h3 <= 512 && (c->d_h0 % 4) == 0 && ((c->d_h1 + c->d_h2) % 4) == 0 && (c->d_h3 % 4) == 0;
 }
 inline bool unsharded(const ltg_config* c) { return c->item_lo == 0 && (c->n_items_global == 0 || c->n_items_global == c->n_items); }
 inline bool small_fast(const ltg_config* c, int rows) {
@@ -1877,14 +1879,14 @@ inline int Ig_of(const ltg_config* cfg) { return cfg->n_items_global > 0 ? cfg->
 
 // stage 1: enc-0 over this rank's item slab.  pre_only: leave the partial pre-activation in acts->h1.
 void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
-                   const ltg_gen_acts* acts, int pre_only, hipStream_t st) {
+                   const ltg_gen_acts* acts, int pre_only, hipStream_t st, float* xd = nullptr) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc;
     const Probe pr{o->probe, st};
     if (fast_on(cfg)) {
         LTG_PROBED(pr, LTG_K_ENC0_FWD,
-                   hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), 0, st, H, I, bt->indptr, bt->indices, bt->values,
-                                      o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1, acts->row_scale,
-                                      bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only));
+                   hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), xd ? (size_t)I * sizeof(float) : 0, st, H, I, bt->indptr,
+                                      bt->indices, bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
+                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd));
         return;
     }
     LTG_PROBED(pr, LTG_K_ENC0_FWD,
@@ -1904,9 +1906,10 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
         hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
     }
     if (mid_fast(cfg, R)) {
-        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1, grid2(2 * Z, R, 16, 16), dim3(NT), 0, st, R, H, 2 * Z, acts->h1, gen->p[1], gen->p[5], acts->mulv));
-        LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->mulv, o->eps, o->is_training, cfg->seed,
-                                                      o->rng_step, gen->p[2], gen->p[6], acts->z, acts->kl_rows, acts->h2));
+        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1, grid2(Z, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->h1, gen->p[1], gen->p[5], o->eps, o->is_training,
+                                                      cfg->seed, o->rng_step, acts->mulv, acts->z));
+        LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6],
+                                                      acts->kl_rows, acts->h2));
     } else {
     pr.before(LTG_K_ENC1);
     if (vz) hipLaunchKernelGGL((k_dense_fwd<0, true>), grid2(2 * Z, R, 32, 32), dim3(NT), 0, st, R, 2 * Z, H, acts->h1, gen->p[1], gen->p[5], acts->mulv);
@@ -2215,32 +2218,66 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
     pe.after(LTG_K_ENC0_GRAD);
 }
 
-// The Adam updates of the step as jobs of one launch (fk_g_tail).  with_dec1: include decoder layer 1 (small item slabs;
-// large ones ran the streaming kernel before) and the step's scalars.
-static void g_tail(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
+// The backward chain dz -> dh1 and the Adam updates of the step as jobs of three launches of fk_g_tail (see there):
+//   stage 0: dz tiles + W_p1t (with_dec1: small item slabs; large ones ran the streaming kernel before)
+//   stage 1: dh1 tiles + W_p0        stage 2: W_q1, W_q0 (dense product when slot == NULL, else sweep + sparse rows), scalars
+static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     TailArgs a;
     a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
-    a.n1 = with_dec1 ? ((I + 31) / 32) * ((H + 1 + 31) / 32) : 0;
-    a.n2 = ((Z + 1 + 31) / 32) * ((H + 31) / 32);
-    a.n3 = ((H + 1 + 31) / 32) * ((2 * Z + 31) / 32);
-    {
-        const size_t total = (size_t)(I + 1) * (H / 4);
-        size_t gx = (total + NT - 1) / NT;
-        if (gx > 262144) gx = 262144;
-        a.n4 = (int)gx;
+    const bool all = stage < 0;     // stage -1: every Adam job in ONE launch (dz / dh1 were launched on their own)
+    a.nz = stage == 0 ? ((B + 15) / 16) * ((Z + 15) / 16) : 0;
+    a.nh = stage == 1 ? ((B + 15) / 16) * ((H + 15) / 16) : 0;
+    a.n1 = ((stage == 0 || all) && with_dec1) ? ((I + 31) / 32) * ((H + 1 + 31) / 32) : 0;
+    a.n2 = (stage == 1 || all) ? ((Z + 1 + 31) / 32) * ((H + 31) / 32) : 0;
+    a.n3 = (stage == 2 || all) ? ((H + 1 + 31) / 32) * ((2 * Z + 31) / 32) : 0;
+    a.n4 = 0;
+    if (stage == 2 || all) {
+        if (!slot) a.n4 = ((I + 1 + 31) / 32) * ((H + 31) / 32);
+        else {
+            const size_t total = (size_t)(I + 1) * (H / 4);
+            size_t gx = (total + NT - 1) / NT;
+            if (gx > 262144) gx = 262144;
+            a.n4 = (int)gx;
+        }
     }
-    a.n5 = with_dec1 ? 1 : 0;
+    a.n5 = ((stage == 2 || all) && with_dec1) ? 1 : 0;
+    a.Wp0 = gen->p[2]; a.Wq1 = gen->p[1]; a.mulv = acts->mulv; a.eps = o->fwd.eps; a.is_training = o->fwd.is_training;
+    a.seed = cfg->seed; a.step = o->fwd.rng_step; a.dmlv_out = w.dmlv; a.da1_out = w.da1;
     a.dlog = w.dlog; a.h2 = acts->h2; a.z = acts->z; a.da2 = w.da2; a.h1 = acts->h1; a.dmlv = w.dmlv; a.G = w.gq0;
+    a.xd = slot ? nullptr : w.xd;
+    a.da1 = w.da1;
     a.slot = slot; a.rowout = w.rowout; a.cnt = o->cnt; a.anneal = o->anneal; a.lam = o->gan_lambda;
     a.loss_out = w.scal; a.loss_out2 = loss_out;
     const Probe pr{o->probe, st};
-    pr.before(LTG_K_G_TAIL);
-    const dim3 g(a.n1 + a.n2 + a.n3 + a.n4 + a.n5);
+    const int kid = stage == 0 ? LTG_K_DZ : (stage == 1 ? LTG_K_DH1 : LTG_K_G_TAIL);
+    pr.before(kid);
+    const dim3 g(a.nz + a.nh + a.n1 + a.n2 + a.n3 + a.n4 + a.n5);
     if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_g_tail<true>, g, dim3(NT), 0, st, a, *gen, ad);
     else hipLaunchKernelGGL(fk_g_tail<false>, g, dim3(NT), 0, st, a, *gen, ad);
-    pr.after(LTG_K_G_TAIL);
+    pr.after(kid);
+}
+
+// dz -> dh1 -> (sparse W_q0 gradient) -> Adam updates.  Tuning-knob bit 20: the Adam jobs ride with the dz / dh1 launches
+// (three launches of fk_g_tail) instead of running as one tail launch behind them.
+static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
+                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st) {
+    const int B = bt->n_rows, H = cfg->h_enc, Z = cfg->z_dim;
+    const bool ride = (cfg->reserved0 & (1 << 20)) != 0;
+    if (ride) {
+        g_jobs(0, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
+        g_jobs(1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
+        if (slot) g_enc0_grad(cfg, bt, o, acts, w, st);
+        g_jobs(2, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
+        return;
+    }
+    const Probe pr{o->probe, st};
+    LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
+                                                o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
+    LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
+    if (slot) g_enc0_grad(cfg, bt, o, acts, w, st);
+    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
 }
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
@@ -2296,12 +2333,8 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     launch_dw();
     if (mid_fast(cfg, B)) {
         // dz -> dh1 -> sparse W_q0 gradient, then every remaining Adam update (W_p0, W_q1, W_q0 + biases) in ONE launch
-        const Probe pf{o->probe, st};
-        LTG_PROBED(pf, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
-                                                    o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
-        LTG_PROBED(pf, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-        g_enc0_grad(cfg, bt, o, acts, w, st);
-        g_tail(cfg, gen, bt, o, acts, w, ad, g_slot_map(cfg, bt, w, st), false, nullptr, st);
+        const int32_t* slot = g_slot_map(cfg, bt, w, st);
+        g_chain(cfg, gen, bt, o, acts, w, ad, slot, false, nullptr, st);
         return check_launch();
     }
     const Probe pc{o->probe, s_chain}, pw{o->probe, s_wg};
@@ -2380,11 +2413,12 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, aux);
         if (hipEventRecord((hipEvent_t)o->ev_join, aux) != hipSuccess) return LTG_ELAUNCH;
     }
-    fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st);
+    const bool small = small_fast(cfg, B);
+    fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st, small ? w.xd : nullptr);
     fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
-    if (small_fast(cfg, B)) {
+    if (small) {
         // small item slab: a row's softmax statistics, loss terms and dlogits need no other row -> one launch per stage,
-        // ten launches per step: enc0, enc1, dec0, dec1 | row softmax + dlogits, dh2, dz, dh1, sparse W_q0 gradient, Adam tail
+        // nine launches per step: enc0, enc1, dec0, dec1 | row softmax + dlogits, dh2, dz, dh1, Adam tail (dW_q0 = xd^T . da1 dense)
         const int I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
         const Probe pr{o->probe, st};
         if (nf > 0 && !fork) {
@@ -2400,11 +2434,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_dh2<true>, grid2(H, B, 16, 16), dim3(NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
         else hipLaunchKernelGGL(fk_dh2<false>, grid2(H, B, 16, 16), dim3(NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
         pr.after(LTG_K_DH2);
-        LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
-                                                    o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
-        LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-        g_enc0_grad(cfg, bt, o, acts, w, st);
-        g_tail(cfg, gen, bt, o, acts, w, make_adam(cfg, o->adam_t), g_slot_map(cfg, bt, w, st), true, loss_out, st);
+        g_chain(cfg, gen, bt, o, acts, w, make_adam(cfg, o->adam_t), nullptr, true, loss_out, st);
         return check_launch();
     }
     g_row_partial(cfg, bt, fake, acts, w.rowpart, st, w.segpart);

@@ -27,7 +27,7 @@
 //   load -- vmcnt(0) fourteen times per pass in the first version of the discriminator's second layer.)
 //   When K % 4 != 0 (K = pair rows / batch rows) the functors clamp the addresses of elements with k + j >= K and a_xf
 //   zeroes them.
-//   epi(m, n, value, in_range) is called by every thread the same number of times (in_range = m < M && n < N), so it may
+//   epi(e, m, n, value, in_range) (e = 0, 1, ...: the call's index) is called by every thread the same number of times (in_range = m < M && n < N), so it may
 //   use wave shuffles.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -66,12 +66,18 @@ struct LtgRg {
 // NBLK: 16-deep k blocks a wave keeps in flight at once (registers: NBLK * (TM + TN) * 4).  K slices longer than NBLK
 // blocks take several passes (one memory round trip each).
 // Product phase: leaves the WK partial tiles in LDS ([WK][BM][LDC]) behind a barrier.
+struct LtgNoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
 struct LtgXfId {
     __device__ __forceinline__ ltg_f32x4 operator()(ltg_f32x4 v, int, int, int) const { return v; }
 };
 
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF>
-__device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds) {
+// mid(): called once, after the requests of the first pass have been issued and before anything consumes them -- the place
+// for work that needs an earlier load of the caller's (e.g. row factors into LDS + a barrier) without costing a round trip.
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
+__device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
+                                                  MID mid = MID()) {
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
     typedef LtgRg<TM, TN, WM, WN, WK> G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -107,12 +113,14 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
             for (int tn = 0; tn < TN; ++tn) rb[i][tn] = b_ld(i, kc, bn[tn]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (base == 0) mid();
         // phase 2: transforms and MFMAs, block by block as the data lands
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) {
             const int k = 16 * (wk * per + base + i) + 4 * q;
             const bool ok = base + i < per && k < K;
             const int kc = min(k, Kc);
+            if (base + i >= per || 16 * (wk * per + base + i) >= K) continue;   // wave-uniform: nothing of this block is in range
             ltg_f32x4 av[TM], bv[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -142,10 +150,11 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
     __syncthreads();
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class EF>
-__device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds) {
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
+__device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds,
+                                          MID mid = MID()) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
-    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
     static_assert(NE % 256 == 0, "tile must divide over 256 threads");
@@ -157,7 +166,7 @@ __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, A
 #pragma unroll
         for (int s = 1; s < WK; ++s) v += lds[s * (G::BM * G::LDC) + mm * G::LDC + nn];
         const int m = m0 + mm, n = n0 + nn;
-        epi(m, n, v, m < M && n < N);
+        epi(e, m, n, v, m < M && n < N);
     }
 }
 
