@@ -42,7 +42,8 @@ def _upload_batch(eng, X, with_csc=False):
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 1e-3)])
-@pytest.mark.parametrize("I,B", [(1000, 100), (777, 37), (64, 1), (2500, 130), (8200, 100), (8200, 150)])
+@pytest.mark.parametrize("I,B", [(1000, 100), (777, 37), (64, 1), (2500, 130), (8200, 100), (8200, 150),
+                                 (20000, 100), (200000, 100)])     # the last two: BASELINE configs 3 and 4 (item counts, BATCH_SIZE)
 def test_forward_parity(precision, tol, I, B):
     import torch
     rng, X, P = _problem(I, B, seed=I + B)
@@ -62,12 +63,16 @@ def test_forward_parity(precision, tol, I, B):
     assert Hh.rel_err(got["mulv"], np.concatenate([F["mu"], F["logvar"]], 1)) < 1e-4
     assert Hh.rel_err(got["z"], F["z"]) < 1e-4
     assert Hh.rel_err(got["h2"], F["h2"]) < 1e-4
-    assert Hh.rel_err(got["kl_rows"], F["KL_rows"]) < 1e-4
+    # KL terms 0.5 (-lv + e^lv + mu^2 - 1) cancel to ~lv^2 / 4 in fp32 (MultiVAE.py:161 as written, also in the reference): each of
+    # the Z terms carries up to one fp32 ulp of e^lv ~ 1, which dominates when the activations are tiny (Xavier at I = 200 000)
+    assert np.abs(got["kl_rows"] - F["KL_rows"]).max() < 1e-4 * np.abs(F["KL_rows"]).max() + 6e-8 * eng.Z
     assert Hh.rel_err(got["logits"], F["logits"]) < tol
     assert np.abs(got["lse"] - F["lse"]).max() < tol
     # probabilities: 1e-3 relative, element-wise (north_star)
     p = probs.cpu().numpy()
-    assert np.max(np.abs(p - F["probs"]) / F["probs"]) < (1e-3 if precision == "fp32" else 3e-3)
+    perr = np.max(np.abs(p - F["probs"]) / F["probs"])
+    print("I=%d B=%d %s: max rel err probs %.2e logits %.2e" % (I, B, precision, perr, Hh.rel_err(got["logits"], F["logits"])))
+    assert perr < 1e-3
     # against the pure-fp32-operand oracle the bf16 path stays within 1e-2 on probabilities
     if precision == "bf16":
         F32 = O.vae_forward(P, X.toarray(), mask, keep, eps, 1.0, 1.0, np.float64, quant=False)
@@ -107,8 +112,10 @@ def _fake_pairs(rng, X, I, per_user=5):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("I,B", [(1000, 100), (333, 17), (8200, 100), (8200, 150)])
+@pytest.mark.parametrize("I,B", [(1000, 100), (333, 17), (8200, 100), (8200, 150), (20000, 100), (200000, 100)])
 def test_g_step_parity(precision, I, B):
+    if I >= 20000 and precision != "bf16":
+        pytest.skip("BASELINE configs 3 / 4 run the bf16 decoder path")
     import torch
     from ltgan.engine import Pairs
     rng, X, P = _problem(I, B, seed=11 * I + B)
