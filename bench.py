@@ -44,6 +44,8 @@ def parse():
                     help="discriminator h0,h1,h2,h3 (config.ini defaults; BASELINE config 5 = 2048,1024,512,256)")
     ap.add_argument("--d-precision", default="fp32", choices=["fp32", "bf16", "fp8"],
                     help="operand precision of the discriminator GEMMs (fp32 = the reference's arithmetic)")
+    ap.add_argument("--d-split", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: split the discriminator's pair rows over the ranks + gradient all-reduce (auto: when the discriminator has >= 1 M parameters)")
     ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event kernel probes (use under rocprofv3 --pmc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -410,7 +412,7 @@ def main():
         data = DeviceData(idx, a.batch_size, device, item_lo=lo, item_hi=hi)
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device, item_lo=lo, item_hi=hi)
         eng.cfg.reserved0 = a.variant
-        tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs)
+        tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs, d_split={"auto": None, "on": True, "off": False}[a.d_split])
     else:
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
         eng.cfg.reserved0 = a.variant
@@ -459,7 +461,8 @@ def main():
         "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
                    "sub_epochs": a.sub_epochs, "batch_size": a.batch_size,
                    "backend": ("%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "test rig: ranks share GPUs")) if dist.is_initialized() else "none",
-                   "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step replicated)" % world)
+                   "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step %s)" %
+                                   (world, "pair rows split + gradient all-reduce" if getattr(tr, "d_split", False) else "replicated"))
                    if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
         "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
     }

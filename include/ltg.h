@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 7
+#define LTG_ABI_VERSION 8
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -199,6 +199,10 @@ typedef struct ltg_g_opts {
     ltg_stream aux_stream;
     void* ev_fork;
     void* ev_join;
+    /* item-sharded runs: ltg_g_bwd_dec1 already updated W_p1t / b_p1 of this step (issued while the dh2 all-reduce was in
+     * flight), ltg_g_bwd_rest must not do it again */
+    int32_t dec1_done;
+    int32_t reserved0;
 } ltg_g_opts;
 
 /* Static per-user sampling inputs for a batch (results of the index path, data_processing.py). */
@@ -245,6 +249,19 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
                const ltg_pairs* fake, const ltg_d_opts* opts, float* loss_out, void* ws,
                size_t ws_bytes, ltg_stream stream);
 
+/* ---- The discriminator step cut at its exchange point, for multi-GPU runs that split the PAIR ROWS over ranks:
+ * the logical pair batch is the concatenation real | fake (rows 0 .. real->n + fake->n); a rank runs forward + backward over
+ * rows [row_lo, row_hi) with the full step's dropout draw (the counter RNG is indexed by the global row) and gets ONE
+ * gradient vector: ltg_d_grad_floats(cfg) floats = the eight trainable tensors in discriminator.py:47 order back to back
+ * (w1, b1, w2, b2, w3, b3, w4, b4), then this rank's share of d_loss (train.py:142), padded to whole float4.  The host
+ * all-reduces (sum) that vector with RCCL; ltg_d_apply then runs the identical TF-Adam sweep on every rank and writes
+ * d_loss.  ltg_d_step == ltg_d_grad over all rows + ltg_d_apply.  opts->adam_t is ignored by ltg_d_grad. */
+size_t ltg_d_grad_floats(const ltg_config* cfg);
+int ltg_d_grad(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real, const ltg_pairs* fake, int32_t row_lo,
+               int32_t row_hi, const ltg_d_opts* opts, float* grad_out, void* ws, size_t ws_bytes, ltg_stream stream);
+int ltg_d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const float* grad, int32_t adam_t, float* loss_out,
+                ltg_stream stream);
+
 /* Generator update: replaces sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss]) --
  * Codes/train.py:326 (losses train.py:145-157, Adam :164).  The dense mask feed `generated_tags`
  * is replaced by the (row, gen id) list of `fake`.  loss_out (device, >= 8 floats): [0..2] = g_loss,
@@ -276,6 +293,10 @@ int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_dis
 int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
                    const ltg_g_opts* opts, const ltg_gen_acts* acts, const float* dh2, void* ws, size_t ws_bytes,
                    ltg_stream stream);
+/* The part of ltg_g_bwd_rest that does not need the all-reduced dh2: Adam on the local W_p1t / b_p1 rows (reads dlogits and
+ * h2 of ltg_g_bwd_dec).  Issue it right after starting the dh2 all-reduce, then call ltg_g_bwd_rest with opts->dec1_done = 1. */
+int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
+                   const ltg_g_opts* opts, const ltg_gen_acts* acts, void* ws, size_t ws_bytes, ltg_stream stream);
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out,
                            ltg_stream stream);
 /* (re)build gen->wp1t_bf16 from gen->p[3] (after initialisation or after loading weights). */

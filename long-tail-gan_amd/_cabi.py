@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 7
+LTG_ABI_VERSION = 8
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -74,7 +74,7 @@ class ltg_d_opts(C.Structure):
 class ltg_g_opts(C.Structure):
     _fields_ = [("fwd", ltg_fwd_opts), ("anneal", C.c_float), ("gan_lambda", C.c_float), ("d_keep_prob", C.c_float),
                 ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp), ("probe", C.POINTER(ltg_probe)),
-                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp)]
+                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("dec1_done", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ltg_sample_inputs(C.Structure):
@@ -92,6 +92,12 @@ SYMBOLS = {
     "ltg_sample_pairs": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp, vp, vp, vp]),
     "ltg_d_step": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), C.POINTER(ltg_pairs),
                              C.POINTER(ltg_pairs), C.POINTER(ltg_d_opts), vp, vp, C.c_size_t, vp]),
+    "ltg_d_grad_floats": (C.c_size_t, [C.POINTER(ltg_config)]),
+    "ltg_d_grad": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), C.POINTER(ltg_pairs), C.POINTER(ltg_pairs), C.c_int32,
+                             C.c_int32, C.POINTER(ltg_d_opts), vp, vp, C.c_size_t, vp]),
+    "ltg_d_apply": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), vp, C.c_int32, vp, vp]),
+    "ltg_g_bwd_dec1": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pairs),
+                                 C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, C.c_size_t, vp]),
     "ltg_g_step": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state),
                              C.POINTER(ltg_batch), C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts),
                              C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),

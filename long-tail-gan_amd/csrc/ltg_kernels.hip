@@ -706,9 +706,11 @@ struct PairView {
 struct DropView {
     const uint8_t *real, *fake;  // optional injected keep flags [rows][width]
     int nr;
+    int row0;                    // logical pair row of local row 0 (a rank that owns rows [row0, ...) of the pair batch draws the
+                                 // mask the whole batch draws: the counter RNG is indexed by the GLOBAL row)
     __device__ __forceinline__ bool keep(int r, int c, int width, uint64_t seed, uint32_t stream, uint64_t step, float kp) const {
         if (real || fake) return r < nr ? (real[(size_t)r * width + c] != 0) : (fake[(size_t)(r - nr) * width + c] != 0);
-        return ltg_rng_keep(seed, stream, step, (uint64_t)r * width + c, kp);
+        return ltg_rng_keep(seed, stream, step, (uint64_t)(r + row0) * width + c, kp);
     }
 };
 
@@ -984,6 +986,25 @@ __global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, int SP, const 
         else for (int z = threadIdx.x; z < ks; z += NT) s += slab[(size_t)z * SP + P];
         s = block_sum(s, red);
         if (threadIdx.x == 0) loss_out[0] = s;
+    }
+}
+
+// One gradient vector from the chunk slabs: out[e] = sum_z slab[z][e], out[P] = the loss sum (from lrow, or from slot P of the
+// slabs) -- what a rank contributes to the gradient all-reduce when the pair rows are split over ranks (ltg_d_grad).
+__global__ __launch_bounds__(NT) void k_d_grad_sum(int ks, int P, int stride, const float* __restrict__ slab, int n,
+                                                   const float* __restrict__ lrow, float* __restrict__ out) {
+    __shared__ float red[NT / 64];
+    for (int e = blockIdx.x * NT + threadIdx.x; e < P; e += gridDim.x * NT) {
+        float g = 0.f;
+        for (int z = 0; z < ks; ++z) g += slab[(size_t)z * stride + e];
+        out[e] = g;
+    }
+    if (blockIdx.x == 0) {
+        float s = 0.f;
+        if (lrow) for (int i = threadIdx.x; i < n; i += NT) s += lrow[i];
+        else for (int z = threadIdx.x; z < ks; z += NT) s += slab[(size_t)z * stride + P];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) out[P] = s;
     }
 }
 
@@ -2069,23 +2090,36 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
     return check_launch();
 }
 
-int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real, const ltg_pairs* fake,
-               const ltg_d_opts* o, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream) {
-    clear_errors();
-    if (!cfg_ok(cfg) || !disc || !real || !fake || !o || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
-    const int n = real->n + fake->n;
-    if (real->n < 0 || fake->n < 0) return LTG_EINVAL;
-    if (ltg_workspace_bytes(cfg, 1, n) > ws_bytes) return LTG_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return hipMemsetAsync(loss_out, 0, sizeof(float), st) == hipSuccess ? LTG_OK : LTG_ELAUNCH;
-    const Workspace w = carve(cfg, 1, n, (char*)ws);
+// One Adam sweep of the discriminator from `ks` gradient slabs of stride `stride` (lrow: the per-row loss terms of the
+// round-1 kernels, else the loss sits in slot P of the slabs)
+static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLayout& L, int ks, int stride, const float* slab, int n,
+                    const float* lrow, const AdamC& ad, float* loss_out, const Probe& pr, hipStream_t st) {
+    const int P = L.off[8];
+    bool flat = lrow == nullptr && (stride % 4) == 0;   // one flat float4 sweep when the eight tensors (and moments) lie back to back
+    for (int i = 0; i < 7; ++i) {
+        const size_t sz = (size_t)(L.off[i + 1] - L.off[i]);
+        flat = flat && disc->p[i + 1] == disc->p[i] + sz && disc->m[i + 1] == disc->m[i] + sz && disc->v[i + 1] == disc->v[i] + sz;
+    }
+    flat = flat && ((uintptr_t)disc->p[0] % 16) == 0 && ((uintptr_t)disc->m[0] % 16) == 0 && ((uintptr_t)disc->v[0] % 16) == 0 &&
+           ((uintptr_t)slab % 16) == 0;
+    int ga = ((flat ? P / 4 : P) + NT - 1) / NT;
+    if (ga > 1024) ga = 1024;
+    if (ga < 1) ga = 1;
+    pr.before(LTG_K_D_ADAM);
+    if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, stride, slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out);
+    else hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, stride, slab, *disc, ad, n, lrow, loss_out);
+    pr.after(LTG_K_D_ADAM);
+}
+
+// forward + backward of the pair rows in `pv` into gradient slabs; then either the Adam sweep (grad_out == NULL: the
+// whole step, train.py:300) or one summed gradient vector in grad_out (this rank's share: ltg_d_grad)
+static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairView pv, DropView dA, DropView dB, DropView dC,
+                       const ltg_d_opts* o, float* grad_out, float* loss_out, const Workspace& w, hipStream_t st) {
+    const int n = pv.nr + pv.nf;
     const int h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
-    PairView pv{real->n, fake->n, real->pop, real->niche, fake->pop, fake->niche};
-    DropView dA{o->drop_real[0], o->drop_fake[0], real->n}, dB{o->drop_real[1], o->drop_fake[1], real->n},
-        dC{o->drop_real[2], o->drop_fake[2], real->n};
     disc_forward(cfg, disc, pv, dA, dB, dC, o->keep_prob, o->rng_step, w, true, o->probe, st);
     const Probe pr{o->probe, st};
-    const AdamC ad = make_adam(cfg, o->adam_t);
+    const AdamC ad = make_adam(cfg, o->adam_t > 0 ? o->adam_t : 1);
     const DLayout L = d_layout(h0, h1, h2, h3);
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     if (d_fast(cfg)) {
@@ -2097,20 +2131,8 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
                                                         w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab));
         const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
         LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab));
-        // one flat float4 sweep when the caller laid the eight tensors (and their moments) out back to back
-        bool flat = true;
-        for (int i = 0; i < 7; ++i) {
-            const size_t sz = (size_t)(L.off[i + 1] - L.off[i]);
-            flat = flat && disc->p[i + 1] == disc->p[i] + sz && disc->m[i + 1] == disc->m[i] + sz && disc->v[i + 1] == disc->v[i] + sz;
-        }
-        flat = flat && ((uintptr_t)disc->p[0] % 16) == 0 && ((uintptr_t)disc->m[0] % 16) == 0 && ((uintptr_t)disc->v[0] % 16) == 0;
-        int ga = (P / 4 + NT - 1) / NT;
-        if (ga > 1024) ga = 1024;
-        if (ga < 1) ga = 1;
-        pr.before(LTG_K_D_ADAM);
-        if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, SP, w.slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out);
-        else hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, SP, w.slab, *disc, ad, 0, (const float*)nullptr, loss_out);
-        pr.after(LTG_K_D_ADAM);
+        if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
+        else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st);
         return check_launch();
     }
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
@@ -2129,9 +2151,66 @@ int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pair
                                                 o->keep_prob, w.dpre1, w.slab));
     const int n2 = ks * tilesb(h0 + 1) * (tilesb(h1) + tilesb(h2));
     LTG_PROBED(pr, LTG_K_D_BWD2, LTG_D_DISPATCH(k_d_bwd2, md, tsb, dim3(n2), st, pv, h0, h1, h2, ks, L, disc->emb, w.dpre1, w.slab));
-    int ga = (L.off[8] + NT - 1) / NT;
-    if (ga > 1024) ga = 1024;
-    LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, L.off[8], w.slab, *disc, ad, n, w.lrow, loss_out));
+    if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, L.off[8], L.off[8], w.slab, n, w.lrow, grad_out);
+    else d_apply(cfg, disc, L, ks, L.off[8], w.slab, n, w.lrow, ad, loss_out, pr, st);
+    return check_launch();
+}
+
+
+int ltg_d_step(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real, const ltg_pairs* fake,
+               const ltg_d_opts* o, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !disc || !real || !fake || !o || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
+    const int n = real->n + fake->n;
+    if (real->n < 0 || fake->n < 0) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, 1, n) > ws_bytes) return LTG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(loss_out, 0, sizeof(float), st) == hipSuccess ? LTG_OK : LTG_ELAUNCH;
+    const Workspace w = carve(cfg, 1, n, (char*)ws);
+    PairView pv{real->n, fake->n, real->pop, real->niche, fake->pop, fake->niche};
+    DropView dA{o->drop_real[0], o->drop_fake[0], real->n, 0}, dB{o->drop_real[1], o->drop_fake[1], real->n, 0},
+        dC{o->drop_real[2], o->drop_fake[2], real->n, 0};
+    return d_step_impl(cfg, disc, pv, dA, dB, dC, o, nullptr, loss_out, w, st);
+}
+
+size_t ltg_d_grad_floats(const ltg_config* cfg) {
+    if (!cfg_ok(cfg)) return 0;
+    return (size_t)d_slab_stride(d_layout(cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3).off[8]);
+}
+
+int ltg_d_grad(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* real, const ltg_pairs* fake, int32_t row_lo,
+               int32_t row_hi, const ltg_d_opts* o, float* grad_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !disc || !real || !fake || !o || !grad_out || !ws) return LTG_EINVAL;
+    const int n = real->n + fake->n;
+    if (real->n < 0 || fake->n < 0 || row_lo < 0 || row_hi < row_lo || row_hi > n) return LTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t gf = ltg_d_grad_floats(cfg);
+    const int m = row_hi - row_lo;
+    if (m == 0) return hipMemsetAsync(grad_out, 0, gf * sizeof(float), st) == hipSuccess ? LTG_OK : LTG_ELAUNCH;
+    if (ltg_workspace_bytes(cfg, 1, m) > ws_bytes) return LTG_EWORKSPACE;
+    const Workspace w = carve(cfg, 1, m, (char*)ws);
+    // the sub-range [row_lo, row_hi) of the logical concatenation real | fake is again a (real, fake) pair of ranges
+    const int r0 = row_lo < real->n ? row_lo : real->n, r1 = row_hi < real->n ? row_hi : real->n;
+    const int f0 = (row_lo > real->n ? row_lo : real->n) - real->n, f1 = (row_hi > real->n ? row_hi : real->n) - real->n;
+    PairView pv{r1 - r0, f1 - f0, real->pop + r0, real->niche + r0, fake->pop + f0, fake->niche + f0};
+    const int wd[3] = {cfg->d_h1, cfg->d_h2, cfg->d_h3};
+    DropView dv[3];
+    for (int i = 0; i < 3; ++i) {
+        dv[i].real = o->drop_real[i] ? o->drop_real[i] + (size_t)r0 * wd[i] : nullptr;
+        dv[i].fake = o->drop_fake[i] ? o->drop_fake[i] + (size_t)f0 * wd[i] : nullptr;
+        dv[i].nr = r1 - r0;
+        dv[i].row0 = row_lo;
+    }
+    return d_step_impl(cfg, disc, pv, dv[0], dv[1], dv[2], o, grad_out, nullptr, w, st);
+}
+
+int ltg_d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const float* grad, int32_t adam_t, float* loss_out, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !disc || !grad || !loss_out || adam_t < 1) return LTG_EINVAL;
+    const DLayout L = d_layout(cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3);
+    const Probe pr{nullptr, (hipStream_t)stream};
+    d_apply(cfg, disc, L, 1, d_slab_stride(L.off[8]), grad, 0, nullptr, make_adam(cfg, adam_t), loss_out, pr, (hipStream_t)stream);
     return check_launch();
 }
 
@@ -2163,7 +2242,7 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     // fake tower forward only (y_data is pruned from the g_trainer fetch, train.py:326); replicated on every rank
     if (nf > 0 && !disc_done) {
         PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
-        DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
+        DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
     }
     hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, st, B, n_ranks, rowpart_all, nf, acts->kl_rows, nf > 0 ? w.y : nullptr, o->cnt,
@@ -2281,7 +2360,8 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
 }
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
-                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false) {
+                            const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false,
+                            bool only_dec1 = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
@@ -2305,7 +2385,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         (void)hipEventRecord(evf, st);
         (void)hipStreamWaitEvent(aux, evf, 0);
     };
-    if (!da2_ready) {
+    if (!da2_ready && !only_dec1) {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
@@ -2330,7 +2410,8 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         prs.after(LTG_K_DEC1_BWD_ADAM);
     };
-    launch_dw();
+    if (!o->dec1_done) launch_dw();
+    if (only_dec1) return check_launch();
     if (mid_fast(cfg, B)) {
         // dz -> dh1 -> sparse W_q0 gradient, then every remaining Adam update (W_p0, W_q1, W_q0 + biases) in ONE launch
         const int32_t* slot = g_slot_map(cfg, bt, w, st);
@@ -2409,7 +2490,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         if (hipEventRecord((hipEvent_t)o->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)o->ev_fork, 0) != hipSuccess)
             return LTG_ELAUNCH;
         PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
-        DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
+        DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, aux);
         if (hipEventRecord((hipEvent_t)o->ev_join, aux) != hipSuccess) return LTG_ELAUNCH;
     }
@@ -2419,11 +2500,11 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     if (small) {
         // small item slab: a row's softmax statistics, loss terms and dlogits need no other row -> one launch per stage,
         // nine launches per step: enc0, enc1, dec0, dec1 | row softmax + dlogits, dh2, dz, dh1, Adam tail (dW_q0 = xd^T . da1 dense)
-        const int I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
+        const int I = cfg->n_items, H = cfg->h_enc;
         const Probe pr{o->probe, st};
         if (nf > 0 && !fork) {
             PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
-            DropView dA{nullptr, o->drop_fake[0], 0}, dB{nullptr, o->drop_fake[1], 0}, dC{nullptr, o->drop_fake[2], 0};
+            DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
             disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
         }
         if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
@@ -2498,6 +2579,15 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
     return g_stage_bwd_rest(cfg, gen, bt, o, acts, dh2, w, (hipStream_t)stream);
+}
+
+int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,
+                   const ltg_g_opts* o, const ltg_gen_acts* acts, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
+    if (!g_args_ok(cfg, gen, bt, acts) || !fake || !o || !ws || o->adam_t < 1 || o->dec1_done) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
+    const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
+    return g_stage_bwd_rest(cfg, gen, bt, o, acts, nullptr, w, (hipStream_t)stream, true, true);
 }
 
 int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream) {

@@ -297,6 +297,27 @@ class Engine:
         cabi.check(rc, "ltg_d_step")
         return loss_out
 
+    # ------------------------------------------------------------------ the D step cut at its exchange point (pair rows split)
+    def d_grad_floats(self):
+        return int(self.lib.ltg_d_grad_floats(C.byref(self.cfg)))
+
+    def d_grad(self, real, fake, row_lo, row_hi, grad_out, keep_prob=0.7, rng_step=0, drop_real=None, drop_fake=None):
+        """forward + backward over pair rows [row_lo, row_hi) of real | fake -> this rank's gradient vector (+ loss share)"""
+        ws = self.workspace(1, max(1, row_hi - row_lo))
+        dr = (cabi.vp * 3)(*[_ptr(t) for t in (drop_real or (None, None, None))])
+        df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
+        o = cabi.ltg_d_opts(keep_prob, 0, rng_step, dr, df, None)
+        rc = self.lib.ltg_d_grad(C.byref(self.cfg), C.byref(self.disc_c), C.byref(real.c), C.byref(fake.c), int(row_lo), int(row_hi),
+                                 C.byref(o), _ptr(grad_out), _ptr(ws), ws.numel(), self.stream())
+        cabi.check(rc, "ltg_d_grad")
+
+    def d_apply(self, grad, loss_out=None):
+        """the (all-reduced) gradient vector -> one TF-Adam sweep at the next shared step; d_loss -> loss_out[0]"""
+        loss_out = self.loss_buf if loss_out is None else loss_out
+        rc = self.lib.ltg_d_apply(C.byref(self.cfg), C.byref(self.disc_c), _ptr(grad), self.next_adam_t(), _ptr(loss_out), self.stream())
+        cabi.check(rc, "ltg_d_apply")
+        return loss_out
+
     def g_step(self, batch, fake, acts, cnt, anneal, gan_lambda=1.0, keep_prob=0.75, is_training=1.0, d_keep_prob=0.7,
                rng_step=0, d_rng_step=0, loss_out=None, drop_keep=None, eps=None, drop_fake=None, probe=None):
         """sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss], ...)  -- train.py:326."""
@@ -343,6 +364,13 @@ class Engine:
         cabi.check(self.lib.ltg_g_bwd_dec(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
                                           C.byref(gopts), C.byref(acts.c), _ptr(rowpart_all), n_ranks, _ptr(loss_out), _ptr(dh2_out),
                                           _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_dec")
+
+    def g_bwd_dec1(self, batch, fake, acts, gopts):
+        """Adam on the local W_p1t / b_p1 rows: needs nothing of the dh2 exchange, so it is issued while that all-reduce flies"""
+        ws = self.workspace(batch.n_rows, fake.n)
+        cabi.check(self.lib.ltg_g_bwd_dec1(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fake.c), C.byref(gopts),
+                                           C.byref(acts.c), _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_dec1")
+        gopts.dec1_done = 1
 
     def g_bwd_rest(self, batch, fake, acts, gopts, dh2):
         ws = self.workspace(batch.n_rows, fake.n)

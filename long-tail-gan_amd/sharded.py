@@ -6,9 +6,20 @@ and identical counter-RNG streams give identical values on every rank, no broadc
 Exchange steps per generator step (torch.distributed over RCCL/xGMI; the C ABI never communicates):
   1. all-reduce(sum)  encoder pre-activation   [B, H]      (240 KB at defaults)
   2. all-gather       row partials             [B, 5]      (max, sum exp, sum x*logit, sum_S exp, sum x)
-  3. all-reduce(sum)  dh2                      [B, H]
-Phase C adds one all-reduce of the candidates' logits (~12 KB).  The discriminator step is replicated.
-Nothing else crosses ranks: the sharded tables never leave their GPU and need no gradient all-reduce.
+  3. all-reduce(sum)  dh2                      [B, H]      -- issued asynchronously; the Adam update of the local W_p1t / b_p1
+                                                              rows (ltg_g_bwd_dec1, the largest kernel of the step) runs under it
+Phase C adds one all-reduce of the candidates' logits (~12 KB).
+The sharded tables never leave their GPU and need no gradient all-reduce.
+
+Discriminator step (train.py:300), two modes:
+  replicated   every rank runs the whole step (identical inputs + identical counter RNG => identical weights, no exchange);
+  pair split    rank r runs forward + backward over rows [r n / R, (r+1) n / R) of the real | fake pair batch
+               (ltg_d_grad: dropout keyed by the GLOBAL row), ONE all-reduce(sum) of the gradient vector
+               (P_D + 1 floats: 644 KB at defaults, 14.2 MB for the wide discriminator), then the identical Adam sweep on
+               every rank (ltg_d_apply).
+`d_split=None` picks the split when the discriminator has >= D_SPLIT_MIN_PARAMS trainable parameters: at config.ini's
+sizes the whole replicated step is ~60 us of latency-bound launches on one GPU, less than the split's four launches plus a
+latency-bound 644-KB all-reduce would take; at the wide sizes (3.5 M parameters, MFMA-bound) the split divides the work.
 """
 from __future__ import annotations
 
@@ -18,6 +29,8 @@ import torch.distributed as dist
 
 from .engine import _ptr
 from .trainer import Trainer, eval_chunk_rows
+
+D_SPLIT_MIN_PARAMS = 1_000_000
 
 
 def item_slab(n_items, rank, world):
@@ -32,12 +45,16 @@ def item_slab(n_items, rank, world):
 
 
 class ShardedTrainer(Trainer):
-    def __init__(self, engine, data, group=None, **kw):
+    def __init__(self, engine, data, group=None, d_split=None, **kw):
         super().__init__(engine, data, **kw)
         self.group = group
         self.R = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         dev = engine.device
+        e = engine
+        self.d_params = e.h0 * e.h1 + e.h1 + e.h0 * e.h2 + e.h2 + (e.h1 + e.h2) * e.h3 + e.h3 + e.h3 + 1
+        self.d_split = (self.d_params >= D_SPLIT_MIN_PARAMS) if d_split is None else bool(d_split)
+        self.d_grad = torch.zeros(engine.d_grad_floats(), dtype=torch.float32, device=dev)
         B = data.max_rows
         self.rowpart = torch.zeros(B * 5, dtype=torch.float32, device=dev)
         self.rowpart_all = torch.zeros(self.R * B * 5, dtype=torch.float32, device=dev)
@@ -89,7 +106,20 @@ class ShardedTrainer(Trainer):
         self.np_rng.shuffle(self.order)          # same seed on every rank -> same order
         return int((~d.idx.user_ok).sum())
 
-    # d_phase: inherited -- the discriminator step is replicated (identical on every rank)
+    # -- discriminator phase ---------------------------------------------------------------------------
+    def d_phase(self):
+        if not self.d_split or self.R == 1:
+            return super().d_phase()          # replicated: identical on every rank
+        d, eng = self.data, self.eng
+        for j in range(self.S):
+            for k in self.order:
+                v = d.view(self.active[k])
+                n = v["n_real"] + v["n_slots"]
+                lo, hi = self.rank * n // self.R, (self.rank + 1) * n // self.R
+                eng.d_grad(v["real"], v["fake"], lo, hi, self.d_grad, keep_prob=self.d_keep, rng_step=self._step())
+                self._allreduce(self.d_grad)
+                eng.d_apply(self.d_grad, loss_out=self.d_losses[j])
+        return self.d_losses
 
     def g_phase(self):
         d, eng = self.data, self.eng
@@ -106,7 +136,10 @@ class ShardedTrainer(Trainer):
                 go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step(), probe=pr)
                 rp_all = self._forward(v, v["fake"], go.fwd)
                 eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
-                self._allreduce(self.dh2[:B])
+                # exchange 3 flies while the decoder weight update (which needs none of it) runs
+                work = dist.all_reduce(self.dh2[:B], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go)
+                work.wait()
                 eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
             self.last_anneal.append(a)
         return self.g_losses

@@ -19,6 +19,7 @@ def main():
     from ltgan.synthetic import synthetic_index
     from ltgan.trainer import Trainer
     workload, users, precision = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    d_split = len(sys.argv) > 4 and sys.argv[4] == "dsplit"      # pair rows of the discriminator step split over the ranks
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda:0"
@@ -33,7 +34,8 @@ def main():
     lo, hi = item_slab(I, rank, world)
     eng = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi)
     data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
-    tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1)
+    tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1, d_split=d_split)
+    assert tr.d_split == d_split
     # ---- ranking metrics over the shards (before training: parameters are identical, only the all-reduce order differs)
     import scipy.sparse as sp
     from ltgan.dataset import EvalData
@@ -68,7 +70,7 @@ def main():
         assert torch.equal(data.fake_cnt, ref_tr.data.fake_cnt)
         dl_ref = ref_tr.d_phase().cpu().numpy()[:S, 0]
         dl = tr.d_phase().cpu().numpy()[:S, 0]
-        np.testing.assert_allclose(dl, dl_ref, rtol=1e-6)
+        np.testing.assert_allclose(dl, dl_ref, rtol=2e-5 if d_split else 1e-6)     # split: gradient and loss sums meet in another order
         gl_ref = ref_tr.g_phase().cpu().numpy()[:S, :6]
         gl = tr.g_phase().cpu().numpy()[:S, :6]
         tol = 2e-5 if precision == "fp32" else 2e-3
@@ -83,11 +85,11 @@ def main():
         err = (eng.g_p[i] - want).abs().max().item()
         assert err < atol * 50 if i not in (0, 3, 7) else err < atol * 50, ("gen tensor", i, err)
     for i in range(8):
-        assert (eng.d_p[i] - ref.d_p[i]).abs().max().item() < 1e-6, ("disc tensor", i)
+        assert (eng.d_p[i] - ref.d_p[i]).abs().max().item() < (2e-5 if d_split else 1e-6), ("disc tensor", i)
     assert eng.adam_t == ref.adam_t
     dist.barrier()
     if rank == 0:
-        print("SHARDED_OK world=%d workload=%s precision=%s" % (world, workload, precision))
+        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s" % (world, workload, precision, d_split))
     dist.destroy_process_group()
 
 

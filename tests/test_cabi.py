@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     lib = cabi.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 7
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 8
 
 
 def test_struct_layouts_match_header():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8
     assert C.sizeof(cabi.ltg_pairs) == 8 + 3 * 8
     assert C.sizeof(cabi.ltg_d_opts) == 8 + 8 + 7 * 8
-    assert C.sizeof(cabi.ltg_g_opts) == C.sizeof(cabi.ltg_fwd_opts) + 16 + 8 + 8 * 8
+    assert C.sizeof(cabi.ltg_g_opts) == C.sizeof(cabi.ltg_fwd_opts) + 16 + 8 + 8 * 8 + 8 and cabi.ltg_g_opts.dec1_done.offset == C.sizeof(cabi.ltg_g_opts) - 8
     assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8
     assert C.sizeof(cabi.ltg_probe) == 8 + 16
 
@@ -52,6 +52,9 @@ def test_argument_validation_returns_codes_without_gpu():
     assert lib.ltg_vae_forward(C.byref(good), None, None, None, None, None, None, 0, None) == -1
     assert lib.ltg_d_step(C.byref(good), None, None, None, None, None, None, 0, None) == -1
     assert lib.ltg_g_step(C.byref(good), None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ltg_d_grad(C.byref(good), None, None, None, 0, 0, None, None, None, 0, None) == -1
+    assert lib.ltg_d_apply(C.byref(good), None, None, 1, None, None) == -1
+    assert lib.ltg_d_grad_floats(C.byref(good)) == (161001 + 1 + 3) // 4 * 4 and lib.ltg_d_grad_floats(C.byref(bad)) == 0
     assert lib.ltg_sample_pairs(C.byref(good), None, None, None, None, None, None, None) == -1
     assert lib.ltg_rank_metrics(C.byref(good), None, None, None, 100, 20, 50, None, None) == -1
 

@@ -236,6 +236,48 @@ def test_d_step_parity(nr, nf):
         _check_adam_move(move_got, move_want, ad.m[k].reshape(-1), ad.lr_t(3), ("theta", k))
 
 
+@pytest.mark.parametrize("hs,nr,nf,cuts", [((100, 150, 250, 300), 900, 950, (0, 463, 925, 1388, 1850)), ((12, 20, 28, 16), 33, 7, (0, 1, 1, 35, 40)),
+                                           ((2048, 1024, 512, 256), 260, 250, (0, 255, 510))])
+def test_d_step_cut_at_the_gradient_exchange_equals_the_step(hs, nr, nf, cuts):
+    """ltg_d_grad over disjoint row ranges of the real | fake pair batch (what each rank of a pair-split run computes: the
+    ranges straddle the real / fake boundary, one is empty), the gradient vectors summed (the all-reduce), ltg_d_apply ==
+    ltg_d_step on the whole batch: same d_loss, same weights and Adam moments (up to the order of the partial sums)."""
+    import torch
+    from ltgan.engine import Pairs
+    I = 500
+    rng = np.random.default_rng(5)
+    D = O.init_discriminator(I, *hs, seed=3)
+    emb, darr = Hh.disc_to_engine(D)
+    a, b = _engine(I, "fp32", hs=hs, lr=1e-3), _engine(I, "fp32", hs=hs, lr=1e-3)
+    for e in (a, b):
+        e.set_discriminator(emb, darr)
+        e.adam_t = 6
+    dev = a.device
+
+    def mk(n):
+        pop = rng.integers(0, I, n).astype(np.int32)
+        nic = rng.integers(0, I, n).astype(np.int32)
+        hole = rng.random(n) < 0.05
+        pop[hole] = -1
+        nic[hole] = -1
+        return Pairs(torch.from_numpy(pop).to(dev), torch.from_numpy(nic).to(dev))
+
+    real, fake = mk(nr), mk(nf)
+    la = float(a.d_step(real, fake, 0.7, rng_step=31)[0].item())
+    total = torch.zeros(b.d_grad_floats(), dtype=torch.float32, device=dev)
+    part = torch.empty_like(total)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        b.d_grad(real, fake, lo, hi, part, keep_prob=0.7, rng_step=31)
+        total += part
+    lb = float(b.d_apply(total)[0].item())
+    torch.cuda.synchronize()
+    assert a.adam_t == b.adam_t == 7 and abs(la - lb) < 2e-6 * abs(la)
+    for i in range(8):
+        for xa, xb, what in ((a.d_m[i], b.d_m[i], "m"), (a.d_v[i], b.d_v[i], "v")):
+            assert Hh.rel_err(xb.cpu().numpy(), xa.cpu().numpy()) < 2e-5, (what, i)
+        assert (a.d_p[i] - b.d_p[i]).abs().max().item() < 0.02 * 1e-3, ("theta", i)     # 2 % of one Adam move
+
+
 # ------------------------------------------------------------------------------------------------
 # sampler (sample.py:40-67 + train.py:227-251) and ranking metrics (eval_functions.py)
 # ------------------------------------------------------------------------------------------------

@@ -10,10 +10,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("workload,users,precision", [("custom:1000", 250, "fp32"), ("ml20m", 200, "fp32"), ("ml20m", 200, "bf16")])
-def test_two_rank_item_sharding_matches_unsharded(workload, users, precision):
+@pytest.mark.parametrize("workload,users,precision,mode", [("custom:1000", 250, "fp32", ""), ("ml20m", 200, "fp32", ""), ("ml20m", 200, "bf16", ""),
+                                                           ("custom:1000", 250, "fp32", "dsplit")])
+def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mode):
+    """mode "dsplit": the discriminator's pair rows are split over the two ranks too (ltg_d_grad -> gradient all-reduce ->
+    ltg_d_apply) -- same d_loss trajectory and weights as the unsharded step."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), precision]
+           "--master-port", "29577", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), precision] + ([mode] if mode else [])
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "SHARDED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
