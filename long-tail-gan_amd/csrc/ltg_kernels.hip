@@ -1106,12 +1106,14 @@ __global__ __launch_bounds__(NT) void k_row_partial_seg(int I, int item_lo, cons
 // merge the segment partials of a row into one partial (same 5-float format); optionally also the row's lse
 __global__ __launch_bounds__(64) void k_row_partial_merge(int B, int nseg, const float* __restrict__ segpart,
                                                           float* __restrict__ rowpart, float* __restrict__ lse) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
+    // one wave per row, lanes over the segments (49 at 200 000 items): every partial is requested at once
+    const int b = blockIdx.x, lane = threadIdx.x;
     float M = -INFINITY;
-    for (int g = 0; g < nseg; ++g) M = fmaxf(M, segpart[((size_t)g * B + b) * RP]);
+    for (int g = lane; g < nseg; g += 64) M = fmaxf(M, segpart[((size_t)g * B + b) * RP]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
     float s = 0.f, xl = 0.f, ps = 0.f, nx = 0.f;
-    for (int g = 0; g < nseg; ++g) {
+    for (int g = lane; g < nseg; g += 64) {
         const float* q = segpart + ((size_t)g * B + b) * RP;
         const float sc = expf(q[0] - M);
         s += q[1] * sc;
@@ -1119,15 +1121,24 @@ __global__ __launch_bounds__(64) void k_row_partial_merge(int B, int nseg, const
         ps += q[3] * sc;
         nx += q[4];
     }
-    if (rowpart) {
-        float* o = rowpart + (size_t)b * RP;
-        o[0] = M;
-        o[1] = s;
-        o[2] = xl;
-        o[3] = ps;
-        o[4] = nx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        xl += __shfl_xor(xl, o);
+        ps += __shfl_xor(ps, o);
+        nx += __shfl_xor(nx, o);
     }
-    if (lse) lse[b] = M + logf(s);
+    if (lane == 0) {
+        if (rowpart) {
+            float* o = rowpart + (size_t)b * RP;
+            o[0] = M;
+            o[1] = s;
+            o[2] = xl;
+            o[3] = ps;
+            o[4] = nx;
+        }
+        if (lse) lse[b] = M + logf(s);
+    }
 }
 
 // Combine the R shards' row partials: lse, n_b, P_b per row, then the step scalars (train.py:145-157):
@@ -1980,7 +1991,7 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
         const int nseg = (I + RS_SEG - 1) / RS_SEG;
         hipLaunchKernelGGL(k_row_partial_seg, dim3(nseg, R), dim3(NT), 0, st, I, cfg->item_lo, bt->indptr, bt->indices, bt->values, acts->logits,
                            0, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, segpart);
-        hipLaunchKernelGGL(k_row_partial_merge, dim3((R + 63) / 64), dim3(64), 0, st, R, nseg, segpart, (float*)nullptr, acts->lse);
+        hipLaunchKernelGGL(k_row_partial_merge, dim3(R), dim3(64), 0, st, R, nseg, segpart, (float*)nullptr, acts->lse);
     } else
     hipLaunchKernelGGL(k_row_lse, dim3(R), dim3(NT), 0, st, I, acts->logits, acts->lse);
     if (probs_out) {
@@ -2225,7 +2236,7 @@ static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_
         const int nseg = (I + RS_SEG - 1) / RS_SEG;
         hipLaunchKernelGGL(k_row_partial_seg, dim3(nseg, B), dim3(NT), 0, st, I, cfg->item_lo, bt->indptr, bt->indices, bt->values, acts->logits,
                            fake ? fake->n : 0, fake ? fake->row : nullptr, fake ? fake->niche : nullptr, fake ? fake->pop : nullptr, segpart);
-        hipLaunchKernelGGL(k_row_partial_merge, dim3((B + 63) / 64), dim3(64), 0, st, B, nseg, segpart, rowpart, lse);
+        hipLaunchKernelGGL(k_row_partial_merge, dim3(B), dim3(64), 0, st, B, nseg, segpart, rowpart, lse);
         return;
     }
     hipLaunchKernelGGL(k_row_partial, dim3(bt->n_rows), dim3(NT), 0, st, cfg->n_items, cfg->item_lo, bt->indptr, bt->indices, bt->values,
@@ -2301,7 +2312,8 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
 //   stage 0: dz tiles + W_p1t (with_dec1: small item slabs; large ones ran the streaming kernel before)
 //   stage 1: dh1 tiles + W_p0        stage 2: W_q1, W_q0 (dense product when slot == NULL, else sweep + sparse rows), scalars
 static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
-                   const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st) {
+                   const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st,
+                   bool no_q0 = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     TailArgs a;
     a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
@@ -2312,7 +2324,7 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
     a.n2 = (stage == 1 || all) ? ((Z + 1 + 31) / 32) * ((H + 31) / 32) : 0;
     a.n3 = (stage == 2 || all) ? ((H + 1 + 31) / 32) * ((2 * Z + 31) / 32) : 0;
     a.n4 = 0;
-    if (stage == 2 || all) {
+    if ((stage == 2 || all) && !no_q0) {
         if (!slot) a.n4 = ((I + 1 + 31) / 32) * ((H + 31) / 32);
         else {
             const size_t total = (size_t)(I + 1) * (H / 4);
@@ -2356,7 +2368,16 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
     if (slot) g_enc0_grad(cfg, bt, o, acts, w, st);
-    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
+    const bool own_sweep = slot && cfg->n_items >= 8192;   // HBM-bound sweep: its own launch at full occupancy (measured 490 vs 525 us at
+                                                           // 200 000 items when it rode in the 118-register job kernel)
+    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st, own_sweep);
+    if (own_sweep) {
+        const int I = cfg->n_items;
+        const size_t total = (size_t)(I + 1) * (H / 4);
+        size_t gx = (total + NT - 1) / NT;
+        if (gx > 262144) gx = 262144;
+        LTG_PROBED(pr, LTG_K_ENC0_BWD_ADAM, hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, I, H, bt->n_unique, slot, w.gq0, *gen, ad));
+    }
 }
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
