@@ -257,6 +257,8 @@ def load_vectors(user_popular_data, user_niche_data, OVERLAP_COEFFS, ITEM_FEATUR
     n_ids = sp.n if sp is not None else oc.shape[0]
     valid = np.zeros(n_ids, bool)
     valid[[k for k in ITEM_FEATURE_DICT if 0 <= k < n_ids]] = True      # only the KEYS are used (a dict or a set of ids)
+    if sp is not None:
+        return _load_vectors_sparse(user_popular_data, user_niche_data, sp, valid, N)
     x_niche, x_pop = {}, {}
     for u in range(N):
         if u not in user_popular_data or u not in user_niche_data:
@@ -273,6 +275,115 @@ def load_vectors(user_popular_data, user_niche_data, OVERLAP_COEFFS, ITEM_FEATUR
     return x_niche, x_pop
 
 
+def _load_vectors_sparse(user_popular_data, user_niche_data, sp, valid, N):
+    """load_vectors over the co-occurrence CSR, all users at once: every (niche item, popular item) pair of every user is
+    scored in one vectorised pass (int64 count * 1.0 / float64 min -- the dense path's arithmetic), then a segmented
+    FIRST-maximum per (user, niche item) (strict '>' at data_processing.py:254)."""
+    users = [u for u in range(N) if u in user_popular_data and u in user_niche_data]
+    x_niche, x_pop = {}, {}
+    if not users:
+        return x_niche, x_pop
+    nic_l = [np.asarray(user_niche_data[u], dtype=np.int64) for u in users]
+    pop_l = [np.asarray(user_popular_data[u], dtype=np.int64) for u in users]
+    n_u = np.array([len(a) for a in nic_l])
+    p_u = np.array([len(a) for a in pop_l])
+    # one segment per (user, niche item) holding that user's popular items in file order
+    seg_len = np.repeat(p_u, n_u)
+    seg_nic = np.concatenate(nic_l)
+    seg_start = np.concatenate([[0], np.cumsum(seg_len)])
+    pop_off = np.concatenate([[0], np.cumsum(p_u)])
+    pop_cat = np.concatenate(pop_l)
+    seg_user = np.repeat(np.arange(len(users)), n_u)
+    pos_in_seg = np.arange(seg_start[-1]) - np.repeat(seg_start[:-1], seg_len)
+    pair_pop = pop_cat[np.repeat(pop_off[seg_user], seg_len) + pos_in_seg]
+    pair_nic = np.repeat(seg_nic, seg_len)
+    if not (sp.present[pair_pop].all() and sp.present[pair_nic].all()):
+        raise KeyError("overlap coefficient missing for a user's popular / niche item")   # the reference raises KeyError
+    cnt = np.asarray(sp.inter[pair_nic, pair_pop], dtype=np.int64).reshape(-1)
+    score = (cnt * 1.0) / (1.0 * np.minimum(sp.size[pair_nic], sp.size[pair_pop]).astype(np.float64))
+    nz = seg_len > 0
+    best = np.full(len(seg_len), -1, np.int64)
+    if nz.any():
+        mx = np.maximum.reduceat(score, seg_start[:-1][nz])
+        is_max = score == np.repeat(mx, seg_len[nz])
+        first = np.minimum.reduceat(np.where(is_max, pos_in_seg, np.iinfo(np.int64).max), seg_start[:-1][nz])
+        best[nz] = pair_pop[seg_start[:-1][nz] + first]
+    ok = valid[seg_nic] & valid[np.maximum(best, 0)] & (best >= 0)
+    u_off = np.concatenate([[0], np.cumsum(n_u)])
+    for k, u in enumerate(users):
+        sl = slice(u_off[k], u_off[k + 1])
+        o = ok[sl]
+        x_niche[u] = seg_nic[sl][o].tolist()
+        x_pop[u] = best[sl][o].tolist()
+    return x_niche, x_pop
+
+
+def _candidates_sorted_order(sp, nics, cur, niche_sorted, want):
+    """load_items_to_sample for one user when `NICHE_TAGS - curr_niche_tags` iterates in ascending id order: the stable
+    descending sort of data_processing.py:214 = tags with a positive score by (score desc, id asc), then zero-score tags by
+    id asc.  Only the tags that share a user with one of the user's niche items can have a positive score."""
+    rows = np.asarray(nics, dtype=np.int64)
+    if (~sp.present[rows]).any():
+        raise KeyError("overlap coefficient missing for a niche item of the user")
+    ip, ix, dt = sp.inter.indptr, sp.inter.indices, sp.inter.data
+    cols, vals = [], []
+    for r in rows.tolist():
+        c = ix[ip[r]:ip[r + 1]]
+        cols.append(c)
+        vals.append((dt[ip[r]:ip[r + 1]].astype(np.int64) * 1.0) / (1.0 * np.minimum(sp.size[r], sp.size[c]).astype(np.float64)))
+    cols = np.concatenate(cols).astype(np.int64)
+    vals = np.concatenate(vals)
+    cur_arr = np.asarray(sorted(cur), dtype=np.int64)
+    n_others = len(niche_sorted) - int(np.isin(cur_arr, niche_sorted, assume_unique=True).sum())
+    k = min(want, n_others)
+    # max score per co-occurring tag, restricted to niche tags outside the user's own
+    keep = np.isin(cols, niche_sorted) & ~np.isin(cols, cur_arr)
+    cols, vals = cols[keep], vals[keep]
+    order = np.lexsort((-vals, cols))
+    cols, vals = cols[order], vals[order]
+    first = np.concatenate([[True], cols[1:] != cols[:-1]]) if len(cols) else np.zeros(0, bool)
+    pid, pscore = cols[first], vals[first]                        # ascending id, max score each
+    pos = pscore > 0
+    pid, pscore = pid[pos], pscore[pos]
+    sel = pid[np.argsort(-pscore, kind="stable")][:k]             # stable: equal scores keep ascending id
+    if len(sel) < k:
+        need = k - len(sel)
+        excl = np.union1d(cur_arr, pid)
+        head = niche_sorted[:need + len(excl)]                    # enough of the smallest ids to survive the exclusion
+        zeros = head[~np.isin(head, excl, assume_unique=True)][:need]
+        sel = np.concatenate([sel, zeros])
+    picked = sorted([int(t) for t in nics] + sel.tolist())
+    return np.asarray(picked)
+
+
+def _cpython_set_difference_is_sorted(so_sorted, n_other):
+    """True when CPython's `so - other` (so: a set of non-negative ints, other: a set of n_other ints) is GUARANTEED to iterate
+    in ascending order: hash(i) == i, so an int sits in slot i & mask of the table, and when every element is below the table
+    size there are no collisions and table order is value order.  Table size of the result (Objects/setobject.c, 3.8+):
+      * len(so) >> 2 > len(other): the result is a COPY of so (set_merge into an empty table resized for 2 * used entries:
+        the smallest power of two above 2 * len(so)) from which other's elements are discarded;
+      * otherwise the elements are inserted one by one (growth by 4x, 2x above 50 000 entries, whenever the table is 3/5 full)."""
+    n = len(so_sorted)
+    if n == 0:
+        return True
+    top = int(so_sorted[-1])
+    if (n >> 2) > n_other:
+        size = 8
+        while size <= 2 * n:
+            size <<= 1
+        return top < size
+    mask, fill = 7, 0
+    for _ in range(max(0, n - n_other)):       # (the loop runs at most len(so) times, once per distinct other-count)
+        fill += 1
+        if fill * 5 >= mask * 3:
+            minused = fill * 2 if fill > 50000 else fill * 4
+            size = 8
+            while size <= minused:
+                size <<= 1
+            mask = size - 1
+    return top <= mask
+
+
 def load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP_COEFFS, N):
     """data_processing.py:170-224: candidate set = the user's niche items + the top
     max(2n, 10-n) other niche items ranked by their max overlap with any of the user's niche items;
@@ -282,6 +393,9 @@ def load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP
     oc = None if sp is not None else _matrix(OVERLAP_COEFFS)
     out = {}
     niche_set = set(NICHE_TAGS)
+    niche_sorted = np.asarray(sorted(niche_set), dtype=np.int64)
+    sorted_ok = {}          # number of distinct niche items of a user -> does `niche_set - cur` iterate in ascending order?
+    all_present = sp is not None and len(niche_sorted) > 0 and int(niche_sorted[-1]) < sp.n and bool(sp.present[niche_sorted].all())
     for u in range(N):
         if u not in user_popular_data or u not in user_niche_data:
             continue
@@ -291,6 +405,15 @@ def load_items_to_sample(user_popular_data, user_niche_data, NICHE_TAGS, OVERLAP
         cur = set()
         for t in nics:
             cur.add(t)
+        if sp is not None and all_present:
+            # large tag sets: when the set difference provably iterates in ascending id order, the candidates follow from the
+            # co-occurring tags alone (score > 0: by score, ties by id) and the smallest remaining ids (score 0) -- no
+            # O(|niche|) set operation per user
+            if len(cur) not in sorted_ok:
+                sorted_ok[len(cur)] = _cpython_set_difference_is_sorted(niche_sorted, len(cur))
+            if sorted_ok[len(cur)]:
+                out[u] = _candidates_sorted_order(sp, nics, cur, niche_sorted, want)
+                continue
         others = np.asarray(list(niche_set - cur), dtype=np.int64)  # CPython set-difference order
         picked = [int(t) for t in nics]
         if len(others) and sp is not None:

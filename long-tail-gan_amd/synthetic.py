@@ -108,3 +108,61 @@ def synthetic_index(name, users=None, seed=1234):
     desc = "synthetic %s-shaped: %d users x %d items, %d interactions (Zipf popularity, log-normal history length; SURVEY 8/d2), seed %d" % (
         name, N, I, train.nnz, seed)
     return idx, desc
+
+
+def write_dataset_dir(out_dir, n_items=20000, n_users=3000, n_eval_users=300, seed=7, niche_frac=0.9, missing_from_item_list=(7, 4242)):
+    """A synthetic dataset DIRECTORY in the reference's file formats (train.py:35-38,51,57,77,83-84,91-92; test.py:68-69), so
+    that the whole index path (ltgan.data_processing, i.e. the reference's data_processing.py:6-340) can be exercised above
+    the SPARSE_OVERLAP_MIN_TAGS switch where the dense I x I overlap table is no longer built:
+      item2id.txt "raw<TAB>id", item_list.txt / niche_items.txt / unique_item_id.txt one id per line, item_counts.csv
+      "userId,tagId,rating" (the user-tag file of load_overlap_coeff, raw tag ids), train_GAN*.csv / validation_* / test_*
+      "uid,sid".  Raw tag id = 100000 + id.  A few ids are left out of item_list.txt (invalid ids, Q9)."""
+    import os
+    rng = np.random.default_rng(seed)
+    os.makedirs(out_dir, exist_ok=True)
+    I = int(n_items)
+    row, item, _ = _histories(rng, n_users + 2 * n_eval_users, I)
+    n_pop = max(1, int(round(I * (1.0 - niche_frac))))
+    is_pop_item = np.zeros(I, bool)
+    is_pop_item[:n_pop] = True
+    raw = lambda ids: np.asarray(ids, np.int64) + 100000
+
+    def csv(name, u, s):
+        with open(os.path.join(out_dir, name), "w") as f:
+            f.write("uid,sid\n")
+            np.savetxt(f, np.stack([np.asarray(u, np.int64), np.asarray(s, np.int64)], 1), fmt="%d", delimiter=",")
+
+    tr = row < n_users
+    csv("train_GAN.csv", row[tr], item[tr])
+    csv("train_GAN_popular.csv", row[tr & is_pop_item[item]], item[tr & is_pop_item[item]])
+    csv("train_GAN_niche.csv", row[tr & ~is_pop_item[item]], item[tr & ~is_pop_item[item]])
+    for name, lo in (("validation", n_users), ("test", n_users + n_eval_users)):
+        sel = (row >= lo) & (row < lo + n_eval_users)
+        held = sel & (rng.random(len(row)) < 0.2)
+        csv(name + "_tr.csv", row[sel & ~held], item[sel & ~held])
+        csv(name + "_te.csv", row[held], item[held])
+    # the user-tag file: every (user, tag) interaction of the training users, plus "background" users (ids beyond the training
+    # range, 5 tags each) that cover the tags no training user touched -- the reference indexes OVERLAP_COEFFS[tag] for every
+    # niche tag (data_processing.py:200-211) and raises KeyError for a tag without users
+    cu, ct = row[tr], item[tr]
+    untouched = np.setdiff1d(np.arange(I), np.unique(ct))
+    bu = n_users + 2 * n_eval_users + np.arange(len(untouched)) // 5
+    cu, ct = np.concatenate([cu, bu]), np.concatenate([ct, untouched])
+    with open(os.path.join(out_dir, "item_counts.csv"), "w") as f:
+        f.write("userId,tagId,rating\n")
+        np.savetxt(f, np.stack([cu, raw(ct), np.ones(len(cu), np.int64)], 1), fmt="%d", delimiter=",")
+    with open(os.path.join(out_dir, "item2id.txt"), "w") as f:
+        for i in range(I):
+            f.write("%d\t%d\n" % (100000 + i, i))
+    skip = set(int(x) for x in missing_from_item_list if x < I)
+    with open(os.path.join(out_dir, "item_list.txt"), "w") as f:
+        for i in range(I):
+            if i not in skip:
+                f.write("%d\n" % (100000 + i))
+    with open(os.path.join(out_dir, "niche_items.txt"), "w") as f:
+        for i in range(n_pop, I):
+            f.write("%d\n" % (100000 + i))
+    with open(os.path.join(out_dir, "unique_item_id.txt"), "w") as f:
+        for i in range(I):
+            f.write("%d\n" % i)
+    return out_dir

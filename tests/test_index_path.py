@@ -144,3 +144,50 @@ def test_valid_item_ids_equal_the_one_hot_dict_keys(tmp_path):
     fdict, flen, _ = dp.load_item_one_hot_features(os.path.join(d, "item_list.txt"), show2id, 1000)
     ids = dp.load_valid_item_ids(os.path.join(d, "item_list.txt"), show2id)
     assert ids == set(fdict.keys()) and len(ids) == 997 and not ({418, 447, 595} & ids) and flen == 1000
+
+
+def test_set_difference_order_predicate_matches_cpython():
+    """_cpython_set_difference_is_sorted may only say True when `so - other` really iterates in ascending order on this
+    interpreter (the candidate ranking's tie order, SURVEY 8/c4b, then follows without performing the set operation)."""
+    rng = np.random.default_rng(0)
+    said_true = 0
+    for trial in range(300):
+        top = int(rng.choice([50, 1000, 5000, 40000]))
+        n = int(rng.integers(1, min(top, 6000)))
+        so = set(rng.choice(top, size=n, replace=False).tolist())
+        n_other = int(rng.integers(0, max(1, n // 2)))
+        other = set(rng.choice(sorted(so), size=min(n_other, n), replace=False).tolist()) if n_other else set()
+        if dp._cpython_set_difference_is_sorted(np.asarray(sorted(so)), len(other)):
+            said_true += 1
+            res = list(so - other)
+            assert res == sorted(res), (top, n, len(other))
+    assert said_true > 50
+
+
+def test_sparse_overlap_form_above_the_switch_is_bit_exact(tmp_path):
+    """SURVEY 8/f3 at a tag count above SPARSE_OVERLAP_MIN_TAGS: a synthetic dataset DIRECTORY in the reference's file
+    formats (9 000 tags) through the whole index path -- the co-occurrence CSR form (what load_overlap_coeff picks by itself
+    at this size; per-user work proportional to the co-occurring tags) against the dense I x I table: real pairs and
+    candidate sets identical, and IndexData.from_dir ingests the directory."""
+    from ltgan.dataset import IndexData
+    from ltgan.synthetic import write_dataset_dir
+    d = str(tmp_path / "syn9000")
+    I = 9000
+    assert I > dp.SPARSE_OVERLAP_MIN_TAGS
+    write_dataset_dir(d, n_items=I, n_users=1200, n_eval_users=60)
+    j = lambda n: os.path.join(d, n)
+    show2id, present, niche, _, _ = dp.load_pop_niche_tags(j("item2id.txt"), j("item_list.txt"), j("niche_items.txt"), I)
+    upop, unic = dp.load_user_items(j("train_GAN_popular.csv")), dp.load_user_items(j("train_GAN_niche.csv"))
+    train, _ = dp.load_train_data(j("train_GAN.csv"), I)
+    N = train.shape[0]
+    valid = dp.load_valid_item_ids(j("item_list.txt"), show2id)
+    assert len(valid) == I - 2 and 7 not in valid and 4242 not in valid
+    dense = dp.load_overlap_coeff(j("item2id.txt"), j("item_counts.csv"), sparse_form=False)
+    auto = dp.load_overlap_coeff(j("item2id.txt"), j("item_counts.csv"))
+    assert isinstance(auto, dp._SparseOverlapView) and isinstance(dense, dp._OverlapView)
+    a, b = dp.load_vectors(upop, unic, dense, valid, N), dp.load_vectors(upop, unic, auto, valid, N)
+    assert a[0] == b[0] and a[1] == b[1] and sum(len(v) for v in a[0].values()) > 3000
+    ca, cb = dp.load_items_to_sample(upop, unic, niche, dense, N), dp.load_items_to_sample(upop, unic, niche, auto, N)
+    assert ca.keys() == cb.keys() and all(np.array_equal(ca[k], cb[k]) for k in ca) and len(ca) > 900
+    idx = IndexData.from_dir(d)
+    assert idx.n_items == I and idx.N == N and int(idx.valid_item.sum()) == I - 2 and len(idx.cand_idx) == sum(len(v) for v in cb.values())
