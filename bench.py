@@ -228,11 +228,13 @@ class KernelProfiler:
         else:
             ach, peak, unit, bound = fl / (avg * 1e-3) / 1e12, peak_f / 1e12, "TFLOP/s", "mfma"
         traffic = None
-        try:   # PMC-derived HBM bytes per launch of this kernel on this workload, measured offline (profiles/README.md)
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                traffic = json.load(f)["workloads"][self.a.workload][name]["traffic_bytes"]
-        except Exception:
-            pass
+        for fn in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):   # PMC-derived HBM bytes per launch of this kernel on this workload,
+            try:                                                       # measured offline (profiles/README.md); newest round first
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    traffic = json.load(f)["workloads"][self.a.workload][name]["traffic_bytes"]
+                break
+            except Exception:
+                pass
         return {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                 "avg_us": avg * 1e3, "launches_timed": len(ms), "algorithmic_flops": fl, "algorithmic_bytes": by,
                 "note": "dominant kernel = largest (avg duration x launches per step) among the probed kernels"}

@@ -12,6 +12,14 @@
 
 #include "ltg_rgemm.h"
 
+// Workgroups b, b + 8, b + 16 ... share an XCD (and its L2) under the observed round-robin placement: give each XCD a CONTIGUOUS
+// run of the n tile ids, so that tiles of neighbouring rows (same A rows, all of B) meet in one L2 instead of all eight.
+// Speed only: any placement computes the same result.  Bijective for every n.
+__device__ __forceinline__ int xcd_chunk(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 typedef LtgRg<1, 1, 1, 1, 4> Rg16;    // 16 x 16 tile, four K slices
 typedef LtgRg<2, 2, 1, 1, 4> Rg32k;   // 32 x 32 tile, four K slices (each wave the whole tile)
 typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over the whole K
@@ -340,10 +348,12 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
                                               uint64_t seed, uint64_t step, float* __restrict__ A3, float* __restrict__ G3,
                                               float* __restrict__ spart) {
     __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tn = (h3 + 31) / 32;
+    const int tid_ = xcd_chunk(blockIdx.x, gridDim.x);
+    const int m0 = (tid_ / tn) * 32, n0 = (tid_ % tn) * 32;
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(A1 + (size_t)m * h12 + k); };
     auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld4s(w3 + (size_t)k * h3 + nn, h3); };
-    const int tile = blockIdx.x;
+    const int tile = tid_ % tn;
     const int pcol = min(n0 + (int)(threadIdx.x & 31), h3 - 1);
     const float b3v = b3[pcol], wv = w4[pcol];
     auto epi = [=] __device__(int, int m, int nn, float v, bool ok) {
@@ -403,7 +413,10 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
     int bid = blockIdx.x;
     if (bid < nA) {
         const int tn = (h12 + 31) / 32;
-        const int m0 = (bid / tn) * 32, n0 = (bid % tn) * 32;
+        const int nAt = ((n + 31) / 32) * tn;          // real job-A tiles; nA is padded to a multiple of 8 (job B starts on XCD 0)
+        const int ta = xcd_chunk(bid, nA);
+        if (ta >= nAt) return;
+        const int m0 = (ta / tn) * 32, n0 = (ta % tn) * 32;
         // requested up front, consumed later: the tile partials of this thread's pair row (threads 0..31) and the A1 values of
         // the four outputs this thread finishes -- neither costs a round trip of its own
         const int prow = min(m0 + (tid & 31), n - 1), pt = tid >> 5;            // thread -> (pair row, tile pt and pt + 8)
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
         return;
     }
     bid -= nA;
+    if (bid < nB) bid = xcd_chunk(bid, nB);            // a chunk of job B = the tiles of one or two row chunks z
     const int tmB = (h12 + 1 + 31) / 32, tnB = (h3 + 31) / 32;
     const int z = bid < nB ? bid / (tmB * tnB) : (bid - nB) / ((h3 + 2 + 31) / 32);
     const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK), K = kend - kbeg;

@@ -2049,7 +2049,7 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
         // A3, G3 (backward only) and the per-tile partial dot products of the output unit; y only when nothing else follows
         LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                                       d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
-        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk_d_l2, grid2(h3, n, 32, 32), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
+        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk_d_l2, dim3(((h3 + 31) / 32) * ((n + 31) / 32)), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
                                                       cfg->seed, step, w.A3, with_bwd ? w.G3 : (float*)nullptr, w.spart));
         if (!with_bwd) hipLaunchKernelGGL(fk_d_y, dim3((n + NT - 1) / NT), dim3(NT), 0, st, pv, (h3 + 31) / 32, w.spart, d->p[7], w.y);
         return;
@@ -2135,7 +2135,7 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
     const int ks = (n + D_KCHUNK - 1) / D_KCHUNK;
     if (d_fast(cfg)) {
         const int P = L.off[8], SP = d_slab_stride(P), ntile = (h3 + 31) / 32;
-        const int nA = ((n + 31) / 32) * ((h12 + 31) / 32);
+        const int nA = (((n + 31) / 32) * ((h12 + 31) / 32) + 7) & ~7;      // padded: job B starts on a multiple of 8 (XCD chunk map)
         const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
         const int nC = ks * ((h3 + 2 + 31) / 32);
         LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,

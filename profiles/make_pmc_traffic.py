@@ -1,6 +1,6 @@
-"""Builds r1_pmc_traffic.json from rocprofv3 --pmc passes (one counter per pass, no trace domains):
+"""Builds <round>_pmc_traffic.json (default r2) from rocprofv3 --pmc passes (one counter per pass, no trace domains):
 
-    python profiles/make_pmc_traffic.py <workload>=<FETCH_SIZE csv>,<WRITE_SIZE csv> ...
+    python profiles/make_pmc_traffic.py [--out r2_pmc_traffic.json] <workload>=<FETCH_SIZE csv>,<WRITE_SIZE csv> ...
 
 Per kernel: average FETCH_SIZE / WRITE_SIZE (KB) per launch and traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 --
 gfx950 tallies the 128-B requests of wide coalesced reads at 64 B (MI355X_MICROARCH.md, HBM section).  Keys are
@@ -13,7 +13,7 @@ import re
 import sys
 
 ALIAS = {"dh2_partial": "dh2", "dh2_stream": "dh2", "dec1_fwd_stream": "dec1_fwd", "dec1_bwd_adam_stream": "dec1_bwd_adam",
-         "dense_fwd<0>": "enc1", "dense_fwd<1>": "dec0", "row_partial_seg": "row_partial"}
+         "dense_fwd<0>": "enc1", "dense_fwd<1>": "dec0", "row_partial_seg": "row_partial", "dec1": "dec1_fwd"}
 
 
 def key(kernel_name):
@@ -22,7 +22,7 @@ def key(kernel_name):
     base = re.sub(r"<.*>", "", n)
     if base == "k_dense_fwd":
         base = n
-    base = base[2:] if base.startswith("k_") else base
+    base = base[3:] if base.startswith("fk_") else (base[2:] if base.startswith("k_") else base)     # round-2 kernels: fk_*
     return ALIAS.get(base, base)
 
 
@@ -38,9 +38,13 @@ def averages(path, counter):
 
 
 def main():
-    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r1_pmc_traffic.json")
+    args = sys.argv[1:]
+    name = "r2_pmc_traffic.json"
+    if args and args[0] == "--out":
+        name, args = args[1], args[2:]
+    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     doc = json.load(open(out_path)) if os.path.exists(out_path) else {"workloads": {}}
-    for arg in sys.argv[1:]:
+    for arg in args:
         wl, files = arg.split("=")
         f_csv, w_csv = files.split(",")
         fetch, n = averages(f_csv, "FETCH_SIZE")

@@ -1,4 +1,4 @@
-"""Per-kernel averages of an SQ counter pass (scripts/run_pmc_sq.sh) -> r1_v9_sq_summary.json.
+"""Per-kernel averages of an SQ counter pass (scripts/run_pmc_sq.sh) -> r2_sq_summary.json (SQ_SUMMARY_OUT overrides the name).
 MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 * kernel duration in shader cycles); the duration
 comes from the kernel-trace stats of the same build (r1_v9_*_kernel_stats.csv), the clock is the 2.4 GHz peak."""
 import collections
@@ -42,7 +42,7 @@ def main():
                           "mfma_util": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc), 4),
                           "wait_any_over_wave_cycles": round(a.get("SQ_WAIT_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
                           "launches": n[k]}
-    json.dump(out, open(os.path.join(HERE, "r1_v9_sq_summary.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(HERE, os.environ.get("SQ_SUMMARY_OUT", "r2_sq_summary.json")), "w"), indent=1)
     for wl in out:
         print(wl)
         for k, v in list(out[wl].items())[:12]:
