@@ -122,7 +122,7 @@ class KernelProfiler:
         ks = (n + 255) // 256
         stream = self.a.precision == "bf16" and I >= 8192 and I % 8 == 0 and B <= 128     # stream_ok() of csrc/ltg_kernels.hip
         if stream:
-            kchunk = -(-(-(-I // 256)) // 32) * 32           # dh2_stream_chunk()
+            kchunk = max(128, -(-(-(-I // 256)) // 32) * 32)  # dh2_stream_chunk()
         else:
             kchunk = max(256, -(-(-(-I // 64)) // 32) * 32)  # dh2_kchunk()
         nsplit = -(-I // kchunk)

@@ -243,32 +243,29 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
     }
 }
 
-// Sparse gradient rows of W_q0 (see k_enc0_grad): one 512-thread workgroup per (block of 256 columns, distinct item | bias
-// part), 8 entries in flight per wave.
-constexpr int G0_NT = 512, G0_NW = 8, G0_U = 8;
-__global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
-                                                      const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
-                                                      const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                      const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
-                                                      const float* __restrict__ row_scale, const float* __restrict__ da1,
-                                                      float* __restrict__ G, int item_lo, int Ig) {
-    __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][64];
-    const int u = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int H4 = H >> 2;
-    const int c4 = min(64 * cb + lane, H4 - 1);
+// Sparse gradient rows of W_q0 (see k_enc0_grad): a 512-thread workgroup takes EIGHT gradient rows (distinct items of the
+// batch, then the partial bias rows) of one block of 256 columns.  A row with at most G0_LIGHT entries -- almost every item of
+// a large item slab occurs once or twice in a 100-user batch -- is summed by ONE wave (its entries all in flight at once); the
+// head items of the popularity distribution (dozens of entries) are summed by the eight waves together, 8 entries in flight
+// per wave, partials meeting in LDS.  4 500 one-item workgroups -> 570 at 20 000 items.  The eight rows of a workgroup are
+// STRIDED over the row list (row j of group g = j * groups + g): the heavy rows are the lowest ids (popularity order) and
+// would otherwise all sit in the first group and run one after the other (measured: 35 us instead of 14).
+constexpr int G0_NT = 512, G0_NW = 8, G0_U = 8, G0_LIGHT = 16;
+__device__ __forceinline__ float4 enc0_grad_entries(int q0, int q1, int stride, bool is_item, int c4, int H4, const int32_t* __restrict__ rowidx,
+                                                    const int32_t* __restrict__ csr_pos, const int32_t* __restrict__ indices,
+                                                    const float* __restrict__ values, const uint8_t* __restrict__ drop_keep, float keep,
+                                                    uint64_t seed, uint64_t step, const float* __restrict__ row_scale,
+                                                    const float4* __restrict__ d4, int item_lo, int Ig) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* d4 = reinterpret_cast<const float4*>(da1);
-    const int bp = u - nu, per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
-    const int q0 = u < nu ? uptr[u] : min(B, bp * per), q1 = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
-    for (int q = q0 + w; q < q1; q += G0_U * G0_NW) {
+    for (int q = q0; q < q1; q += G0_U * stride) {
         int b[G0_U];
         float sc[G0_U];
 #pragma unroll
         for (int t = 0; t < G0_U; ++t) {
-            const int qt = q + t * G0_NW;
+            const int qt = q + t * stride;
             const bool ok = qt < q1;
             const int qc = ok ? qt : q;
-            if (u < nu) {   // uniform
+            if (is_item) {   // uniform
                 b[t] = rowidx[qc];
                 const int pos = csr_pos[qc];
                 const int it = indices[pos];
@@ -291,16 +288,62 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
             acc.w += sc[t] * d[t].w;
         }
     }
-    s_g[w][lane] = acc;
-    __syncthreads();
-    if (tid < 64 && 64 * cb + tid < H4) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    return acc;
+}
+__global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
+                                                      const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
+                                                      const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                      const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
+                                                      const float* __restrict__ row_scale, const float* __restrict__ da1,
+                                                      float* __restrict__ G, int item_lo, int Ig) {
+    __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][64];
+    const int cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H4 = H >> 2, nrows = nu + ENC0_BIAS_PARTS;
+    const int c4 = min(64 * cb + lane, H4 - 1);
+    const bool cok = 64 * cb + lane < H4;
+    const float4* d4 = reinterpret_cast<const float4*>(da1);
+    float4* G4 = reinterpret_cast<float4*>(G);
+    const int per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+    // entry ranges of the group's eight rows (every wave computes all eight: the heavy / light split must be uniform)
+    int q0[G0_NW], q1[G0_NW];
 #pragma unroll
-        for (int i = 0; i < G0_NW; ++i) {
-            const float4 p = s_g[i][tid];
-            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+    for (int j = 0; j < G0_NW; ++j) {
+        const int u = min(j * (int)gridDim.y + (int)blockIdx.y, nrows - 1);
+        const int bp = u - nu;
+        q0[j] = u < nu ? uptr[u] : min(B, bp * per);
+        q1[j] = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
+        if (j * (int)gridDim.y + (int)blockIdx.y >= nrows) q1[j] = q0[j];     // beyond the last row: empty
+    }
+    // light rows: wave j alone
+#pragma unroll
+    for (int j = 0; j < G0_NW; ++j) {
+        const int u = j * (int)gridDim.y + (int)blockIdx.y;
+        if (j == w && u < nrows && q1[j] - q0[j] <= G0_LIGHT) {
+            const float4 acc = enc0_grad_entries(q0[j], q1[j], 1, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step,
+                                                 row_scale, d4, item_lo, Ig);
+            if (cok) G4[(size_t)u * H4 + c4] = acc;
         }
-        reinterpret_cast<float4*>(G)[(size_t)u * H4 + 64 * cb + tid] = t;
+    }
+    // heavy rows: all eight waves, one row after the other
+#pragma unroll
+    for (int j = 0; j < G0_NW; ++j) {
+        const int u = j * (int)gridDim.y + (int)blockIdx.y;
+        if (u < nrows && q1[j] - q0[j] > G0_LIGHT) {     // uniform over the workgroup
+            const float4 acc = enc0_grad_entries(q0[j] + w, q1[j], G0_NW, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed,
+                                                 step, row_scale, d4, item_lo, Ig);
+            __syncthreads();
+            s_g[w][lane] = acc;
+            __syncthreads();
+            if (w == 0 && cok) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < G0_NW; ++i) {
+                    const float4 p = s_g[i][lane];
+                    t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+                }
+                G4[(size_t)u * H4 + c4] = t;
+            }
+        }
     }
 }
 

@@ -1241,6 +1241,94 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
     }
 }
 
+// The same with the combine of the R shards' row partials folded in (no k_g_combine launch in front): every workgroup merges
+// the R x 5 partials of ITS row (uniform addresses: scalar loads) and adds up sum_j y_j itself; the segment-0 workgroups also
+// publish lse, and workgroup (0, 0) the step's scalars (train.py:154-157).  Same arithmetic and order as k_g_combine.
+__global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, const int32_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                        const float* __restrict__ logits, const float* __restrict__ rowpart_all,
+                                                        const float* __restrict__ kl_rows, const float* __restrict__ y,
+                                                        const int32_t* __restrict__ cnt, float anneal, float lam, int nf,
+                                                        const int32_t* __restrict__ f_row, const int32_t* __restrict__ f_gen,
+                                                        const int32_t* __restrict__ f_pop, float* __restrict__ dlog, float* __restrict__ lse,
+                                                        float* __restrict__ out, float* __restrict__ out2, int item_lo) {
+    __shared__ float s_x[DL_SEG];
+    __shared__ uint8_t s_s[DL_SEG];
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG;
+    const int i1 = min(I, i0 + DL_SEG);
+    for (int j = threadIdx.x; j < DL_SEG; j += NT) {
+        s_x[j] = 0.f;
+        s_s[j] = 0;
+    }
+    float sy = 0.f;
+    if (y)
+        for (int q = threadIdx.x; q < nf; q += NT) sy += y[q];
+    __syncthreads();
+    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+        const int it = indices[e];
+        if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
+    }
+    for (int q = threadIdx.x; q < nf; q += NT) {
+        const int it = f_gen[q] - item_lo;  // fake pairs carry global item ids
+        if (f_row[q] == b && f_gen[q] >= 0 && it >= i0 && it < i1 && f_pop[q] >= 0) s_s[it - i0] = 1;
+    }
+    sy = block_sum(sy, red);   // (its barriers also publish s_x / s_s)
+    auto row_terms = [=] __device__(int rb, float& l, float& nx, float& pb, float& xl) {
+        float M = -INFINITY;
+        for (int r = 0; r < R; ++r) M = fmaxf(M, rowpart_all[((size_t)r * B + rb) * RP]);
+        float se = 0.f;
+        xl = 0.f;
+        nx = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
+            se += q[1] * expf(q[0] - M);
+            xl += q[2];
+            nx += q[4];
+        }
+        l = M + logf(se);
+        pb = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
+            pb += q[3] * expf(q[0] - l);
+        }
+    };
+    float l, nx, pb, xl;
+    row_terms(b, l, nx, pb, xl);
+    const float invB = 1.f / (float)B;
+    const float c = (cnt && cnt[0] > 0) ? lam / (float)cnt[0] * sy : 0.f;
+    const float alpha = nx * invB + c * pb;
+    const size_t base = (size_t)b * I;
+    for (int i = i0 + threadIdx.x; i < i1; i += NT) {
+        const float p = expf(logits[base + i] - l);
+        dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) lse[b] = l;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {   // the step's scalars: out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
+        float a = 0.f, k = 0.f, pp = 0.f;
+        for (int rb = threadIdx.x; rb < B; rb += NT) {
+            float l2, nx2, pb2, xl2;
+            row_terms(rb, l2, nx2, pb2, xl2);
+            a += -xl2 + nx2 * l2;
+            if (kl_rows) k += kl_rows[rb];
+            pp += pb2;
+        }
+        a = block_sum(a, red);
+        k = block_sum(k, red);
+        pp = block_sum(pp, red);
+        if (threadIdx.x == 0) {
+            const float negll = a / (float)B, KL = k / (float)B;
+            const float vae = negll + anneal * KL, gan = -c * pp;
+            const float r6[6] = {vae + gan, vae, gan, pp, sy, c};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (out) out[i] = r6[i];
+                if (out2) out2[i] = r6[i];
+            }
+        }
+    }
+}
+
 // dh2 partials: part[z][b][h] = sum_{i in split z} dlog[b][i] * W_p1t[i][h]   (split-K over items)
 template <bool BF16, bool BIG, bool V = false>
 __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kchunk, const float* __restrict__ dlog,
@@ -1264,34 +1352,21 @@ __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kch
 // da2 = (sum_z part) * (1 - h2^2)
 __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __restrict__ part, const float* __restrict__ h2,
                                             float* __restrict__ da2) {
-    // n % 4 == 0 (H % 4 == 0): 16 B per lane, 8 slabs in flight
-    const int n4 = n >> 2;
-    const float4* p4 = reinterpret_cast<const float4*>(part);
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n4; i += gridDim.x * NT) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // one output per thread (B H = 60 000 outputs -> 235 workgroups instead of 59 with float4), 16 slabs in flight; the slabs
+    // are added in ascending order whatever the unroll: bitwise the same sum as a serial walk
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        float s = 0.f;
         int z = 0;
-        for (; z + 8 <= nsplit; z += 8) {
-            float4 x[8];
+        for (; z + 16 <= nsplit; z += 16) {
+            float x[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p4[(size_t)(z + u) * n4 + i];
+            for (int u = 0; u < 16; ++u) x[u] = part[(size_t)(z + u) * n + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                s.x += x[u].x;
-                s.y += x[u].y;
-                s.z += x[u].z;
-                s.w += x[u].w;
-            }
+            for (int u = 0; u < 16; ++u) s += x[u];
         }
-        for (; z < nsplit; ++z) {
-            const float4 x = p4[(size_t)z * n4 + i];
-            s.x += x.x;
-            s.y += x.y;
-            s.z += x.z;
-            s.w += x.w;
-        }
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h2) t = reinterpret_cast<const float4*>(h2)[i];
-        reinterpret_cast<float4*>(da2)[i] = make_float4(s.x * (1.f - t.x * t.x), s.y * (1.f - t.y * t.y), s.z * (1.f - t.z * t.z), s.w * (1.f - t.w * t.w));
+        for (; z < nsplit; ++z) s += part[(size_t)z * n + i];
+        const float t = h2 ? h2[i] : 0.f;
+        da2[i] = s * (1.f - t * t);
     }
 }
 
@@ -1771,8 +1846,11 @@ inline bool stream_ok(const ltg_config* cfg, const ltg_gen_state* gen, int rows)
 // k_dec1_bwd_adam_stream walks the 4 H/4 float4 a wave owns per tile as exactly ten 64-lane accesses
 inline bool dw_stream_ok(int H) { return (H % 4) == 0 && H > 576 && H <= 640; }
 inline int dh2_stream_chunk(int I) {
+    // items per workgroup of k_dh2_stream = one partial [B][H] slab each: up to 256 workgroups, but at least 4 tiles per
+    // workgroup -- at 20 000 items 157 slabs instead of 209 (each slab is 240 KB written and read once more by k_da2)
     int c = (I + 255) / 256;
-    return (c + ST_BN - 1) / ST_BN * ST_BN;
+    c = (c + ST_BN - 1) / ST_BN * ST_BN;
+    return c < 4 * ST_BN ? 4 * ST_BN : c;
 }
 
 inline int dh2_kchunk(int I) {
@@ -2256,10 +2334,16 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
         DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
     }
+    if (fast_on(cfg)) {
+        hipLaunchKernelGGL(k_dlogits_combine, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, n_ranks, bt->indptr, bt->indices, bt->values,
+                           acts->logits, rowpart_all, acts->kl_rows, nf > 0 ? w.y : (const float*)nullptr, o->cnt, o->anneal, o->gan_lambda, nf,
+                           fake->row, fake->niche, fake->pop, w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo);
+    } else {
     hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, st, B, n_ranks, rowpart_all, nf, acts->kl_rows, nf > 0 ? w.y : nullptr, o->cnt,
                        o->anneal, o->gan_lambda, acts->lse, w.nb, w.Pb, w.scal, loss_out);
     hipLaunchKernelGGL(k_dlogits, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, bt->indptr, bt->indices, bt->values,
                        acts->logits, acts->lse, w.nb, w.Pb, w.scal, nf, fake->row, fake->niche, fake->pop, w.dlog, cfg->item_lo);
+    }
     const bool stream = stream_ok(cfg, gen, B);
     const int kchunk = stream ? dh2_stream_chunk(I) : dh2_kchunk(I);
     const int nsplit = (I + kchunk - 1) / kchunk;
@@ -2275,7 +2359,7 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     pr.after(LTG_K_DH2);
     {
         const int n = B * H;
-        const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
+        const int gx = (n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048;
         // slab sum; the single-GPU path folds the tanh derivative in (dh2_out is then already da2)
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, nsplit, w.part, h2_for_da2, dh2_out);
     }
@@ -2298,7 +2382,7 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_GRAD);
     if (fast_on(cfg))
-        hipLaunchKernelGGL(fk_enc0_grad, dim3((H / 4 + 63) / 64, nu + ENC0_BIAS_PARTS), dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos,
+        hipLaunchKernelGGL(fk_enc0_grad, dim3((H / 4 + 63) / 64, (nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW), dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos,
                            bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0,
                            cfg->item_lo, Ig_of(cfg));
     else

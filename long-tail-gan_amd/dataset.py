@@ -141,10 +141,11 @@ class DeviceData:
         """item_lo/item_hi: this rank's item slab (multi-GPU item sharding).  Only the interaction matrix is
         cut (columns [item_lo, item_hi), re-indexed from 0); pair / candidate / popular lists keep global ids
         and are identical on every rank.
-        slot_cache: keep the per-batch item -> gradient-row maps (n_batches x I int32) on the device; None = only for
-        small item slabs (< 8192 items: two launches fewer per step).  Without it the library rebuilds the map of a batch
-        in its workspace each step -- measured FASTER at I = 200 000 (50.3 vs 56.5 ms per 32-step epoch: the one map in
-        the workspace stays in L2, 64 cold 800-KB maps do not) and it removes the n_batches x I memory."""
+        slot_cache: keep the per-batch item -> gradient-row maps (n_batches x I int32) on the device; None = for item slabs
+        below 65 536 items (two launches = ~16 us fewer per G step; 1 GB for 10 000 batches of a 25 000-item slab).  Without
+        it the library rebuilds the map of a batch in its workspace each step -- measured FASTER at I = 200 000 (50.3 vs
+        56.5 ms per 32-step epoch: the one map in the workspace stays in L2, 64 cold 800-KB maps do not) and it removes
+        the n_batches x I memory (8 GB at 10 000 batches)."""
         self.idx, self.BS, self.device = idx, int(batch_size), torch.device(device)
         N = idx.N
         self.item_lo, self.item_hi = int(item_lo), int(idx.n_items if item_hi is None else item_hi)
@@ -166,7 +167,7 @@ class DeviceData:
         self.values = None if ones else up(tr.data, np.float32)
         slots, uptrs, rowidx, cpos, ent_off, uptr_off = [], [], [], [], [0], [0]
         if slot_cache is None:
-            slot_cache = I < 8192
+            slot_cache = I < 65536
         for b in range(self.n_batches):
             lo, hi = b * self.BS, min(N, (b + 1) * self.BS)
             sl, up_, ri, ps = batch_csc(tr, lo, hi, I)
