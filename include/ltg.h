@@ -94,6 +94,15 @@ typedef struct ltg_disc_state {
     float* p[8];
     float* m[8];
     float* v[8];
+    /* optional OPERAND-FORMAT shadows for d_precision = LTG_PREC_FP8 (all four or none; every layer size a multiple of 64):
+     * OCP e4m3 bytes with the mode's static scales (embeddings and weights 2^8), k-contiguous for the forward GEMMs --
+     * emb_fp8 [F][h0], w1t_fp8 [h1][h0], w2t_fp8 [h2][h0], w3t_fp8 [h3][h1+h2] (the weight shadows TRANSPOSED).  Built by
+     * ltg_refresh_d_shadow, kept in step by the Adam sweep of ltg_d_step / ltg_d_apply.  When present the two forward layers
+     * read 1 byte per operand element instead of converting 4-byte values on the fly. */
+    const uint8_t* emb_fp8;
+    uint8_t* w1t_fp8;
+    uint8_t* w2t_fp8;
+    uint8_t* w3t_fp8;
 } ltg_disc_state;
 
 /* A batch of user rows in CSR form (replaces the dense [B,I] float32 feed of train.py:194-198).
@@ -301,6 +310,8 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
                            ltg_stream stream);
 /* (re)build gen->wp1t_bf16 from gen->p[3] (after initialisation or after loading weights). */
 int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream);
+/* (re)build the e4m3 operand shadows of the discriminator (ltg_disc_state.emb_fp8 ... w3t_fp8) from the fp32 tensors. */
+int ltg_refresh_d_shadow(const ltg_config* cfg, const ltg_disc_state* disc, ltg_stream stream);
 
 /* Ranking metrics on device: replaces pred[X.nonzero()] = -inf (Codes/train.py:341) +
  * NDCG_binary_at_k_batch / Recall_at_k_batch (Codes/eval_functions.py:11-62).

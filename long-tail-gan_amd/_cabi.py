@@ -35,7 +35,8 @@ class ltg_gen_state(C.Structure):
 
 
 class ltg_disc_state(C.Structure):
-    _fields_ = [("emb", vp), ("p", vp * 8), ("m", vp * 8), ("v", vp * 8)]
+    _fields_ = [("emb", vp), ("p", vp * 8), ("m", vp * 8), ("v", vp * 8),
+                ("emb_fp8", vp), ("w1t_fp8", vp), ("w2t_fp8", vp), ("w3t_fp8", vp)]      # optional e4m3 operand shadows
 
 
 class ltg_batch(C.Structure):
@@ -113,6 +114,7 @@ SYMBOLS = {
                                  C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
     "ltg_gather_cand_logits": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp]),
     "ltg_refresh_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
+    "ltg_refresh_d_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,
                                    C.c_int32, C.c_int32, vp, vp]),
     "ltg_rank_scores": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), vp, vp]),

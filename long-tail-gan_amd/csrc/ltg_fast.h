@@ -1036,3 +1036,175 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// wide discriminator, LTG_PREC_FP8 (BASELINE config 5): forward layers fed from OPERAND-FORMAT storage
+// ---------------------------------------------------------------------------------------------------------------------
+// The fp8 mode of round 1 read every operand as fp32 and converted it on the way into LDS: 4 bytes moved per 1-byte operand,
+// bound by L2 traffic (d_l1: 101 us for 11.5 GFLOP).  Here the operands LIVE in e4m3, k-contiguous: the frozen embedding table
+// (emb_fp8 [F][h0], scale 2^8), transposed weight shadows (w1t [h1][h0], w2t [h2][h0], w3t [h3][h1+h2], scale 2^8; refreshed
+// by the Adam sweep) and the branch layers' output (A1_fp8 [n][h1+h2], scale 2^6, written by the producing epilogue next to
+// the fp32 copy the backward reads).  Same static scales and the same conversion (ltg_f2fp8) as before: the values the MFMA
+// sees are bit-identical to the on-the-fly path, so the parity against the quantised oracle is unchanged.
+//
+// Block: 64 x 64 outputs per workgroup, each wave 32 x 32 over the whole K, no LDS: lane (r, q) requests 16 bytes
+// k = 64 jb + 16 q .. + 15 of its row / column and the two MFMA steps of the block (v_mfma_f32_16x16x32_fp8_fp8) consume
+// bytes 0-7 and 8-15 -- the k permutation both operands share.  Two register sets of four 64-byte blocks ping-pong: the
+// requests of the next pass are in flight while this one multiplies.
+// a_ld(t, m, k) / b_ld(t, k, n): PURE requests (t = which of the wave's two row / column tiles); a_mask(t) = all ones, or 0 to
+// zero that row's operand (a hole in the pair list) -- applied when the registers are consumed, so that no arithmetic sits
+// between the requests (a select next to its load makes the compiler wait for that load before issuing the next one).
+template <class ALD, class AMK, class BLD, class EF>
+__device__ __forceinline__ void ltg_rgemm8(int M, int N, int K, int m0, int n0, ALD a_ld, AMK a_mask, BLD b_ld, float scale, EF epi) {
+    constexpr int NB = 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    int am[2], bn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        am[t] = min(m0 + (wm * 2 + t) * 16 + r, M - 1);
+        bn[t] = min(n0 + (wn * 2 + t) * 16 + r, N - 1);
+    }
+    ltg_f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nblk = K >> 6;   // K % 64 == 0
+    const unsigned amk[2] = {a_mask(0), a_mask(1)};
+    ltg_u32x4 a0[NB][2], b0[NB][2], a1[NB][2], b1[NB][2];
+#define RG8_LOAD(A, B, base)                                                   \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                           \
+        const int k = 64 * min((base) + i, nblk - 1) + 16 * q;                 \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                        \
+            A[i][t] = a_ld(t, am[t], k);                                       \
+            B[i][t] = b_ld(t, k, bn[t]);                                       \
+        }                                                                      \
+    }
+#define RG8_MMA(A, B, base)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                                         \
+        if ((base) + i < nblk) { /* wave-uniform */                                                                          \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                    \
+                _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                             \
+                    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                                       \
+                        const long av = (long)(((unsigned long)(A[i][tm][2 * s + 1] & amk[tm]) << 32) | (A[i][tm][2 * s] & amk[tm])); \
+                        const long bv = (long)(((unsigned long)B[i][tn][2 * s + 1] << 32) | B[i][tn][2 * s]);               \
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av, bv, acc[tm][tn], 0, 0, 0);               \
+                    }                                                                                                        \
+        }                                                                                                                    \
+    }
+    RG8_LOAD(a0, b0, 0)
+    for (int base = 0; base < nblk; base += 2 * NB) {
+        RG8_LOAD(a1, b1, base + NB)
+        __builtin_amdgcn_sched_barrier(0);
+        RG8_MMA(a0, b0, base)
+        __builtin_amdgcn_sched_barrier(0);
+        RG8_LOAD(a0, b0, base + 2 * NB)
+        __builtin_amdgcn_sched_barrier(0);
+        RG8_MMA(a1, b1, base + NB)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef RG8_LOAD
+#undef RG8_MMA
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int m = m0 + (wm * 2 + tm) * 16 + 4 * q + x, n = n0 + (wn * 2 + tn) * 16 + r;
+                if (m < M && n < N) epi(tn, m, n, acc[tm][tn][x] * scale);
+            }
+}
+
+__device__ __forceinline__ ltg_u32x4 ltg_ld16(const uint8_t* __restrict__ p) { return *reinterpret_cast<const ltg_u32x4*>(p); }
+// tanh by one hardware exponential and one reciprocal (absolute error ~2e-7): the epilogues of the e4m3 layers, whose outputs are
+// rounded to 3 mantissa bits anyway -- libm's tanhf is ~40 instructions per element and these epilogues are issue-bound (SQ
+// counters: waves active 87 % of the time, MFMA busy 7 %)
+__device__ __forceinline__ float ltg_tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
+// branch layers from e4m3 storage: blockIdx.z = 0 popular -> h1, 1 niche -> h2
+__global__ __launch_bounds__(NT) void fk8_d_l1(PairView pv, int h0, int h1, int h2, const uint8_t* __restrict__ emb8,
+                                               const uint8_t* __restrict__ w1t8, const float* __restrict__ b1,
+                                               const uint8_t* __restrict__ w2t8, const float* __restrict__ b2, DropView dA, DropView dB,
+                                               float keep, uint64_t seed, uint64_t step, float* __restrict__ A1, uint8_t* __restrict__ A1_8) {
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    // 1-D grid of 8 x per x row-tiles blocks.  Blocks b, b + 8, ... share an XCD: XCD x takes the `per` consecutive COLUMN tiles
+    // x per .. x per + per - 1 (of the tn1 + tn2 column tiles of both branches) for every row tile, so the weight rows an
+    // XCD streams are 1/8 of the shadows (393 KB at the wide sizes) and stay in its 4-MiB L2 next to the embedding table --
+    // with the natural order every XCD walked all 3 MB of weights + 2 MB of embeddings and was served from beyond its L2
+    // (57 us; PMC).  Speed only.
+    const int tn1 = (h1 + 63) / 64, tn2 = (h2 + 63) / 64, tm = (n + 63) / 64;
+    const int per = (tn1 + tn2 + 7) / 8;
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int ct = x * per + i % per, rt = i / per;
+    if (ct >= tn1 + tn2 || rt >= tm) return;
+    const bool br = ct >= tn1;
+    const int N = br ? h2 : h1;
+    const int m0 = rt * 64, n0 = (br ? ct - tn1 : ct) * 64;
+    const uint8_t* Wt = br ? w2t8 : w1t8;
+    const float* bias = br ? b2 : b1;
+    const int coff = br ? h1 : 0;
+    // the embedding rows of this lane's two operand rows (ids requested once, not per k block)
+    const int lane = threadIdx.x & 63, wm = threadIdx.x >> 7;
+    const uint8_t* erow[2];
+    unsigned emask[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = min(m0 + (wm * 2 + t) * 16 + (lane & 15), n - 1);
+        const int id = br ? pv.nic(m) : pv.pop(m);
+        erow[t] = emb8 + (size_t)max(id, 0) * h0;
+        emask[t] = id >= 0 ? 0xFFFFFFFFu : 0u;
+    }
+    auto a_ld = [=] __device__(int t, int, int k) { return ltg_ld16(erow[t] + k); };
+    auto a_mask = [=] __device__(int t) { return emask[t]; };
+    auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld16(Wt + (size_t)nn * h0 + k); };
+    const int wn = (threadIdx.x >> 6) & 1;
+    const float biasv[2] = {bias[min(n0 + (wn * 2) * 16 + (lane & 15), N - 1)], bias[min(n0 + (wn * 2 + 1) * 16 + (lane & 15), N - 1)]};   // requested up front
+    auto epi = [=] __device__(int tn, int m, int nn, float v) {
+        const float t = ltg_tanh_fast(v + biasv[tn]);
+        const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
+        const float a = kp ? t / keep : 0.f;
+        A1[(size_t)m * h12 + coff + nn] = a;
+        A1_8[(size_t)m * h12 + coff + nn] = ltg_f2fp8(a * (float)(1 << FP8_S_ACT));
+    };
+    ltg_rgemm8(n, N, h0, m0, n0, a_ld, a_mask, b_ld, 1.f / (float)(1 << (FP8_S_EMB + FP8_S_W)), epi);
+}
+
+// fully connected layer from e4m3 storage
+__global__ __launch_bounds__(NT) void fk8_d_l2(int n, int h12, int h3, const uint8_t* __restrict__ A1_8, const uint8_t* __restrict__ w3t8,
+                                               const float* __restrict__ b3, DropView dC, float keep, uint64_t seed, uint64_t step,
+                                               float* __restrict__ A3) {
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld16(A1_8 + (size_t)m * h12 + k); };
+    auto a_mask = [=] __device__(int) { return 0xFFFFFFFFu; };
+    auto b_ld = [=] __device__(int, int k, int nn) { return ltg_ld16(w3t8 + (size_t)nn * h12 + k); };
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+    const float biasv[2] = {b3[min(n0 + (wn * 2) * 16 + (lane & 15), h3 - 1)], b3[min(n0 + (wn * 2 + 1) * 16 + (lane & 15), h3 - 1)]};
+    auto epi = [=] __device__(int tn, int m, int nn, float v) {
+        const float t = ltg_tanh_fast(v + biasv[tn]);
+        A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
+    };
+    ltg_rgemm8(n, h3, h12, m0, n0, a_ld, a_mask, b_ld, 1.f / (float)(1 << (FP8_S_ACT + FP8_S_W)), epi);
+}
+
+// (re)build the e4m3 operand shadows of the discriminator from the fp32 tensors: emb8 [F][h0] and the TRANSPOSED weights
+__global__ __launch_bounds__(NT) void k_d_shadow(int F, int h0, int h1, int h2, int h3, const float* __restrict__ emb, const float* __restrict__ w1,
+                                                 const float* __restrict__ w2, const float* __restrict__ w3, uint8_t* __restrict__ emb8,
+                                                 uint8_t* __restrict__ w1t8, uint8_t* __restrict__ w2t8, uint8_t* __restrict__ w3t8) {
+    const size_t nE = (size_t)F * h0, n1 = (size_t)h0 * h1, n2 = (size_t)h0 * h2, n3 = (size_t)(h1 + h2) * h3;
+    const size_t total = nE + n1 + n2 + n3;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        if (e < nE) emb8[e] = ltg_f2fp8(emb[e] * (float)(1 << FP8_S_EMB));
+        else if (e < nE + n1) {
+            const size_t i = e - nE, k = i / h1, nn = i % h1;
+            w1t8[nn * h0 + k] = ltg_f2fp8(w1[i] * (float)(1 << FP8_S_W));
+        } else if (e < nE + n1 + n2) {
+            const size_t i = e - nE - n1, k = i / h2, nn = i % h2;
+            w2t8[nn * h0 + k] = ltg_f2fp8(w2[i] * (float)(1 << FP8_S_W));
+        } else {
+            const size_t i = e - nE - n1 - n2, k = i / h3, nn = i % h3;
+            w3t8[nn * (size_t)(h1 + h2) + k] = ltg_f2fp8(w3[i] * (float)(1 << FP8_S_W));
+        }
+    }
+}

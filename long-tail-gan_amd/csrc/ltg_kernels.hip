@@ -978,7 +978,15 @@ __global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, int SP, const 
         int t = 0;
 #pragma unroll
         for (int i = 1; i < 8; ++i) t += e >= L.off[i] ? 1 : 0;
-        adam_update(st.p[t], st.m[t], st.v[t], (size_t)(e - L.off[t]), g, ad);
+        const size_t i = (size_t)(e - L.off[t]);
+        adam_update(st.p[t], st.m[t], st.v[t], i, g, ad);
+        if (st.w1t_fp8 && (t == 0 || t == 2 || t == 4)) {   // operand-format shadow of the weight just written: [n][k], k contiguous
+            const int nn_w = L.off[t + 2] - L.off[t + 1];   // row length of the weight = size of the bias that follows it
+            const size_t k = i / nn_w, nn = i % nn_w;
+            const size_t kdim = (size_t)(L.off[t + 1] - L.off[t]) / nn_w;
+            uint8_t* dst = t == 0 ? st.w1t_fp8 : (t == 2 ? st.w2t_fp8 : st.w3t_fp8);
+            dst[nn * kdim + k] = ltg_f2fp8(st.p[t][i] * (float)(1 << FP8_S_W));
+        }
     }
     if (blockIdx.x == 0) {
         float s = 0.f;
@@ -1874,6 +1882,7 @@ struct Workspace {
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
     // fast path: per-column-tile partial dot products of the output unit, w4 * dA3/dpre, per-row loss terms of the G step
     float *spart, *G3, *rowout, *xd;
+    uint8_t* A1_8;      // the branch layers' output in e4m3 (fp8 operand storage of the wide discriminator)
     size_t bytes;
 };
 // stride of one discriminator gradient slab: the P gradients + one slot for the chunk's loss sum, padded to whole float4
@@ -1924,6 +1933,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.G3 = take(P * h3);
     w.rowout = take(R * 4);
     w.xd = take(I <= (size_t)RD_MAXI ? R * I : 1);   // dense operand rows of enc-0 (small item slabs)
+    w.A1_8 = reinterpret_cast<uint8_t*>(take((P * h12 + 3) / 4));
     w.bytes = off;
     return w;
 }
@@ -2133,6 +2143,17 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
         return;
     }
     const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? 32 : ts, t2 = ts2 < 0 ? 32 : ts2;
+    if (md == 2 && fast_on(cfg) && d->emb_fp8 && d->w1t_fp8 && d->w2t_fp8 && d->w3t_fp8 && (h0 % 64) == 0 && (h12 % 64) == 0) {
+        // operand-format storage: both forward layers read e4m3 bytes (embedding table, transposed weight shadows, A1 in e4m3)
+        LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk8_d_l1, dim3(8 * (((h1 + 63) / 64 + (h2 + 63) / 64 + 7) / 8) * ((n + 63) / 64)), dim3(NT), 0, st, pv, h0, h1, h2, d->emb_fp8, d->w1t_fp8, d->p[1],
+                                                      d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.A1, w.A1_8));
+        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk8_d_l2, grid2(h3, n, 64, 64), dim3(NT), 0, st, n, h12, h3, w.A1_8, d->w3t_fp8, d->p[5], dC, keep,
+                                                      cfg->seed, step, w.A3));
+        const dim3 go8((n + NT / 64 - 1) / (NT / 64));
+        if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go8, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
+        else hipLaunchKernelGGL(k_d_out<false>, go8, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
+        return;
+    }
     LTG_PROBED(pr, LTG_K_D_L1, LTG_D_DISPATCH(k_d_l1, md, ts, grid2(nmax, n, t1, t1, 2), st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                               d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
     LTG_PROBED(pr, LTG_K_D_L2, LTG_D_DISPATCH(k_d_l2, md, ts2, grid2(h3, n, t2, t2), st, n, h12, h3, w.A1, d->p[4], d->p[5], dC, keep, cfg->seed, step, w.A3));
@@ -2693,6 +2714,14 @@ int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
     return g_stage_bwd_rest(cfg, gen, bt, o, acts, nullptr, w, (hipStream_t)stream, true, true);
+}
+
+int ltg_refresh_d_shadow(const ltg_config* cfg, const ltg_disc_state* d, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !d || !d->emb || !d->emb_fp8 || !d->w1t_fp8 || !d->w2t_fp8 || !d->w3t_fp8) return LTG_EINVAL;
+    hipLaunchKernelGGL(k_d_shadow, dim3(2048), dim3(NT), 0, (hipStream_t)stream, cfg->d_feat, cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3, d->emb, d->p[0],
+                       d->p[2], d->p[4], const_cast<uint8_t*>(d->emb_fp8), d->w1t_fp8, d->w2t_fp8, d->w3t_fp8);
+    return check_launch();
 }
 
 int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream) {

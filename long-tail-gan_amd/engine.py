@@ -225,7 +225,17 @@ class Engine:
         self.d_flat_m, self.d_m = flat([None] * 8 if m is None else list(m))
         self.d_flat_v, self.d_v = flat([None] * 8 if v is None else list(v))
         arr = lambda ts: (cabi.vp * 8)(*[_ptr(t) for t in ts])
-        self.disc_c = cabi.ltg_disc_state(_ptr(self.d_emb), arr(self.d_p), arr(self.d_m), arr(self.d_v))
+        # e4m3 operand-format shadows for the fp8 mode of the wide discriminator (every layer size a multiple of 64): the frozen
+        # embedding table and the TRANSPOSED weights, kept in step by the library's Adam sweep
+        self.d_fp8 = None
+        h0, h1, h2, h3 = self.h0, self.h1, self.h2, self.h3
+        if self.d_precision == cabi.LTG_PREC_FP8 and all(x % 64 == 0 for x in (h0, h1, h2, h3)):
+            u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)
+            self.d_fp8 = (u8(self.feature_len * h0), u8(h1 * h0), u8(h2 * h0), u8(h3 * (h1 + h2)))
+        sh = [_ptr(t) for t in self.d_fp8] if self.d_fp8 else [None] * 4
+        self.disc_c = cabi.ltg_disc_state(_ptr(self.d_emb), arr(self.d_p), arr(self.d_m), arr(self.d_v), *sh)
+        if self.d_fp8:
+            cabi.check(self.lib.ltg_refresh_d_shadow(C.byref(self.cfg), C.byref(self.disc_c), self.stream()), "ltg_refresh_d_shadow")
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):

@@ -645,6 +645,36 @@ def test_d_step_precision_modes(dq, hs, tol):
         assert np.max(np.abs(Tr["y"] - T32["y"])) < lim
 
 
+def test_fp8_operand_shadows_stay_in_step_with_the_master_weights():
+    """LTG_PREC_FP8 with operand-format storage (wide discriminator): after several D steps the transposed e4m3 weight
+    shadows the Adam sweep maintains equal a fresh rebuild from the fp32 master weights, bit for bit; and the forward fed
+    from them matches the on-the-fly conversion path (tuning-knob bit 18) to fp32 round-off of the accumulation order."""
+    import ctypes as C
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import Pairs
+    I, hs = 600, (2048, 1024, 512, 256)
+    rng = np.random.default_rng(9)
+    a, b = _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8"), _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8")
+    assert a.d_fp8 is not None
+    b.cfg.reserved0 = 262144                      # round-1 path: operands converted on the fly from fp32
+    b.set_discriminator(a.d_emb.cpu().numpy(), [p.cpu().numpy() for p in a.d_p])
+    dev = a.device
+    t = lambda x: torch.from_numpy(x.astype(np.int32)).to(dev)
+    real = Pairs(t(rng.integers(0, I, 200)), t(rng.integers(0, I, 200)))
+    fake = Pairs(t(rng.integers(0, I, 190)), t(rng.integers(0, I, 190)))
+    for k in range(3):
+        la = float(a.d_step(real, fake, 0.7, rng_step=5 + k)[0].item())
+        lb = float(b.d_step(real, fake, 0.7, rng_step=5 + k)[0].item())
+        assert abs(la - lb) < 2e-3 * abs(lb), (k, la, lb)      # fp8 pipeline: a flipped rounding moves one operand by 6 %
+    kept = [x.clone() for x in a.d_fp8]
+    cabi.check(a.lib.ltg_refresh_d_shadow(C.byref(a.cfg), C.byref(a.disc_c), a.stream()), "ltg_refresh_d_shadow")
+    torch.cuda.synchronize()
+    for name, x, y in zip(("emb", "w1t", "w2t", "w3t"), kept, a.d_fp8):
+        assert torch.equal(x, y), name
+    assert int((kept[1] != 0).sum()) > 0.9 * kept[1].numel()
+
+
 def test_gemm_block_operand_modes():
     """The MFMA block template against exact products of the operands each mode feeds it (ltg_debug_gemm): fp32 and bf16
     accumulate to fp32 round-off; the fp8 MFMA of gfx950 accumulates with ~1.5e-5 relative error (measured, asserted)."""
