@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--d-split", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: split the discriminator's pair rows over the ranks + gradient all-reduce (auto: when the discriminator has >= 1 M parameters)")
     ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
+    ap.add_argument("--warm-moments", action="store_true", help="give every row of W_q0 non-zero Adam moments before timing (a long-trained "
+                    "model: the lazy clock then has its full deferred arithmetic to do; rows no batch has touched cost nothing otherwise)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event kernel probes (use under rocprofv3 --pmc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the bounded C3 / C4-shaped 1-GPU measurements reported beside the headline")
@@ -92,6 +94,8 @@ class KernelProfiler:
             self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "row_dlogits", "dh2", "dz", "dh1", "g_tail"]
         elif fast:
             self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "dh1", "enc0_grad", "g_tail"]
+            if eng.I >= 8192:
+                self.G_KERNELS.append("enc0_bwd_adam")     # its own launch(es): the dense sweep of W_q0, or the lazy clock's two kernels
         else:
             self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "wgrad_p0", "dh1", "wgrad_q1", "enc0_bwd_adam"]
         self.samples = []        # (event pair, n_pairs, nnz) recorded in the timed region
@@ -145,7 +149,9 @@ class KernelProfiler:
             "wgrad_p0": (2 * B * (Z + 1) * H, 24 * (Z + 1) * H + 4 * (B * Z + B * H)),
             "dh1": (2 * B * 2 * Z * H, 4 * (B * 2 * Z + H * 2 * Z + 2 * B * H)),
             "wgrad_q1": (2 * B * (H + 1) * 2 * Z, 24 * (H + 1) * 2 * Z + 4 * (B * H + B * 2 * Z)),
-            "enc0_bwd_adam": (2 * sh["nnz"] * H, 24 * (I + 1) * H + 4 * B * H),
+            # dense: every row of W_q0 every step; lazy clock: the batch's rows + one row in q0_period + the gradient rows
+            "enc0_bwd_adam": (2 * sh["nnz"] * H, (24 * (min(I, sh["nnz"]) + 1 + I // e.q0_period) * H + 4 * min(I, sh["nnz"]) * H) if e.lazy_q0
+                              else (24 * (I + 1) * H + 4 * B * H)),
             "row_dlogits": (0, 8 * B * I),
             "enc0_grad": (2 * sh["nnz"] * H, 4 * (sh["nnz"] * H + min(I, sh["nnz"]) * H)),
             # one launch = every Adam update of the generator: 24 B per parameter + the operands of the three gradient products
@@ -240,11 +246,13 @@ class KernelProfiler:
                 "note": "dominant kernel = largest (avg duration x launches per step) among the probed kernels"}
 
 
-def step_algorithmic_bytes(idx, data, eng, S, active=None):
+def step_algorithmic_bytes(idx, data, eng, S, active=None, lazy=False):
     """HBM bytes one step (C + S x D + S x G over the workload's batches) has to move with fp32 master weights,
     fp32 Adam moments, sparse X / sparse mask, fused Adam and one write + one read of the [B, I] logits:
       G = 24 P_G + 2 (4 H I) + 4 H min(I, nnz_B) + 8 B I      D = 24 P_D + 8 K h0      C = 4 H I + 4 H min(I, nnz_B) + 4 B I
-    with I = the GLOBAL item count (a sharded job moves the same bytes, spread over its GPUs)."""
+    with I = the GLOBAL item count (a sharded job moves the same bytes, spread over its GPUs).
+    lazy=True: the byte model of the lazy Adam clock of W_q0 instead (engine.lazy_q0): a G step moves the batch's rows of
+    W_q0 / m / v and one row in q0_period, not all I of them -- fewer bytes than SURVEY's dense-Adam count."""
     I, H, Z = eng.I_global, eng.H, eng.Z
     h0, h1, h2, h3 = eng.h0, eng.h1, eng.h2, eng.h3
     P_G = (2 * H + 1) * I + H * 2 * Z + Z * H + 2 * H + 2 * Z
@@ -261,6 +269,8 @@ def step_algorithmic_bytes(idx, data, eng, S, active=None):
         if b in act:
             tot += S * (24 * P_D + 8 * K * h0)
             tot += S * (24 * P_G + 8 * H * I + 4 * H * min(I, nnz) + 8 * B * I)
+            if lazy and eng.lazy_q0:
+                tot -= S * 24 * H * max(0, I - min(I, nnz) - I // eng.q0_period)
     return tot
 
 
@@ -321,6 +331,15 @@ def self_launch(a):
     raise SystemExit(0)
 
 
+def warm_moments(eng):
+    """--warm-moments: Adam moments of W_q0 as after long training (every item seen at some point)"""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(7)
+    eng.g_flush()
+    eng.g_m[0].normal_(0.0, 1e-4, generator=g)
+    eng.g_v[0].uniform_(1e-9, 1e-7, generator=g)
+
+
 def other_workloads(a, device, users=6400):
     """BASELINE configs 3 and 4 (item counts 20 000 / 200 000) on ONE GPU, bounded to 64 batches of 100 users each so the
     default run stays short: users/s of C + S x D + S x G over those batches, the dominant kernel's HBM fraction (HIP events
@@ -333,6 +352,8 @@ def other_workloads(a, device, users=6400):
         idx, data, desc = load_workload(name, a.batch_size, device, users)
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
         eng.cfg.reserved0 = a.variant
+        if a.warm_moments:
+            warm_moments(eng)
         tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
         tr.epoch()
         aa = argparse.Namespace(**vars(a))
@@ -355,6 +376,8 @@ def other_workloads(a, device, users=6400):
                     "ms_per_step": dt * 1e3, "g_step_us": float(np.median([p["t_g"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
                     "d_step_us": float(np.median([p["t_d"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
                     "step_frac": sb / dt / PEAK["hbm"],
+                    "lazy_q0": bool(eng.lazy_q0),
+                    "step_frac_bytes_moved": step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active, lazy=True) / dt / PEAK["hbm"],
                     "dominant_kernel": None if r is None else {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}}
         del tr, prof, eng, data, idx
         torch.cuda.empty_cache()
@@ -414,10 +437,14 @@ def main():
         data = DeviceData(idx, a.batch_size, device, item_lo=lo, item_hi=hi)
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device, item_lo=lo, item_hi=hi)
         eng.cfg.reserved0 = a.variant
+        if a.warm_moments:
+            warm_moments(eng)
         tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs, d_split={"auto": None, "on": True, "off": False}[a.d_split])
     else:
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
         eng.cfg.reserved0 = a.variant
+        if a.warm_moments:
+            warm_moments(eng)
         tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
 
     def barrier():
@@ -479,6 +506,9 @@ def main():
         sb = step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active)
         res["roofline"]["step_algorithmic_bytes"] = sb
         res["roofline"]["step_frac"] = sb / (dt / a.steps) / (PEAK["hbm"] * (1 if replicas else world))
+        if eng.lazy_q0:   # the lazy Adam clock of W_q0 moves fewer bytes than SURVEY's dense-Adam count: the fraction on its own byte model
+            res["roofline"]["lazy_q0"] = {"period": eng.q0_period, "step_frac_bytes_moved": step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active, lazy=True) /
+                                          (dt / a.steps) / (PEAK["hbm"] * (1 if replicas else world))}
         res["roofline"]["copy_ceiling_this_box"] = copy_ceiling(device)
         if calib:
             res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 8
+#define LTG_ABI_VERSION 9
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -85,7 +85,22 @@ typedef struct ltg_gen_state {
      * 8192, n_items % 8 == 0, bf16 precision, <= 128 rows) the decoder forward and the dh2 product stream it
      * (1216 B/item instead of 2400 B/item).  NULL: the fp32 rows are converted on the fly. */
     uint16_t* wp1t_bf16;
+    /* optional lazy Adam clock of W_q0 (item slabs of 8192 items or more).  tf.train.AdamOptimizer (train.py:160-164) moves
+     * every row of W_q0 every step, but a row's gradient is zero unless one of the batch's users holds the item, and a
+     * zero-gradient step is a function of (W, m, v, lr_t) of that row alone: it can be applied LATER, step by step, with the
+     * same arithmetic -- before the row is next read.  q0_last[i] = ordinal of the last G step applied to row i; q0_ord =
+     * ordinal of the last G step issued (HOST value: the caller adds 1 after every ltg_g_step / ltg_g_bwd_rest);
+     * q0_lr_hist[j % LTG_Q0_HIST] = lr_t of G step j (written by the library).  Every G step applies itself to the batch's
+     * rows (caught up first), and catches up the rows i = ord (mod q0_period), so that no row lags more than q0_period steps
+     * (1 <= q0_period <= LTG_Q0_HIST / 2).  Every forward catches up the rows it reads.  ltg_g_flush brings all rows to
+     * q0_ord (before W_q0 / its moments are read by anything else: checkpoints, host copies).  Results are bit-identical
+     * to the dense sweep.  q0_last == NULL: dense sweep every step. */
+    int32_t* q0_last;
+    float* q0_lr_hist;
+    int32_t q0_ord;
+    int32_t q0_period;
 } ltg_gen_state;
+#define LTG_Q0_HIST 1024
 
 /* Discriminator: emb is read-only (discriminator.py:14 is not in d_params, :47).
  * Trainable order (discriminator.py:47): 0 w1, 1 b1, 2 w2, 3 b2, 4 w3, 5 b3, 6 w4, 7 b4. */
@@ -212,6 +227,9 @@ typedef struct ltg_g_opts {
      * flight), ltg_g_bwd_rest must not do it again */
     int32_t dec1_done;
     int32_t reserved0;
+    /* optional third caller-created hipEvent_t (with aux_stream): ltg_g_step then runs the rotating slice of the lazy Adam
+     * clock of W_q0 (arithmetic-bound) on aux_stream, beside the HBM-bound decoder kernels, and joins it at the end */
+    void* ev_sweep;
 } ltg_g_opts;
 
 /* Static per-user sampling inputs for a batch (results of the index path, data_processing.py). */
@@ -310,6 +328,8 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
                            ltg_stream stream);
 /* (re)build gen->wp1t_bf16 from gen->p[3] (after initialisation or after loading weights). */
 int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream);
+/* lazy Adam clock of W_q0 (ltg_gen_state.q0_last): apply every deferred zero-gradient step, all rows up to gen->q0_ord */
+int ltg_g_flush(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream);
 /* (re)build the e4m3 operand shadows of the discriminator (ltg_disc_state.emb_fp8 ... w3t_fp8) from the fp32 tensors. */
 int ltg_refresh_d_shadow(const ltg_config* cfg, const ltg_disc_state* disc, ltg_stream stream);
 

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 8
+LTG_ABI_VERSION = 9
+LTG_Q0_HIST = 1024
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
 
@@ -31,7 +32,8 @@ class ltg_config(C.Structure):
 
 
 class ltg_gen_state(C.Structure):
-    _fields_ = [("p", vp * 8), ("m", vp * 8), ("v", vp * 8), ("wp1t_bf16", vp)]
+    _fields_ = [("p", vp * 8), ("m", vp * 8), ("v", vp * 8), ("wp1t_bf16", vp),
+                ("q0_last", vp), ("q0_lr_hist", vp), ("q0_ord", C.c_int32), ("q0_period", C.c_int32)]   # optional lazy Adam clock of W_q0
 
 
 class ltg_disc_state(C.Structure):
@@ -75,7 +77,7 @@ class ltg_d_opts(C.Structure):
 class ltg_g_opts(C.Structure):
     _fields_ = [("fwd", ltg_fwd_opts), ("anneal", C.c_float), ("gan_lambda", C.c_float), ("d_keep_prob", C.c_float),
                 ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp), ("probe", C.POINTER(ltg_probe)),
-                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("dec1_done", C.c_int32), ("reserved0", C.c_int32)]
+                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("dec1_done", C.c_int32), ("reserved0", C.c_int32), ("ev_sweep", vp)]
 
 
 class ltg_sample_inputs(C.Structure):
@@ -114,6 +116,7 @@ SYMBOLS = {
                                  C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
     "ltg_gather_cand_logits": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp]),
     "ltg_refresh_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
+    "ltg_g_flush": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
     "ltg_refresh_d_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,
                                    C.c_int32, C.c_int32, vp, vp]),

@@ -642,9 +642,9 @@ __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const flo
         ltg_f32x4 pp = ltg_ld4(p + 4 * e), mm = ltg_ld4(m + 4 * e), vv = ltg_ld4(v + 4 * e);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mm[j] = ad.b1 * mm[j] + (1.f - ad.b1) * g[j];
-            vv[j] = ad.b2 * vv[j] + (1.f - ad.b2) * g[j] * g[j];
-            pp[j] = pp[j] - ad.lr_t * mm[j] / (sqrtf(vv[j]) + ad.eps);
+            float pj = pp[j], mj = mm[j], vj = vv[j];
+            adam1(pj, mj, vj, g[j], ad.lr_t, ad);
+            pp[j] = pj; mm[j] = mj; vv[j] = vj;
         }
         *reinterpret_cast<ltg_f32x4*>(p + 4 * e) = pp;
         *reinterpret_cast<ltg_f32x4*>(m + 4 * e) = mm;
@@ -887,9 +887,9 @@ __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const f
         const WgWhere x = where(m, n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r.m[j] = ad.b1 * r.m[j] + (1.f - ad.b1) * g[j];
-            r.v[j] = ad.b2 * r.v[j] + (1.f - ad.b2) * g[j] * g[j];
-            r.p[j] = r.p[j] - ad.lr_t * r.m[j] / (sqrtf(r.v[j]) + ad.eps);
+            float pj = r.p[j], mj = r.m[j], vj = r.v[j];
+            adam1(pj, mj, vj, g[j], ad.lr_t, ad);
+            r.p[j] = pj; r.m[j] = mj; r.v[j] = vj;
         }
         if (x.vec) {
             *reinterpret_cast<ltg_f32x4*>(x.p) = r.p;
@@ -999,10 +999,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
                     g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
                 }
             }
-#define LTG_ADAM1(f)                                              \
-    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;                    \
-    vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;              \
-    p.f = p.f - ad.lr_t * mm.f / (sqrtf(vv.f) + ad.eps);
+#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
             LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
 #undef LTG_ADAM1
             *P = p;

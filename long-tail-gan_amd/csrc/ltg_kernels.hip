@@ -17,13 +17,21 @@ struct AdamC {
 };
 
 // tf.train.AdamOptimizer update (train.py:160-164, Q5): m,v updated for EVERY element (dense).
+// One element, with the rounding PINNED (explicit fma; `b1 m + (1-b1) g` may otherwise contract either way, kernel by
+// kernel): every kernel that applies Adam -- dense sweeps, tile epilogues, the lazy clock of W_q0 -- yields the same bits
+// for the same (p, m, v, g).
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, const float g, const float lr_t, const AdamC& c) {
+    m = __builtin_fmaf(c.b1, m, (1.f - c.b1) * g);
+    v = __builtin_fmaf(c.b2, v, ((1.f - c.b2) * g) * g);
+    p = p - (lr_t * m) / (sqrtf(v) + c.eps);
+}
 __device__ __forceinline__ void adam_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                             size_t i, float g, const AdamC c) {
-    const float mn = c.b1 * m[i] + (1.f - c.b1) * g;
-    const float vn = c.b2 * v[i] + (1.f - c.b2) * g * g;
+    float pn = p[i], mn = m[i], vn = v[i];
+    adam1(pn, mn, vn, g, c.lr_t, c);
     m[i] = mn;
     v[i] = vn;
-    p[i] = p[i] - c.lr_t * mn / (sqrtf(vn) + c.eps);
+    p[i] = pn;
 }
 
 __device__ __forceinline__ float block_sum(float x, float* red /*[NT/64]*/) {
@@ -525,10 +533,12 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     const unsigned rowB = (unsigned)H * 4u;
     const unsigned lo = 16u * lane, lo9 = 16u * (unsigned)(min(576 + lane, nel - 1) - 576);
     ltg_f32x4 Ap[2], Am[2], Av[2], Bp[2], Bm[2], Bv[2];
-#define DW_ADAM1(f)                                   \
-    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;        \
-    v2.f = ad.b2 * v2.f + (1.f - ad.b2) * g.f * g.f;  \
-    p.f = p.f - ad.lr_t * mm.f / (sqrtf(v2.f) + ad.eps);
+#define DW_ADAM1(f)                                  \
+    {                                                \
+        float p_ = p.f, m_ = mm.f, v_ = v2.f;        \
+        adam1(p_, m_, v_, g.f, ad.lr_t, ad);         \
+        p.f = p_; mm.f = m_; v2.f = v_;              \
+    }
     // addressing: (uniform row base, computed on the scalar unit) + (one 32-bit lane offset per pass) -- global_load with
     // an SGPR base, so the unrolled stages do not pin a VGPR pair per access
 #define DW_AT(T, BASE, UB, LB) (*(T __attribute__((address_space(1)))*)(ltg_uniform_ptr(reinterpret_cast<const char*>(BASE) + (UB)) + (LB)))
@@ -619,9 +629,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         {                                                                                                            \
             const float gbias = Cs[(H / 80) * (32 * DW_LDC) + (4 * w + min(lane, 3)) * DW_LDC + H % 80];             \
-            mbv = ad.b1 * mbv + (1.f - ad.b1) * gbias;                                                               \
-            vbv = ad.b2 * vbv + (1.f - ad.b2) * gbias * gbias;                                                       \
-            pbv = pbv - ad.lr_t * mbv / (sqrtf(vbv) + ad.eps);                                                       \
+            adam1(pbv, mbv, vbv, gbias, ad.lr_t, ad);                                                                \
             mb[ib] = mbv;                                                                                            \
             vb[ib] = vbv;                                                                                            \
             bb[ib] = pbv;                                                                                            \
@@ -1399,10 +1407,7 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
             if (n < H) {
                 const size_t o = ((size_t)m * H + n) >> 2;
                 float4 p = reinterpret_cast<float4*>(W)[o], mm = reinterpret_cast<float4*>(mW)[o], vv = reinterpret_cast<float4*>(vW)[o];
-#define LTG_ADAM4(f)                                  \
-    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;        \
-    vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;  \
-    p.f = p.f - ad.lr_t * mm.f / (sqrtf(vv.f) + ad.eps);
+#define LTG_ADAM4(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
                 LTG_ADAM4(x) LTG_ADAM4(y) LTG_ADAM4(z) LTG_ADAM4(w)
 #undef LTG_ADAM4
                 reinterpret_cast<float4*>(W)[o] = p;
@@ -1622,15 +1627,151 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int I, int H, int nu, cons
                 g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
             }
         }
-#define LTG_ADAM1(f)                                              \
-    mm.f = ad.b1 * mm.f + (1.f - ad.b1) * g.f;                    \
-    vv.f = ad.b2 * vv.f + (1.f - ad.b2) * g.f * g.f;              \
-    p.f = p.f - ad.lr_t * mm.f / (sqrtf(vv.f) + ad.eps);
+#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
         LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
 #undef LTG_ADAM1
         *P = p;
         *Mm = mm;
         *Vv = vv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lazy Adam clock of W_q0 (ltg_gen_state.q0_last, include/ltg.h).  A zero-gradient Adam step of a row is
+//     m <- b1 m,  v <- b2 v,  W <- W - lr_t m / (sqrt(v) + eps)
+// -- the dense sweep's expressions with g == 0 (b1 m + (1-b1) 0 rounds once either way) -- so a row that lags k steps is
+// brought up to date by running those k steps in registers: 24 B/parameter of traffic once per k steps instead of every
+// step.  The arithmetic (k x IEEE sqrt and divide per parameter) does not shrink; it moves off the HBM stream.
+// ---------------------------------------------------------------------------------------------
+#define LTG_Q0_MASK (LTG_Q0_HIST - 1)
+
+// One row (H4 float4 columns at W4/m4/v4) from ordinal `from` to ordinal `to`: zero-gradient steps, then -- if G4 is given --
+// the step `to` itself with gradient row G4 and learning rate ad.lr_t (the caller's current step).
+__device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* __restrict__ m4, float4* __restrict__ v4, int H4, int from, int to,
+                                               const float* __restrict__ lr_hist, const float4* __restrict__ G4, const AdamC ad) {
+    const int nz = G4 ? to - 1 : to;   // last zero-gradient step
+    for (int c = threadIdx.x; c < H4; c += blockDim.x) {
+        float4 p = W4[c], mm = m4[c], vv = v4[c];
+        const bool m0 = mm.x == 0.f && mm.y == 0.f && mm.z == 0.f && mm.w == 0.f;
+        const bool v0 = vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
+        if (!G4 && m0 && v0) continue;                       // a row no batch has touched yet: every step is the identity
+        if (m0) {                                             // W does not move (0 / (sqrt(v) + eps) == 0): only v decays
+            if (!v0)
+                for (int j = from + 1; j <= nz; ++j) { vv.x *= ad.b2; vv.y *= ad.b2; vv.z *= ad.b2; vv.w *= ad.b2; }
+        } else {
+            for (int j = from + 1; j <= nz; ++j) {
+                const float lr = lr_hist[j & LTG_Q0_MASK];
+#define LTG_ADAM0(f)          \
+    mm.f = ad.b1 * mm.f;      \
+    vv.f = ad.b2 * vv.f;      \
+    p.f = p.f - (lr * mm.f) / (sqrtf(vv.f) + ad.eps);   /* adam1 with g == 0: fma(b1, m, 0) rounds like b1 m */
+                LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
+#undef LTG_ADAM0
+            }
+        }
+        if (G4) {
+            const float4 g = G4[c];
+#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
+            LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
+#undef LTG_ADAM1
+        }
+        W4[c] = p;
+        m4[c] = mm;
+        v4[c] = vv;
+    }
+}
+
+#define Q0_NT 192
+// rows of the batch's distinct items (G-step batches carry the list): up to `target`, before enc-0 reads them
+__global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
+                                                           const int32_t* __restrict__ indices, int target, ltg_gen_state st, AdamC ad) {
+    const int u = blockIdx.x;
+    if (u >= nu) return;
+    const int i = indices[csr_pos[uptr[u]]];
+    const int from = st.q0_last[i];
+    if (from >= target) return;
+    const int H4 = H >> 2;
+    const size_t off = (size_t)i * H4;
+    q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
+                   from, target, st.q0_lr_hist, nullptr, ad);
+    __syncthreads();   // every thread has read q0_last[i]
+    if (threadIdx.x == 0) st.q0_last[i] = target;
+}
+
+// forward-only batches (no distinct-item list): one workgroup per user row walks its entries; the first workgroup to claim
+// a lagging item row (compare-and-swap on its clock) brings it up to date, the consumers are later launches
+__global__ __launch_bounds__(Q0_NT) void k_q0_touch_rows(int H, int R, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int target,
+                                                         ltg_gen_state st, AdamC ad) {
+    __shared__ int s_from;
+    const int r = blockIdx.x;
+    const int H4 = H >> 2;
+    const int e1 = indptr[r + 1];
+    for (int e = indptr[r]; e < e1; ++e) {
+        const int i = indices[e];
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_load(st.q0_last + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_from = (old < target && atomicCAS(st.q0_last + i, old, target) == old) ? old : -1;
+        }
+        __syncthreads();
+        const int from = s_from;
+        __syncthreads();
+        if (from < 0) continue;
+        const size_t off = (size_t)i * H4;
+        q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off,
+                       H4, from, target, st.q0_lr_hist, nullptr, ad);
+    }
+}
+
+// G step `ord` on the batch's rows: gradient row u of G (k_enc0_grad layout) for distinct item u; block nu = the bias row
+// (dense: its gradient is never zero) + the learning rate of this step into the history ring
+__global__ __launch_bounds__(Q0_NT) void k_q0_step_touched(int I, int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
+                                                           const int32_t* __restrict__ indices, const float* __restrict__ G, int ord, ltg_gen_state st,
+                                                           AdamC ad) {
+    const int u = blockIdx.x;
+    const int H4 = H >> 2;
+    const float4* G4 = reinterpret_cast<const float4*>(G);
+    if (u == nu) {
+        if (threadIdx.x == 0) st.q0_lr_hist[ord & LTG_Q0_MASK] = ad.lr_t;
+        float4* b4 = reinterpret_cast<float4*>(st.p[4]);
+        float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
+        float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
+        for (int c = threadIdx.x; c < H4; c += blockDim.x) {
+            float4 g = G4[(size_t)nu * H4 + c];
+#pragma unroll
+            for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
+                const float4 t = G4[(size_t)(nu + j) * H4 + c];
+                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            }
+            float4 p = b4[c], mm = mb4[c], vv = vb4[c];
+#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
+            LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
+#undef LTG_ADAM1
+            b4[c] = p;
+            mb4[c] = mm;
+            vb4[c] = vv;
+        }
+        return;
+    }
+    const int i = indices[csr_pos[uptr[u]]];
+    const int from = st.q0_last[i];
+    const size_t off = (size_t)i * H4;
+    q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
+                   from, ord, st.q0_lr_hist, G4 + (size_t)u * H4, ad);
+    __syncthreads();
+    if (threadIdx.x == 0) st.q0_last[i] = ord;
+}
+
+// rows start, start + stride, ...: zero-gradient steps up to `target` (the rotating slice of a G step; the flush: 0, 1)
+__global__ __launch_bounds__(Q0_NT) void k_q0_sweep(int I, int H, int start, int stride, int target, ltg_gen_state st, AdamC ad) {
+    const int H4 = H >> 2;
+    for (size_t i = (size_t)start + (size_t)blockIdx.x * stride; i < (size_t)I; i += (size_t)gridDim.x * stride) {
+        const int from = st.q0_last[i];
+        __syncthreads();   // every thread has read the row's clock before thread 0 may move it
+        if (from >= target) continue;
+        const size_t off = i * H4;
+        q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off,
+                       H4, from, target, st.q0_lr_hist, nullptr, ad);
+        if (threadIdx.x == 0) st.q0_last[i] = target;
     }
 }
 
@@ -1997,11 +2138,29 @@ bool cfg_ok(const ltg_config* c) {
 
 inline int Ig_of(const ltg_config* cfg) { return cfg->n_items_global > 0 ? cfg->n_items_global : cfg->n_items; }
 
+// lazy Adam clock of W_q0 (ltg_gen_state.q0_last): usable when the caller supplies clock, history ring and a period
+inline bool q0_lazy(const ltg_config* cfg, const ltg_gen_state* gen) {
+    return gen->q0_last && gen->q0_lr_hist && gen->q0_period >= 1 && gen->q0_period <= LTG_Q0_HIST / 2 && gen->q0_ord >= 0 && (cfg->h_enc % 4) == 0 &&
+           cfg->n_items >= 8192;   // smaller slabs update W_q0 as a dense product: nothing to defer
+}
+// the item rows this batch reads, up to the caller's clock (no-ops for rows that are current)
+void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st) {
+    if (!q0_lazy(cfg, gen) || bt->n_rows <= 0) return;
+    const AdamC ad = make_adam(cfg, 1);   // b1, b2, eps; the learning rates come from the history ring
+    if (bt->uptr && bt->csr_pos) {
+        if (bt->n_unique > 0)
+            hipLaunchKernelGGL(k_q0_touch_unique, dim3(bt->n_unique), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, gen->q0_ord, *gen, ad);
+    } else {
+        hipLaunchKernelGGL(k_q0_touch_rows, dim3(bt->n_rows), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_rows, bt->indptr, bt->indices, gen->q0_ord, *gen, ad);
+    }
+}
+
 // stage 1: enc-0 over this rank's item slab.  pre_only: leave the partial pre-activation in acts->h1.
 void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
-                   const ltg_gen_acts* acts, int pre_only, hipStream_t st, float* xd = nullptr) {
+                   const ltg_gen_acts* acts, int pre_only, hipStream_t st, float* xd = nullptr, bool touched = false) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc;
     const Probe pr{o->probe, st};
+    if (!touched) q0_touch(cfg, gen, bt, st);
     if (fast_on(cfg)) {
         LTG_PROBED(pr, LTG_K_ENC0_FWD,
                    hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), xd ? (size_t)I * sizeof(float) : 0, st, H, I, bt->indptr,
@@ -2457,10 +2616,24 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
 
 // dz -> dh1 -> (sparse W_q0 gradient) -> Adam updates.  Tuning-knob bit 20: the Adam jobs ride with the dz / dh1 launches
 // (three launches of fk_g_tail) instead of running as one tail launch behind them.
+// Adam step gen->q0_ord + 1 of W_q0 / b_q0 on the lazy clock: the batch's rows with their gradient rows (w.gq0), the bias
+// row, then the rotating slice of untouched rows
+// the rotating slice of G step gen->q0_ord + 1: rows i = ord (mod period) up to `target`
+static void q0_slice_sweep(const ltg_config* cfg, const ltg_gen_state* gen, int target, hipStream_t st) {
+    const int I = cfg->n_items, P = gen->q0_period, start = (gen->q0_ord + 1) % P;
+    if (start < I) hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + P - 1) / P), dim3(Q0_NT), 0, st, I, cfg->h_enc, start, P, target, *gen, make_adam(cfg, 1));
+}
+static void q0_lazy_update(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const Workspace& w, const AdamC& ad,
+                           hipStream_t st) {
+    const int I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique, ord = gen->q0_ord + 1;
+    hipLaunchKernelGGL(k_q0_step_touched, dim3(nu + 1), dim3(Q0_NT), 0, st, I, H, nu, bt->uptr, bt->csr_pos, bt->indices, w.gq0, ord, *gen, ad);
+    if (!o->reserved0) q0_slice_sweep(cfg, gen, ord, st);   // (reserved0 != 0: ltg_g_step has the slice on its aux stream, up to ord - 1)
+}
+
 static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
-                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st) {
+                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st, bool lazy = false) {
     const int B = bt->n_rows, H = cfg->h_enc, Z = cfg->z_dim;
-    const bool ride = (cfg->reserved0 & (1 << 20)) != 0;
+    const bool ride = (cfg->reserved0 & (1 << 20)) != 0 && !lazy;
     if (ride) {
         g_jobs(0, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
         g_jobs(1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
@@ -2472,11 +2645,13 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-    if (slot) g_enc0_grad(cfg, bt, o, acts, w, st);
-    const bool own_sweep = slot && cfg->n_items >= 8192;   // HBM-bound sweep: its own launch at full occupancy (measured 490 vs 525 us at
-                                                           // 200 000 items when it rode in the 118-register job kernel)
+    if (slot || lazy) g_enc0_grad(cfg, bt, o, acts, w, st);
+    const bool own_sweep = (slot && cfg->n_items >= 8192) || lazy;   // HBM-bound sweep: its own launch at full occupancy (measured 490 vs
+                                                                     // 525 us at 200 000 items when it rode in the 118-register job kernel)
     g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st, own_sweep);
-    if (own_sweep) {
+    if (lazy) {
+        LTG_PROBED(pr, LTG_K_ENC0_BWD_ADAM, q0_lazy_update(cfg, gen, bt, o, w, ad, st));
+    } else if (own_sweep) {
         const int I = cfg->n_items;
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
@@ -2536,12 +2711,21 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         prs.after(LTG_K_DEC1_BWD_ADAM);
     };
-    if (!o->dec1_done) launch_dw();
+    if (o->reserved0 && q0_lazy(cfg, gen)) {
+        // ltg_g_step, lazy Adam clock of W_q0: the rotating slice becomes eligible on the aux stream together with the decoder
+        // weight update (enqueued first: its 256 persistent workgroups take their CUs, the slice's waves fill what is left)
+        (void)hipEventRecord(evf, st);
+        (void)hipStreamWaitEvent(aux, evf, 0);
+        if (!o->dec1_done) launch_dw();
+        q0_slice_sweep(cfg, gen, gen->q0_ord, aux);   // the batch's rows are at q0_ord already (q0_touch): skipped
+        (void)hipEventRecord((hipEvent_t)o->ev_sweep, aux);
+    } else if (!o->dec1_done) launch_dw();
     if (only_dec1) return check_launch();
     if (mid_fast(cfg, B)) {
         // dz -> dh1 -> sparse W_q0 gradient, then every remaining Adam update (W_p0, W_q1, W_q0 + biases) in ONE launch
-        const int32_t* slot = g_slot_map(cfg, bt, w, st);
-        g_chain(cfg, gen, bt, o, acts, w, ad, slot, false, nullptr, st);
+        const bool lazy = q0_lazy(cfg, gen);   // no item -> gradient-row map needed: the update walks the batch's distinct items
+        const int32_t* slot = lazy ? nullptr : g_slot_map(cfg, bt, w, st);
+        g_chain(cfg, gen, bt, o, acts, w, ad, slot, false, nullptr, st, lazy);
         return check_launch();
     }
     const Probe pc{o->probe, s_chain}, pw{o->probe, s_wg};
@@ -2577,7 +2761,8 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), s_chain, B, I, H, nu, bt->uptr, bt->rowidx,
                        bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
                        acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
-    {
+    if (q0_lazy(cfg, gen)) q0_lazy_update(cfg, gen, bt, o, w, ad, st);
+    else {
         const size_t total = (size_t)(I + 1) * (H / 4);
         size_t gx = (total + NT - 1) / NT;
         if (gx > 262144) gx = 262144;
@@ -2609,19 +2794,28 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const Workspace w = carve(cfg, B, nf, (char*)ws);
+    // lazy Adam clock of W_q0: the batch's rows up to date first; its rotating slice (rows NOT of this batch: arithmetic-bound,
+    // 48 registers -- it fits beside the 2 x 232-register waves of the HBM-bound decoder kernels) then runs on the aux stream
+    q0_touch(cfg, gen, bt, st);
+    const bool aux_sweep = q0_lazy(cfg, gen) && o->aux_stream && o->ev_fork && o->ev_sweep && (cfg->reserved0 & 512) == 0;
     // fork: the fake tower (independent of the generator forward) runs on the caller's aux stream
     const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0 && (cfg->reserved0 & 512) == 0;
-    if (fork) {
+    if (fork || aux_sweep) {
         hipStream_t aux = (hipStream_t)o->aux_stream;
         if (hipEventRecord((hipEvent_t)o->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)o->ev_fork, 0) != hipSuccess)
             return LTG_ELAUNCH;
-        PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
-        DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
-        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, aux);
-        if (hipEventRecord((hipEvent_t)o->ev_join, aux) != hipSuccess) return LTG_ELAUNCH;
+        if (fork) {
+            PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
+            DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
+            disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, aux);
+            if (hipEventRecord((hipEvent_t)o->ev_join, aux) != hipSuccess) return LTG_ELAUNCH;
+        }
     }
+    ltg_g_opts o_local = *o;
+    o_local.reserved0 = aux_sweep ? 1 : 0;
+    o = &o_local;
     const bool small = small_fast(cfg, B);
-    fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st, small ? w.xd : nullptr);
+    fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st, small ? w.xd : nullptr, true);
     fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
     if (small) {
         // small item slab: a row's softmax statistics, loss terms and dlogits need no other row -> one launch per stage,
@@ -2649,7 +2843,9 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)
     int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork, acts->h2);
     if (rc != LTG_OK) return rc;
-    return g_stage_bwd_rest(cfg, gen, bt, o, acts, w.da2, w, st, true);
+    rc = g_stage_bwd_rest(cfg, gen, bt, o, acts, w.da2, w, st, true);
+    if (aux_sweep && hipStreamWaitEvent(st, (hipEvent_t)o->ev_sweep, 0) != hipSuccess) return LTG_ELAUNCH;   // join
+    return rc;
 }
 
 /* ---- the same step cut at its three exchange points (item-sharded multi-GPU; include/ltg.h) ---- */
@@ -2721,6 +2917,14 @@ int ltg_refresh_d_shadow(const ltg_config* cfg, const ltg_disc_state* d, ltg_str
     if (!cfg_ok(cfg) || !d || !d->emb || !d->emb_fp8 || !d->w1t_fp8 || !d->w2t_fp8 || !d->w3t_fp8) return LTG_EINVAL;
     hipLaunchKernelGGL(k_d_shadow, dim3(2048), dim3(NT), 0, (hipStream_t)stream, cfg->d_feat, cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3, d->emb, d->p[0],
                        d->p[2], d->p[4], const_cast<uint8_t*>(d->emb_fp8), d->w1t_fp8, d->w2t_fp8, d->w3t_fp8);
+    return check_launch();
+}
+
+int ltg_g_flush(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !gen || !q0_lazy(cfg, gen)) return LTG_EINVAL;
+    const int I = cfg->n_items;
+    hipLaunchKernelGGL(k_q0_sweep, dim3(I < 65536 ? I : 65536), dim3(Q0_NT), 0, (hipStream_t)stream, I, cfg->h_enc, 0, 1, gen->q0_ord, *gen, make_adam(cfg, 1));
     return check_launch();
 }
 

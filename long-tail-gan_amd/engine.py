@@ -8,6 +8,7 @@ AdamOptimizer whose step counter is shared by the D and the G updates (train.py:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -117,10 +118,13 @@ class Pairs:
 class Engine:
     def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
                  precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8,
-                 item_lo=0, item_hi=None, d_precision="fp32"):
+                 item_lo=0, item_hi=None, d_precision="fp32", lazy_q0=None, q0_period=32):
         """n_items = GLOBAL item count; [item_lo, item_hi) = the slab this rank owns (default: everything).
         precision: operands of the three decoder GEMMs; d_precision: operands of the discriminator GEMMs
-        ("fp32" = the reference's arithmetic, "bf16", "fp8" = BASELINE config 5)."""
+        ("fp32" = the reference's arithmetic, "bf16", "fp8" = BASELINE config 5).
+        lazy_q0: lazy Adam clock of W_q0 (include/ltg.h, ltg_gen_state.q0_last; same results as the dense sweep).  None = on
+        for item slabs of 8192 items or more.  Rows are brought up to date by every forward that reads them; `g_flush()`
+        does it for all rows and runs after every G step unless a trainer holds `q0_defer` for the length of its phase."""
         self.lib = cabi.load()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
@@ -140,6 +144,13 @@ class Engine:
                                    lr, beta1, beta2, eps, seed)
         self.lr, self.beta1, self.beta2 = lr, beta1, beta2
         self.adam_t = 0                                              # shared by D and G (Q5)
+        if lazy_q0 is None:
+            lazy_q0 = os.environ.get("LTGAN_LAZY_Q0", "1") != "0"   # measurement switch: 0 = dense sweep every step
+        self.lazy_q0 = bool(lazy_q0) and self.I >= 8192
+        self.q0_period = int(q0_period)
+        self.q0_defer = False                                        # True: the caller flushes (end of its G phase)
+        self.q0_sweep_overlap = os.environ.get("LTGAN_Q0_OVERLAP", "1") != "0"   # measurement switch
+        self._q0_dirty = False
         self._init_generator(seed)
         self._init_discriminator(d_seed)
         self._ws = None
@@ -177,7 +188,13 @@ class Engine:
         self.g_shadow = None
         if self.precision == cabi.LTG_PREC_BF16 and self.I >= 8192 and self.I % 8 == 0 and self.H <= 608:
             self.g_shadow = torch.zeros(self.I, 608, dtype=torch.int16, device=dev)
-        self.gen_c = cabi.ltg_gen_state(arr(self.g_p), arr(self.g_m), arr(self.g_v), _ptr(self.g_shadow))
+        self.q0_last = self.q0_lr_hist = None
+        if self.lazy_q0:                                             # all rows current at ordinal 0
+            self.q0_last = torch.zeros(self.I, dtype=torch.int32, device=dev)
+            self.q0_lr_hist = torch.zeros(cabi.LTG_Q0_HIST, dtype=torch.float32, device=dev)
+        self._q0_dirty = False
+        self.gen_c = cabi.ltg_gen_state(arr(self.g_p), arr(self.g_m), arr(self.g_v), _ptr(self.g_shadow),
+                                        _ptr(self.q0_last), _ptr(self.q0_lr_hist), 0, self.q0_period if self.lazy_q0 else 0)
         if self.g_shadow is not None:
             cabi.check(self.lib.ltg_refresh_shadow(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_refresh_shadow")
 
@@ -270,9 +287,16 @@ class Engine:
             return None, None, None
         if self._aux is None:
             from ._hip import EventPair
-            self._aux = (torch.cuda.Stream(self.device), EventPair(timing=False))
-        st, ev = self._aux
+            self._aux = (torch.cuda.Stream(self.device), EventPair(timing=False), EventPair(timing=False))
+        st, ev = self._aux[:2]
         return st.cuda_stream, ev.start, ev.stop
+
+    def _sweep_event(self):
+        """ltg_g_opts.ev_sweep: the lazy clock's rotating slice runs on the aux stream beside the decoder kernels"""
+        if not (self.overlap and self.lazy_q0 and self.q0_sweep_overlap):
+            return None
+        self._fork_handles()
+        return self._aux[2].start
 
     def next_adam_t(self):
         self.adam_t += 1
@@ -336,12 +360,27 @@ class Engine:
         f = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
         o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
-                            *self._fork_handles())
+                            *self._fork_handles(), 0, 0, self._sweep_event())
         rc = self.lib.ltg_g_step(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c),
                                  C.byref(fake.c), C.byref(o), C.byref(acts.c), _ptr(loss_out), _ptr(ws), ws.numel(),
                                  self.stream())
         cabi.check(rc, "ltg_g_step")
+        self._q0_stepped()
         return loss_out
+
+    def _q0_stepped(self):
+        """one more G step on the lazy clock of W_q0 (ltg_gen_state.q0_ord is the caller's to advance)"""
+        if self.lazy_q0:
+            self.gen_c.q0_ord += 1
+            self._q0_dirty = True
+            if not self.q0_defer:
+                self.g_flush()
+
+    def g_flush(self):
+        """every deferred zero-gradient Adam step of W_q0, all rows: before W_q0 / its moments are read outside a forward"""
+        if self.lazy_q0 and self._q0_dirty:
+            cabi.check(self.lib.ltg_g_flush(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_g_flush")
+            self._q0_dirty = False
 
     # ------------------------------------------------------------------ the G step cut at its exchange points
     def fwd_opts(self, keep_prob=0.75, is_training=0.0, rng_step=0, drop_keep=None, eps=None, probe=None):
@@ -386,6 +425,7 @@ class Engine:
         ws = self.workspace(batch.n_rows, fake.n)
         cabi.check(self.lib.ltg_g_bwd_rest(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fake.c), C.byref(gopts),
                                            C.byref(acts.c), _ptr(dh2), _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_rest")
+        self._q0_stepped()
 
     def gather_cand_logits(self, samp_c, acts, out):
         cabi.check(self.lib.ltg_gather_cand_logits(C.byref(self.cfg), C.byref(samp_c), _ptr(acts.logits), _ptr(out), self.stream()),
@@ -413,6 +453,7 @@ class Engine:
     def generator_params_tf(self):
         """The 8 tensors in the reference's order and TF shapes (MultiVAE.py:129-141); W_p1 is a
         transposed view of the item-major storage."""
+        self.g_flush()
         p = self.g_p
         return [p[0], p[1], p[2], p[3].t(), p[4], p[5], p[6], p[7]]
 

@@ -124,6 +124,7 @@ class ShardedTrainer(Trainer):
     def g_phase(self):
         d, eng = self.data, self.eng
         self.last_anneal = []
+        eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
         for j in range(self.S):
             a = self.anneal()
             for k in self.order:
@@ -142,6 +143,8 @@ class ShardedTrainer(Trainer):
                 work.wait()
                 eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
             self.last_anneal.append(a)
+        eng.q0_defer = False
+        eng.g_flush()
         return self.g_losses
 
 

@@ -74,6 +74,7 @@ def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
     import torch
     st = {"format": CKPT_FORMAT, "epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step,
           "shuffle_rng_state": tr.np_rng.get_state(), "d_w1": eng.d_emb.cpu()}
+    eng.g_flush()                                      # lazy Adam clock of W_q0: every row up to date before it is read
     gp, gm, gv = _full(eng.g_p, eng, world), _full(eng.g_m, eng, world), _full(eng.g_v, eng, world)     # collective: every rank
     for i, n in enumerate(G_NAMES):
         tf = (lambda t: t.t().contiguous()) if i == 3 else (lambda t: t)

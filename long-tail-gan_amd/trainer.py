@@ -79,6 +79,7 @@ class Trainer:
     def g_phase(self):
         d, eng = self.data, self.eng
         self.last_anneal = []
+        eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
         for j in range(self.S):
             a = self.anneal()
             for k in self.order:
@@ -91,6 +92,8 @@ class Trainer:
                            d_rng_step=self._step(), loss_out=self.g_losses[j],
                            probe=self.probe_hook("g", b) if self.probe_hook else None)
             self.last_anneal.append(a)
+        eng.q0_defer = False
+        eng.g_flush()
         return self.g_losses
 
     def epoch(self):

@@ -727,3 +727,55 @@ def test_g_step_without_slot_cache_is_bit_identical():
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision,period", [("fp32", 3), ("bf16", 5)])
+def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dense_sweep(precision, period):
+    """ltg_gen_state.q0_last: TF's Adam (train.py:160-164) moves every row of W_q0 every step; the lazy clock applies a row's
+    zero-gradient steps later, with the same arithmetic.  Several G steps over DIFFERENT batches (rows go in and out of the
+    batches, the rotating slice has a short period), a forward over other users in the middle of the phase, one flush at
+    the end: every parameter, moment and output bit equals the dense sweep's."""
+    import torch
+    from ltgan.engine import CsrRows, Pairs
+    I, B, n_batches = 9000, 48, 7
+    rng = np.random.default_rng(4242)
+    P = O.init_generator(I, seed=3)
+    Xs = [Hh.random_history(rng, B, I, mean_nnz=14) for _ in range(n_batches)]
+    Xf = Hh.random_history(rng, 40, I, mean_nnz=30)                       # forward-only batch (no distinct-item list)
+    fakes = [_fake_pairs(rng, X, I) for X in Xs]
+    outs = []
+    for lazy in (False, True):
+        eng = _engine(I, precision, lr=1e-3, lazy_q0=lazy, q0_period=period)
+        assert eng.lazy_q0 == lazy
+        eng.set_generator(Hh.gen_to_engine(P))
+        dev = eng.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        acts = eng.new_acts(B)
+        eng.q0_defer = True
+        losses, mids = [], []
+        for s in range(2 * n_batches):
+            X = Xs[s % n_batches]
+            rows, gen, pop = fakes[s % n_batches]
+            slot, uptr, rowidx, pos, nu = Hh.csc_view(X)
+            batch = CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, uptr=t(uptr), rowidx=t(rowidx), csr_pos=t(pos), n_unique=nu)
+            fake = Pairs(t(pop), t(gen), t(rows))
+            cnt = torch.tensor([int(((gen >= 0) & (pop >= 0)).sum())], dtype=torch.int32, device=dev)
+            eng.adam_t += s % 3                                           # the shared counter also moves between G steps (D steps)
+            losses.append(eng.g_step(batch, fake, acts, cnt, 0.05, rng_step=10 + s, d_rng_step=200 + s).clone())
+            if s == n_batches + 2:                                        # mid-phase forward: rows are caught up as they are read
+                fa = eng.new_acts(40)
+                eng.forward(CsrRows(t(Xf.indptr.astype(np.int32)), t(Xf.indices.astype(np.int32)), 0, 40), fa)
+                mids.append(fa.logits[:40].clone())
+                mids.append(fa.h1[:40].clone())
+        if lazy:
+            torch.cuda.synchronize()
+            assert int(eng.q0_last.min()) < eng.gen_c.q0_ord              # some rows really lag before the flush
+            assert int(eng.q0_last.min()) >= eng.gen_c.q0_ord - period    # ... by no more than the period
+        eng.q0_defer = False
+        eng.g_flush()
+        torch.cuda.synchronize()
+        if lazy:
+            assert int(eng.q0_last.min()) == eng.gen_c.q0_ord == 2 * n_batches
+        outs.append([x.cpu() for x in losses + mids + eng.g_p + eng.g_m + eng.g_v])
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
