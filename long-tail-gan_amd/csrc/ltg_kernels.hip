@@ -1779,20 +1779,20 @@ __global__ __launch_bounds__(Q0_NT) void k_q0_sweep(int I, int H, int start, int
 // Sampler: sample_from_generator_new (sample.py:40-67) + pair construction (train.py:227-251).
 // One wave per user.  Successive sampling without replacement == Gumbel-top-k on log p.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __restrict__ cand_ptr,
-                                                     const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ pop_ptr,
-                                                     const int32_t* __restrict__ pop_idx, const int32_t* __restrict__ n_sample,
-                                                     const int32_t* __restrict__ slot_ptr, const uint8_t* __restrict__ valid_item,
-                                                     const float* __restrict__ u_gumbel, const float* __restrict__ u_pick,
-                                                     uint64_t seed, uint64_t step, const float* __restrict__ logits,
-                                                     const float* __restrict__ lse, int32_t* __restrict__ gen_out,
-                                                     int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out,
-                                                     const float* __restrict__ cand_logit) {
+constexpr int SP_NT = 1024;   // 16 waves: the rank loop is arithmetic over LDS broadcasts -- four waves per SIMD hide the LDS latency
+__global__ __launch_bounds__(SP_NT) void k_sample_pairs(int I, const int32_t* __restrict__ cand_ptr,
+                                                        const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ pop_ptr,
+                                                        const int32_t* __restrict__ pop_idx, const int32_t* __restrict__ n_sample,
+                                                        const int32_t* __restrict__ slot_ptr, const uint8_t* __restrict__ valid_item,
+                                                        const float* __restrict__ u_gumbel, const float* __restrict__ u_pick,
+                                                        uint64_t seed, uint64_t step, const float* __restrict__ logits,
+                                                        const float* __restrict__ lse, int32_t* __restrict__ gen_out,
+                                                        int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out,
+                                                        const float* __restrict__ cand_logit) {
     // I is the GLOBAL item count (RNG index space); cand_logit (optional, aligned with cand_idx) replaces
     // the [B, I] logits matrix when the items are sharded over ranks.
     extern __shared__ __attribute__((aligned(16))) float s_key[];
-    __shared__ int s_w[NT / 64];
-    __shared__ float red[NT / 64];
+    __shared__ int s_w[SP_NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ns = n_sample[b];
     const int s0 = slot_ptr[b];
@@ -1800,40 +1800,72 @@ __global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __res
     const int c0 = cand_ptr[b], nc = cand_ptr[b + 1] - c0;
     const float l = lse[b];
     const float* row = logits + (size_t)b * I;
-    float nnzf = 0.f;
-    for (int j = tid; j < nc; j += NT) {
+    // sum over the workgroup of a small non-negative count (all threads get it)
+    auto block_count = [&](int x) -> int {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        __syncthreads();
+        if (lane == 0) s_w[w] = x;
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < SP_NT / 64; ++i) t += s_w[i];
+        return t;
+    };
+    int nnz_l = 0;
+    for (int j = tid; j < nc; j += SP_NT) {
         const int it = cand_idx[c0 + j];
         const float lp = (cand_logit ? cand_logit[c0 + j] : row[it]) - l;
         const bool pos = expf(lp) > 0.f;  // softmax underflow == "zero probability" of sample.py:45
         float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, (uint64_t)b * (uint64_t)I + it);
         u = fmaxf(u, 2.98023223876953125e-8f);  // 2^-25
         s_key[j] = pos ? lp - logf(-logf(u)) : -INFINITY;
-        nnzf += pos ? 1.f : 0.f;
+        nnz_l += pos ? 1 : 0;
     }
-    const int nnz = (int)block_sum(nnzf, red);  // includes the barrier that publishes s_key
+    const int nnz = block_count(nnz_l);  // includes the barrier that publishes s_key
     const int k_eff = min(ns, nnz);  // Q10: exception-driven decrement of to_sample
     const int np = pop_ptr[b + 1] - pop_ptr[b];
-    int written = 0;
-    float okf = 0.f;
-    for (int j0 = 0; j0 < nc; j0 += NT) {
-        const int j = j0 + tid;
-        bool sel = false;
-        if (j < nc) {
+    // Selected = the k_eff largest keys, ties to the smaller index.  Fast pass: g(j) = #{t : key_t > key_j} (one compare per
+    // pair, 16-byte LDS broadcasts).  {j : g(j) < k_eff} is the selected set unless equal keys straddle the boundary -- then it
+    // is larger than k_eff, and the exact ranks (with the index tie-break) are counted instead.  A -inf key has g >= nnz >= k_eff.
+    const int nc4 = nc >> 2;
+    const ltg_f32x4* k4 = reinterpret_cast<const ltg_f32x4*>(s_key);
+    unsigned selmask = 0;   // bit p: candidate j = tid + p * SP_NT (<= 16 passes: max_cand <= 16384)
+    int nsel_l = 0;
+    for (int j = tid, p = 0; j < nc; j += SP_NT, ++p) {
+        const float kj = s_key[j];
+        int g = 0;
+        for (int t = 0; t < nc4; ++t) {
+            const ltg_f32x4 k = k4[t];
+            g += (k[0] > kj ? 1 : 0) + (k[1] > kj ? 1 : 0) + (k[2] > kj ? 1 : 0) + (k[3] > kj ? 1 : 0);
+        }
+        for (int t = nc4 * 4; t < nc; ++t) g += s_key[t] > kj ? 1 : 0;
+        if (g < k_eff) { selmask |= 1u << p; ++nsel_l; }
+    }
+    if (block_count(nsel_l) != k_eff) {   // equal keys at the boundary (uniform branch)
+        selmask = 0;
+        for (int j = tid, p = 0; j < nc; j += SP_NT, ++p) {
             const float kj = s_key[j];
             int rank = 0;
             for (int t = 0; t < nc; ++t) {
                 const float kt = s_key[t];
                 rank += (kt > kj || (kt == kj && t < j)) ? 1 : 0;
             }
-            sel = rank < k_eff;
+            if (rank < k_eff) selmask |= 1u << p;
         }
+    }
+    int written = 0;
+    int ok_l = 0;
+    for (int j0 = 0, p = 0; j0 < nc; j0 += SP_NT, ++p) {
+        const int j = j0 + tid;
+        const bool sel = (selmask >> p) & 1u;
         const unsigned long long bal = __ballot(sel);
         __syncthreads();
         if (lane == 0) s_w[w] = __popcll(bal);
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
-        for (int i = 0; i < NT / 64; ++i) {
+        for (int i = 0; i < SP_NT / 64; ++i) {
             before += i < w ? s_w[i] : 0;
             total += s_w[i];
         }
@@ -1847,15 +1879,15 @@ __global__ __launch_bounds__(NT) void k_sample_pairs(int I, const int32_t* __res
             const bool ok = valid_item[gid] != 0 && valid_item[pid] != 0;  // train.py:240
             gen_out[s] = ok ? gid : -1;
             pop_out[s] = ok ? pid : -1;
-            okf += ok ? 1.f : 0.f;
+            ok_l += ok ? 1 : 0;
         }
         written += total;
     }
-    for (int s = s0 + written + tid; s < s0 + ns; s += NT) {
+    for (int s = s0 + written + tid; s < s0 + ns; s += SP_NT) {
         gen_out[s] = -1;
         pop_out[s] = -1;
     }
-    const int okcnt = (int)block_sum(okf, red);
+    const int okcnt = block_count(ok_l);
     if (tid == 0 && okcnt > 0) atomicAdd(cnt_out, okcnt);
 }
 
@@ -2353,7 +2385,7 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
     const int max_cand = in->max_cand > 0 ? in->max_cand : 1;
     const size_t lds = (size_t)max_cand * sizeof(float);
     if (lds > 64 * 1024) return LTG_EINVAL;
-    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(NT), lds, st, Ig_of(cfg), in->cand_ptr, in->cand_idx, in->pop_ptr,
+    hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(SP_NT), lds, st, Ig_of(cfg), in->cand_ptr, in->cand_idx, in->pop_ptr,
                        in->pop_idx, in->n_sample, in->slot_ptr, in->valid_item, in->u_gumbel, in->u_pick, cfg->seed, in->rng_step,
                        logits, lse, gen_out, pop_out, cnt_out, in->cand_logit);
     return check_launch();

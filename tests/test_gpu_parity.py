@@ -779,3 +779,66 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
         outs.append([x.cpu() for x in losses + mids + eng.g_p + eng.g_m + eng.g_v])
     for k, (a, b) in enumerate(zip(*outs)):
         assert torch.equal(a, b), k
+
+
+def test_sampler_ties_and_long_candidate_lists():
+    """Equal Gumbel keys go to the smaller index (oracle: lexsort on (-key, index)); the kernel's fast pass counts strictly
+    larger keys only and must fall back to the exact ranks when equal keys straddle the selection boundary.  Users:
+    0 = every key equal, 1 = 2 500 candidates (several passes of the 1 024-thread workgroup), 2 = a block of equal maximal
+    keys larger than the sample, 3 = equal keys entirely inside the sample (fast pass suffices)."""
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import _ptr
+    I, B = 6000, 4
+    rng = np.random.default_rng(99)
+    eng = _engine(I, "fp32")
+    ncs, nsamp = [50, 2500, 300, 300], [7, 40, 9, 30]
+    cand = [np.sort(rng.choice(I, n, replace=False)).astype(np.int32) for n in ncs]
+    cand_ptr = np.concatenate([[0], np.cumsum(ncs)]).astype(np.int32)
+    cand_idx = np.concatenate(cand)
+    pop_ptr = np.arange(B + 1, dtype=np.int32) * 3
+    pop_idx = rng.choice(I, 3 * B, replace=False).astype(np.int32)
+    n_sample = np.array(nsamp, np.int32)
+    slot_ptr = np.concatenate([[0], np.cumsum(n_sample)]).astype(np.int32)
+    valid = np.ones(I, np.uint8)
+    logits = rng.normal(0, 1.5, (B, I)).astype(np.float32)
+    u_g = rng.random(len(cand_idx)).astype(np.float32)
+    logits[0, cand[0]] = 0.25
+    u_g[cand_ptr[0]:cand_ptr[1]] = 0.5
+    tie = rng.choice(ncs[2], 40, replace=False)                  # user 2: 40 equal keys above everything else, 9 to sample
+    logits[2, cand[2][tie]] = 9.0
+    u_g[cand_ptr[2] + tie] = 0.75
+    tie3 = rng.choice(ncs[3], 12, replace=False)                 # user 3: 12 equal top keys, 30 to sample
+    logits[3, cand[3][tie3]] = 9.0
+    u_g[cand_ptr[3] + tie3] = 0.75
+    mx = logits.max(1, keepdims=True).astype(np.float64)
+    lse = (mx + np.log(np.exp(logits - mx).sum(1, keepdims=True)))[:, 0].astype(np.float32)
+    ns = int(slot_ptr[-1])
+    u_p = rng.random(ns).astype(np.float32)
+    acts = eng.new_acts(B)
+    acts.logits[:B].copy_(torch.from_numpy(logits))
+    acts.lse[:B].copy_(torch.from_numpy(lse))
+    dev = eng.device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d = [t(x) for x in (cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, slot_ptr, valid)]
+    ug, up = t(u_g), t(u_p)
+    samp = cabi.ltg_sample_inputs(B, max(ncs), *[_ptr(x) for x in d], 3, _ptr(ug), _ptr(up), None)
+    gen = torch.full((ns,), -7, dtype=torch.int32, device=dev)
+    pop = torch.full((ns,), -7, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng.sample_pairs(samp, acts, gen, pop, cnt)
+    torch.cuda.synchronize()
+    gen = gen.cpu().numpy()
+    assert int(cnt.item()) == ns
+    for b in range(B):
+        c = cand[b]
+        lp = (logits[b, c] - lse[b]).astype(np.float32)
+        key32 = lp - np.log(-np.log(u_g[cand_ptr[b]:cand_ptr[b + 1]].astype(np.float32))).astype(np.float32)
+        want = np.sort(np.lexsort((np.arange(len(c)), -key32.astype(np.float64)))[:nsamp[b]])
+        got = gen[slot_ptr[b]:slot_ptr[b + 1]]
+        if b in (0, 2, 3):                                       # the ties are exact in any precision: the answer is determined
+            assert np.array_equal(got, c[want]), b
+        else:                                                    # fp32 keys of the kernel vs numpy's: allow a boundary flip
+            assert len(np.setdiff1d(got, c[want])) <= 1, b
+    assert np.array_equal(gen[slot_ptr[0]:slot_ptr[1]], cand[0][:7])                       # all equal: the first seven
+    assert np.array_equal(gen[slot_ptr[2]:slot_ptr[3]], cand[2][np.sort(tie)[:9]])         # the first nine of the tied block
