@@ -254,6 +254,9 @@ int32_t ltg_abi_version(void);
 /* Bytes of workspace needed by any entry point for at most max_rows user rows and max_pairs
  * discriminator rows (real+fake) per call. */
 size_t ltg_workspace_bytes(const ltg_config* cfg, int32_t max_rows, int32_t max_pairs);
+/* Bytes of the optional scratch of ltg_vae_forward (its ws argument) for at most max_rows rows: row statistics of large item
+ * slabs in one pass.  Without it (ws == NULL or smaller) the forward computes them row by row. */
+size_t ltg_forward_scratch_bytes(const ltg_config* cfg, int32_t max_rows);
 
 /* Generator forward: replaces sess.run(generator_out, {input_ph: X}) -- Codes/train.py:200, :339,
  * Codes/test.py:146 (graph: MultiVAE.py:145-186, softmax :143).  Fills `acts`; if probs_out != NULL

@@ -116,6 +116,7 @@ SYMBOLS = {
                                  C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), vp, vp, C.c_size_t, vp]),
     "ltg_gather_cand_logits": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_sample_inputs), vp, vp, vp]),
     "ltg_refresh_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
+    "ltg_forward_scratch_bytes": (C.c_size_t, [C.POINTER(ltg_config), C.c_int32]),
     "ltg_g_flush": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
     "ltg_refresh_d_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,

@@ -296,9 +296,14 @@ __device__ __forceinline__ void st_stash_w(unsigned short* __restrict__ Wl, cons
     if (c0 + 64 < ST_C16) row[c0 + 64] = r.e;
 }
 
+// STATS: every lane also keeps the running (max, sum of exp) of the logits it stores (four batch rows x two items per tile);
+// at the end the 16 lanes of a row merge theirs and the workgroup writes stat[blockIdx.x][row] = (max, sum exp(. - max)) over
+// ITS tiles -- the softmax statistics come out of the producing epilogue, the [B, I] logits are not read again for them
+// (k_row_stats_merge folds the workgroups' pairs and adds the sparse terms).
+template <bool STATS>
 __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, const float* __restrict__ h2,
                                                            const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
-                                                           float* __restrict__ logits) {
+                                                           float* __restrict__ logits, float* __restrict__ stat) {
     extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup).  Rows >= M MIRROR row M - 1:
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
         }
     }
     const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
+    float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rs[4] = {0.f, 0.f, 0.f, 0.f};
     StW r0, r1;
     int t = blockIdx.x, cur = 0;
     if (t < ntiles) {
@@ -349,8 +355,16 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
         }                                                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                         \
             const size_t ro = (size_t)min(16 * w + 4 * lq + q, M - 1) * I;                                                      \
-            logits[ro + ia] = acc0[q] + biasa;                                                                                  \
-            logits[ro + ib] = acc1[q] + biasb;                                                                                  \
+            const float la = acc0[q] + biasa, lb = acc1[q] + biasb;                                                             \
+            logits[ro + ia] = la;                                                                                               \
+            logits[ro + ib] = lb;                                                                                               \
+            if constexpr (STATS) { /* a clamped repeat of the last tile / an item past the end counts for nothing */            \
+                const float xa = (t <= last && tc * ST_BN + lr < I) ? la : -INFINITY;                                           \
+                const float xb = (t <= last && tc * ST_BN + 16 + lr < I) ? lb : -INFINITY;                                      \
+                const float mn = fmaxf(rm[q], fmaxf(xa, xb)), mr = fmaxf(mn, -1e30f);                                           \
+                rs[q] = rs[q] * __expf(rm[q] - mr) + __expf(xa - mr) + __expf(xb - mr);                                         \
+                rm[q] = mn;                                                                                                     \
+            }                                                                                                                   \
         }                                                                                                                       \
         st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                    \
         __syncthreads();                                                                                                        \
@@ -363,6 +377,24 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
         t -= G;
     }
 #undef ST_STEP
+    if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {   // the 16 lanes lr of a row
+                const float m2 = __shfl_xor(rm[q], o), s2 = __shfl_xor(rs[q], o);
+                const float mn = fmaxf(rm[q], m2), mr = fmaxf(mn, -1e30f);
+                rs[q] = rs[q] * __expf(rm[q] - mr) + s2 * __expf(m2 - mr);
+                rm[q] = mn;
+            }
+            const int row = 16 * w + 4 * lq + q;
+            if (lr == 0 && row < M) {
+                float* o2 = stat + ((size_t)blockIdx.x * M + row) * 2;
+                o2[0] = rm[q];
+                o2[1] = rs[q];
+            }
+        }
+    }
 }
 
 // part[blockIdx.x][b][h]: this workgroup's share of dh2 (k_da2 sums the slabs)
@@ -1072,6 +1104,12 @@ __global__ __launch_bounds__(NT) void k_row_partial(int I, int item_lo, const in
 // Large item slabs: the same statistics per (4096-item segment, row) in one pass over the logits (the segment
 // lives in registers between the max and the exp-sum), merged per row by k_row_partial_merge.
 constexpr int RS_SEG = 4096;
+// scratch of the row statistics: 5 floats per (4096-item segment, row) for k_row_partial_seg, or 2 floats per (workgroup of
+// k_dec1_fwd_stream<true>, row) -- at most 256 workgroups
+inline size_t segpart_floats(int I, int rows) {
+    const size_t a = ((size_t)I + RS_SEG - 1) / RS_SEG * rows * 5, b = (size_t)256 * rows * 2;
+    return a > b ? a : b;
+}
 __global__ __launch_bounds__(NT) void k_row_partial_seg(int I, int item_lo, const int32_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices, const float* __restrict__ values,
                                                         const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
@@ -1154,6 +1192,50 @@ __global__ __launch_bounds__(64) void k_row_partial_merge(int B, int nseg, const
             o[4] = nx;
         }
         if (lse) lse[b] = M + logf(s);
+    }
+}
+
+// Row partial (same 5 floats) from the statistics k_dec1_fwd_stream<true> left: fold the G workgroups' (max, sum exp) pairs
+// of the row, then the sparse terms -- sum x logit and sum x over the row's entries, sum exp(logit - max) over its fake pairs
+__global__ __launch_bounds__(NT) void k_row_stats_merge(int B, int G, int I, int item_lo, const float* __restrict__ stat, const int32_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                        const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
+                                                        const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
+                                                        float* __restrict__ rowpart, float* __restrict__ lse) {
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x;
+    const float* row = logits + (size_t)b * I;
+    float mx = -INFINITY;
+    for (int g = threadIdx.x; g < G; g += NT) mx = fmaxf(mx, stat[((size_t)g * B + b) * 2]);
+    mx = block_max(mx, red);
+    float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
+    for (int g = threadIdx.x; g < G; g += NT) {
+        const float* q = stat + ((size_t)g * B + b) * 2;
+        s += q[1] * expf(q[0] - mx);
+    }
+    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+        const float x = values ? values[e] : 1.f;
+        xl += x * row[indices[e]];
+        nx += x;
+    }
+    for (int q = threadIdx.x; q < nf; q += NT) {
+        const int it = f_gen[q] - item_lo;
+        if (f_row[q] == b && f_gen[q] >= 0 && f_pop[q] >= 0 && it >= 0 && it < I) ps += expf(row[it] - mx);
+    }
+    s = block_sum(s, red);
+    xl = block_sum(xl, red);
+    nx = block_sum(nx, red);
+    ps = block_sum(ps, red);
+    if (threadIdx.x == 0) {
+        if (rowpart) {
+            float* o = rowpart + (size_t)b * RP;
+            o[0] = mx;
+            o[1] = s;
+            o[2] = xl;
+            o[3] = ps;
+            o[4] = nx;
+        }
+        if (lse) lse[b] = mx + logf(s);
     }
 }
 
@@ -2078,7 +2160,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
         if (ns2 > nsplit) nsplit = ns2;
     }
     w.rowpart = take(R * RP);
-    w.segpart = take(((I + RS_SEG - 1) / RS_SEG) * R * RP);
+    w.segpart = take(segpart_floats(I, R));
     w.nb = take(R);
     w.Pb = take(R);
     w.scal = take(16);
@@ -2207,8 +2289,11 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 }
 
 // stage 2: (bias + tanh of the all-reduced pre-activation,) enc-1, reparameterisation, dec-0, dec-1 over the local slab
-void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
-                    const ltg_gen_acts* acts, int apply_bias_tanh, hipStream_t st) {
+// stat (optional scratch of segpart_floats()): the streaming decoder kernel leaves its per-workgroup softmax statistics there;
+// returns the number of workgroups that wrote them (0: the caller reads the logits for the statistics)
+int fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
+                   const ltg_gen_acts* acts, int apply_bias_tanh, hipStream_t st, float* stat = nullptr) {
+    int stat_groups = 0;
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const Probe pr{o->probe, st};
     const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
@@ -2240,9 +2325,14 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
             if (bf) hipLaunchKernelGGL(fk_dec1<true>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
             else hipLaunchKernelGGL(fk_dec1<false>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         } else if (stream_ok(cfg, gen, R)) {
-            const int ntiles = (I + ST_BN - 1) / ST_BN;
-            hipLaunchKernelGGL(k_dec1_fwd_stream, dim3(ntiles < 256 ? ntiles : 256), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H,
-                               acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits);
+            const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
+            if (stat && (cfg->reserved0 & (1 << 21)) == 0) {   // (tuning-knob bit 21: statistics from a second pass over the logits)
+                hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H, acts->h2, gen->wp1t_bf16,
+                                   gen->p[7], acts->logits, stat);
+                stat_groups = G;
+            } else
+                hipLaunchKernelGGL(k_dec1_fwd_stream<false>, dim3(G), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H, acts->h2, gen->wp1t_bf16,
+                                   gen->p[7], acts->logits, (float*)nullptr);
         } else if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dec1_fwd<true, false, true>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf) hipLaunchKernelGGL((k_dec1_fwd<true, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
@@ -2250,12 +2340,12 @@ void fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
         else hipLaunchKernelGGL((k_dec1_fwd<false, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         pr.after(LTG_K_DEC1_FWD);
     }
+    return stat_groups;
 }
 
 // bytes of the segment-partial scratch for `rows` rows (the first two carve entries of the workspace)
 inline size_t segpart_bytes(const ltg_config* cfg, int rows) {
-    const size_t nseg = ((size_t)cfg->n_items + RS_SEG - 1) / RS_SEG;
-    return align_up((size_t)rows * RP * sizeof(float)) + align_up(nseg * rows * RP * sizeof(float));
+    return align_up((size_t)rows * RP * sizeof(float)) + align_up(segpart_floats(cfg->n_items, rows) * sizeof(float));
 }
 
 int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
@@ -2263,10 +2353,14 @@ int vae_forward_impl(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_
     const int R = bt->n_rows, I = cfg->n_items;
     if (R <= 0) return LTG_OK;
     fwd_stage_enc(cfg, gen, bt, o, acts, 0, st);
-    fwd_stage_rest(cfg, gen, bt, o, acts, 0, st);
-    if (ws && I > 2 * RS_SEG && ws_bytes >= segpart_bytes(cfg, R)) {
+    const bool have_scratch = ws && I > 2 * RS_SEG && ws_bytes >= segpart_bytes(cfg, R);
+    float* segpart = have_scratch ? reinterpret_cast<float*>((char*)ws + align_up((size_t)R * RP * sizeof(float))) : nullptr;
+    const int sg = fwd_stage_rest(cfg, gen, bt, o, acts, 0, st, segpart);
+    if (sg > 0) {
+        hipLaunchKernelGGL(k_row_stats_merge, dim3(R), dim3(NT), 0, st, R, sg, I, cfg->item_lo, segpart, bt->indptr, bt->indices, bt->values, acts->logits, 0,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr, acts->lse);
+    } else if (have_scratch) {
         // large item slab: one pass over the logits in (segment, row) blocks, then a per-row merge
-        float* segpart = reinterpret_cast<float*>((char*)ws + align_up((size_t)R * RP * sizeof(float)));
         const int nseg = (I + RS_SEG - 1) / RS_SEG;
         hipLaunchKernelGGL(k_row_partial_seg, dim3(nseg, R), dim3(NT), 0, st, I, cfg->item_lo, bt->indptr, bt->indices, bt->values, acts->logits,
                            0, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, segpart);
@@ -2372,6 +2466,11 @@ int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
         !acts->kl_rows || !acts->row_scale)
         return LTG_EINVAL;
     return vae_forward_impl(cfg, gen, batch, opts, acts, probs_out, (hipStream_t)stream, ws, ws_bytes);
+}
+
+size_t ltg_forward_scratch_bytes(const ltg_config* cfg, int32_t max_rows) {
+    if (!cfg_ok(cfg) || max_rows <= 0) return 0;
+    return segpart_bytes(cfg, max_rows);
 }
 
 int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, const float* lse,
@@ -2520,8 +2619,14 @@ int ltg_d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const float* 
 // ltg_g_step runs the same stages back to back with one "rank".
 
 static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_pairs* fake, const ltg_gen_acts* acts,
-                          float* rowpart, hipStream_t st, float* segpart = nullptr, float* lse = nullptr) {
+                          float* rowpart, hipStream_t st, float* segpart = nullptr, float* lse = nullptr, int stat_groups = 0) {
     const int I = cfg->n_items, B = bt->n_rows;
+    if (stat_groups > 0) {   // the decoder kernel left its statistics in segpart
+        hipLaunchKernelGGL(k_row_stats_merge, dim3(B), dim3(NT), 0, st, B, stat_groups, I, cfg->item_lo, segpart, bt->indptr, bt->indices, bt->values,
+                           acts->logits, fake ? fake->n : 0, fake ? fake->row : nullptr, fake ? fake->niche : nullptr, fake ? fake->pop : nullptr,
+                           rowpart, lse);
+        return;
+    }
     if (segpart && I > 2 * RS_SEG) {
         const int nseg = (I + RS_SEG - 1) / RS_SEG;
         hipLaunchKernelGGL(k_row_partial_seg, dim3(nseg, B), dim3(NT), 0, st, I, cfg->item_lo, bt->indptr, bt->indices, bt->values, acts->logits,
@@ -2848,7 +2953,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     o = &o_local;
     const bool small = small_fast(cfg, B);
     fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st, small ? w.xd : nullptr, true);
-    fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st);
+    const int sgroups = fwd_stage_rest(cfg, gen, bt, &o->fwd, acts, 0, st, small ? nullptr : w.segpart);
     if (small) {
         // small item slab: a row's softmax statistics, loss terms and dlogits need no other row -> one launch per stage,
         // nine launches per step: enc0, enc1, dec0, dec1 | row softmax + dlogits, dh2, dz, dh1, Adam tail (dW_q0 = xd^T . da1 dense)
@@ -2870,7 +2975,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         g_chain(cfg, gen, bt, o, acts, w, make_adam(cfg, o->adam_t), nullptr, true, loss_out, st);
         return check_launch();
     }
-    g_row_partial(cfg, bt, fake, acts, w.rowpart, st, w.segpart);
+    g_row_partial(cfg, bt, fake, acts, w.rowpart, st, w.segpart, nullptr, sgroups);
     if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
     // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)
     int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork, acts->h2);
@@ -2895,10 +3000,10 @@ int ltg_g_fwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
     clear_errors();
     if (!g_args_ok(cfg, gen, bt, acts) || !opts || !rowpart_out) return LTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    fwd_stage_rest(cfg, gen, bt, opts, acts, 1, st);
     float* segpart = (ws && ws_bytes >= segpart_bytes(cfg, bt->n_rows))
                          ? reinterpret_cast<float*>((char*)ws + align_up((size_t)bt->n_rows * RP * sizeof(float))) : nullptr;
-    g_row_partial(cfg, bt, (fake && fake->n > 0) ? fake : nullptr, acts, rowpart_out, st, segpart);
+    const int sgroups = fwd_stage_rest(cfg, gen, bt, opts, acts, 1, st, segpart);
+    g_row_partial(cfg, bt, (fake && fake->n > 0) ? fake : nullptr, acts, rowpart_out, st, segpart, nullptr, sgroups);
     return check_launch();
 }
 

@@ -271,10 +271,10 @@ class Engine:
         return self._ws
 
     def _fwd_scratch(self, rows):
-        """segment-partial scratch of the forward (large item slabs only): 5 floats per (4096-item segment, row)"""
+        """row-statistics scratch of the forward (large item slabs only)"""
         if self.I <= 8192:
             return None
-        need = (rows * 5 * 4 + 256) + ((self.I + 4095) // 4096) * rows * 5 * 4 + 512
+        need = int(self.lib.ltg_forward_scratch_bytes(C.byref(self.cfg), rows))
         if getattr(self, "_fs", None) is None or self._fs.numel() < need:
             self._fs = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._fs
