@@ -198,14 +198,14 @@ class KernelProfiler:
         return out
 
     def hook(self, name):
-        """called by the trainer for every D / G step of the timed region; probes every 8th one"""
+        """called by the trainer for every D / G step of the timed region; probes every 32nd one (an event pair costs the stream a few microseconds of bubbles)"""
         state = {"i": 0}
 
         def h(kind, b):
             if (kind == "d") != (name in self.D_KERNELS):
                 return None
             state["i"] += 1
-            if state["i"] % 8 or not self.pool:
+            if state["i"] % 32 or not self.pool:
                 return None
             ev, p = self._probe(name)
             sh = self._shapes(b)
@@ -466,7 +466,7 @@ def main():
         dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
     tr.probe_hook = prof.hook(dominant) if (dominant and rank == 0) else None
     if tr.probe_hook:
-        prof.reserve(min(2048, a.steps * a.sub_epochs * data.n_batches // 8 + 1))
+        prof.reserve(min(2048, a.steps * a.sub_epochs * data.n_batches // 32 + 1))
     barrier()
     t0 = time.perf_counter()
     phases = []

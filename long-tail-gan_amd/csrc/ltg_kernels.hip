@@ -398,6 +398,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
 }
 
 // part[blockIdx.x][b][h]: this workgroup's share of dh2 (k_da2 sums the slabs)
+template <bool D16>
 __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int chunk, const float* __restrict__ dlog,
                                                       const unsigned short* __restrict__ Wb, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     if (ibeg >= iend) return;
     const int row = 16 * w + lr;
     const float* drow = dlog + (size_t)min(row, B - 1) * I;
+    const unsigned short* drow16 = reinterpret_cast<const unsigned short*>(dlog) + (size_t)min(row, B - 1) * I;   // D16: [B][I] bf16
     const int ilast = ibeg + (iend - ibeg - 1) / ST_BN * ST_BN;      // start of the chunk's last 32-item step
     // A fragment of a 32-item step: dlog[row][i0 + 8*lq .. +7] (I % 8 == 0: whole 32-B groups, 16-B aligned).  Loads are
     // unconditional (clamped); rows >= B and steps past the end of the chunk are zeroed with a bit mask, so a clamped
@@ -417,8 +419,11 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
 #define DH_LOAD_A(i0, X0, X1)                                                      \
     {                                                                              \
         const int ib_ = min(min((i0), ilast) + 8 * lq, I - 8);                     \
-        X0 = *reinterpret_cast<const float4*>(drow + ib_);                         \
-        X1 = *reinterpret_cast<const float4*>(drow + ib_ + 4);                     \
+        if constexpr (D16) X0 = *reinterpret_cast<const float4*>(drow16 + ib_);    \
+        else {                                                                     \
+            X0 = *reinterpret_cast<const float4*>(drow + ib_);                     \
+            X1 = *reinterpret_cast<const float4*>(drow + ib_ + 4);                 \
+        }                                                                          \
     }
     StW r0, r1;
     float4 e0, e1, o0, o1;     // A fragments of the even / odd steps
@@ -437,9 +442,14 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     {                                                                                                                           \
         st_fetch_w(Wb, I, min(i0 + 2 * ST_BN, ilast), RL);                                                                      \
         const unsigned keep = (row < B && i0 + 8 * lq < iend) ? 0xFFFFFFFFu : 0u;                                               \
-        const uint2 pa = ltg_pack4(X0), pb = ltg_pack4(X1);                                                                     \
         ltg_u32x4 au;                                                                                                           \
-        au[0] = pa.x & keep; au[1] = pa.y & keep; au[2] = pb.x & keep; au[3] = pb.y & keep;                                     \
+        if constexpr (D16) {                                                                                                    \
+            au[0] = __float_as_uint(X0.x) & keep; au[1] = __float_as_uint(X0.y) & keep;                                         \
+            au[2] = __float_as_uint(X0.z) & keep; au[3] = __float_as_uint(X0.w) & keep;                                         \
+        } else {                                                                                                                \
+            const uint2 pa = ltg_pack4(X0), pb = ltg_pack4(X1);                                                                 \
+            au[0] = pa.x & keep; au[1] = pa.y & keep; au[2] = pb.x & keep; au[3] = pb.y & keep;                                 \
+        }                                                                                                                       \
         const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);                                                               \
         DH_LOAD_A(i0 + 2 * ST_BN, X0, X1)                                                                                       \
         const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
@@ -486,6 +496,7 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
 // (row-major bf16 LDS image, consumed transposed by ds_read_b64_tr_b16), theta/m/v touched exactly once.
 constexpr int DW_LDD = 40;  // LDS row stride of the dlog tile in bf16 (80 B: 16-B aligned)
 constexpr int DW_LDC = 84;  // row stride of a wave's fp32 gradient block (80 columns + 4)
+template <bool D16>
 __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, int H, const float* __restrict__ dlog,
                                                                 const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
     __shared__ __attribute__((aligned(16))) unsigned short Dl[2][128 * DW_LDD];
@@ -529,16 +540,25 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     // dlog tile loader: thread -> (row b = tid / 4, 8 items at 8 * (tid % 4))
     const int lb = tid >> 2, lseg = tid & 3;
     const float* lrow = dlog + (size_t)min(lb, B - 1) * I;
+    const unsigned short* lrow16 = reinterpret_cast<const unsigned short*>(dlog) + (size_t)min(lb, B - 1) * I;   // D16: [B][I] bf16
     auto fetch = [&](int t, float4& x0, float4& x1) {
         const int ib = min(t * 32 + 8 * lseg, I - 8);
-        x0 = *reinterpret_cast<const float4*>(lrow + ib);
-        x1 = *reinterpret_cast<const float4*>(lrow + ib + 4);
+        if constexpr (D16) x0 = *reinterpret_cast<const float4*>(lrow16 + ib);   // eight bf16 = the LDS image as it is
+        else {
+            x0 = *reinterpret_cast<const float4*>(lrow + ib);
+            x1 = *reinterpret_cast<const float4*>(lrow + ib + 4);
+        }
     };
     auto stash = [&](unsigned short* D, int t, const float4& x0, const float4& x1) {
         const bool ok = lb < B && t * 32 + 8 * lseg < I;
         ltg_u32x4 p;
-        const uint2 a = ltg_pack4(x0), c = ltg_pack4(x1);
-        p[0] = ok ? a.x : 0u; p[1] = ok ? a.y : 0u; p[2] = ok ? c.x : 0u; p[3] = ok ? c.y : 0u;
+        if constexpr (D16) {
+            p[0] = ok ? __float_as_uint(x0.x) : 0u; p[1] = ok ? __float_as_uint(x0.y) : 0u;
+            p[2] = ok ? __float_as_uint(x0.z) : 0u; p[3] = ok ? __float_as_uint(x0.w) : 0u;
+        } else {
+            const uint2 a = ltg_pack4(x0), c = ltg_pack4(x1);
+            p[0] = ok ? a.x : 0u; p[1] = ok ? a.y : 0u; p[2] = ok ? c.x : 0u; p[3] = ok ? c.y : 0u;
+        }
         *reinterpret_cast<ltg_u32x4*>(D + lb * DW_LDD + 8 * lseg) = p;
     };
     int t = blockIdx.x, cur = 0;
@@ -1342,6 +1362,8 @@ __global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __r
 // The same with the combine of the R shards' row partials folded in (no k_g_combine launch in front): every workgroup merges
 // the R x 5 partials of ITS row (uniform addresses: scalar loads) and adds up sum_j y_j itself; the segment-0 workgroups also
 // publish lse, and workgroup (0, 0) the step's scalars (train.py:154-157).  Same arithmetic and order as k_g_combine.
+// D16: dlog is stored as bf16 (the streaming consumers feed it to the bf16 MFMA anyway: same operand bits, half the bytes)
+template <bool D16>
 __global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, const int32_t* __restrict__ indptr,
                                                         const int32_t* __restrict__ indices, const float* __restrict__ values,
                                                         const float* __restrict__ logits, const float* __restrict__ rowpart_all,
@@ -1397,9 +1419,19 @@ __global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, con
     const float c = (cnt && cnt[0] > 0) ? lam / (float)cnt[0] * sy : 0.f;
     const float alpha = nx * invB + c * pb;
     const size_t base = (size_t)b * I;
-    for (int i = i0 + threadIdx.x; i < i1; i += NT) {
-        const float p = expf(logits[base + i] - l);
-        dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
+    if constexpr (D16) {   // I % 8 == 0 (stream_ok): pairs of items, one 8-B load and one 4-B store per lane
+        for (int i = i0 + 2 * threadIdx.x; i < i1; i += 2 * NT) {
+            const float2 lg = *reinterpret_cast<const float2*>(logits + base + i);
+            const float p0 = expf(lg.x - l), p1 = expf(lg.y - l);
+            const float d0 = p0 * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p0 : 0.f);
+            const float d1 = p1 * alpha - s_x[i + 1 - i0] * invB - (s_s[i + 1 - i0] ? c * p1 : 0.f);
+            reinterpret_cast<unsigned*>(dlog)[(base + i) >> 1] = (unsigned)ltg_f2bf(d0) | ((unsigned)ltg_f2bf(d1) << 16);
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += NT) {
+            const float p = expf(logits[base + i] - l);
+            dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) lse[b] = l;
     if (blockIdx.x == 0 && blockIdx.y == 0) {   // the step's scalars: out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
@@ -1469,7 +1501,7 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
 }
 
 // dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
-template <bool BF16, int VAR, bool V = false>
+template <bool BF16, int VAR, bool V = false, bool D16 = false>
 __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
                                                       const float* __restrict__ h2, ltg_gen_state st, AdamC ad, int i_begin) {
     // VAR 0: 32x32 tiles, scalar Adam epilogue; 1: 64x128, 2: 64x64, 3: 32x128 tiles with the float4 epilogue
@@ -1478,7 +1510,10 @@ __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const
     const int m0 = i_begin + blockIdx.y * BM, n0 = blockIdx.x * BN;   // i_begin: first item row of this launch
     float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
     unsigned short* Wb = st.wp1t_bf16;  // optional bf16 shadow [I][ST_KP], kept in step with the master weights
-    auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)k * I + m]; };
+    auto a = [=] __device__(int m, int k) -> float {
+        if constexpr (D16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(dlog)[(size_t)k * I + m] << 16);   // dlog stored as bf16
+        else return dlog[(size_t)k * I + m];
+    };
     auto b = [=] __device__(int k, int n) -> float {
         const float v = h2[(size_t)k * H + min(n, H - 1)];
         return n < H ? v : 1.f;
@@ -2639,6 +2674,11 @@ static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_
                        fake ? fake->pop : nullptr, rowpart);
 }
 
+// dlog as bf16: when BOTH its consumers are the streaming kernels (k_dh2_stream, k_dec1_bwd_adam_stream + ragged tail)
+static bool dlog16_ok(const ltg_config* cfg, const ltg_gen_state* gen, int B) {
+    return fast_on(cfg) && stream_ok(cfg, gen, B) && dw_stream_ok(cfg->h_enc) && (cfg->reserved0 & 15) == 0 && (cfg->reserved0 & (1 << 22)) == 0;
+}
+
 static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
                            const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, const float* rowpart_all,
                            int n_ranks, float* loss_out, const Workspace& w, float* dh2_out, hipStream_t st,
@@ -2651,10 +2691,15 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
         DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
         disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
     }
+    const bool d16 = dlog16_ok(cfg, gen, B);
     if (fast_on(cfg)) {
-        hipLaunchKernelGGL(k_dlogits_combine, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, n_ranks, bt->indptr, bt->indices, bt->values,
-                           acts->logits, rowpart_all, acts->kl_rows, nf > 0 ? w.y : (const float*)nullptr, o->cnt, o->anneal, o->gan_lambda, nf,
-                           fake->row, fake->niche, fake->pop, w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo);
+#define LTG_DLC(D16)                                                                                                                                \
+    hipLaunchKernelGGL(k_dlogits_combine<D16>, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, n_ranks, bt->indptr, bt->indices, bt->values, \
+                       acts->logits, rowpart_all, acts->kl_rows, nf > 0 ? w.y : (const float*)nullptr, o->cnt, o->anneal, o->gan_lambda, nf,       \
+                       fake->row, fake->niche, fake->pop, w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo)
+        if (d16) LTG_DLC(true);
+        else LTG_DLC(false);
+#undef LTG_DLC
     } else {
     hipLaunchKernelGGL(k_g_combine, dim3(1), dim3(NT), 0, st, B, n_ranks, rowpart_all, nf, acts->kl_rows, nf > 0 ? w.y : nullptr, o->cnt,
                        o->anneal, o->gan_lambda, acts->lse, w.nb, w.Pb, w.scal, loss_out);
@@ -2667,7 +2712,8 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
     pr.before(LTG_K_DH2);
-    if (stream) hipLaunchKernelGGL(k_dh2_stream, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
+    if (stream && d16) hipLaunchKernelGGL(k_dh2_stream<true>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
+    else if (stream) hipLaunchKernelGGL(k_dh2_stream<false>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
     else if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf && (I % 4) == 0 && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dh2_partial<true, false, true>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf) hipLaunchKernelGGL((k_dh2_partial<true, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
@@ -2835,9 +2881,15 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
         if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->reserved0 & 15) == 0) {
             const int ntl = I / 32;
-            hipLaunchKernelGGL(k_dec1_bwd_adam_stream, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
-            if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
-                hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
+            if (dlog16_ok(cfg, gen, B)) {   // (the producer, g_stage_bwd_dec, stored dlog as bf16 under the same predicate)
+                hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
+                if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
+                    hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
+            } else {
+                hipLaunchKernelGGL(k_dec1_bwd_adam_stream<false>, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
+                if (I % 32)
+                    hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
+            }
         } else if (!bf) {
             if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
             else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);

@@ -842,3 +842,40 @@ def test_sampler_ties_and_long_candidate_lists():
             assert len(np.setdiff1d(got, c[want])) <= 1, b
     assert np.array_equal(gen[slot_ptr[0]:slot_ptr[1]], cand[0][:7])                       # all equal: the first seven
     assert np.array_equal(gen[slot_ptr[2]:slot_ptr[3]], cand[2][np.sort(tie)[:9]])         # the first nine of the tied block
+
+
+def test_streaming_decoder_storage_choices_are_bit_identical():
+    """Large item slabs, bf16 decoder: (a) dlogits stored as bf16 for the streaming consumers (they round it to bf16 for the
+    MFMA anyway) vs fp32 storage (tuning-knob bit 22), (b) softmax statistics from the decoder epilogue vs a second pass over
+    the logits (bit 21: same partial format, another summation order -> compared with a tolerance).  I = 8264: 258 full
+    32-item tiles + a ragged tail of 8 rows for the generic weight-gradient kernel."""
+    import torch
+    from ltgan.engine import CsrRows, Pairs
+    I, B = 8264, 100
+    rng, X, P = _problem(I, B, seed=31)
+    rows, gen, pop = _fake_pairs(rng, X, I)
+    outs = {}
+    for knob in (0, 1 << 22, 1 << 21):
+        eng = _engine(I, "bf16", lr=1e-3)
+        eng.cfg.reserved0 = knob
+        eng.set_generator(Hh.gen_to_engine(P))
+        dev = eng.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        slot, uptr, rowidx, pos, nu = Hh.csc_view(X)
+        batch = CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, uptr=t(uptr), rowidx=t(rowidx), csr_pos=t(pos), n_unique=nu)
+        acts = eng.new_acts(B)
+        fake = Pairs(t(pop), t(gen), t(rows))
+        cnt = torch.tensor([int(((gen >= 0) & (pop >= 0)).sum())], dtype=torch.int32, device=dev)
+        for step in range(3):
+            loss = eng.g_step(batch, fake, acts, cnt, 0.05, rng_step=10 + step, d_rng_step=20 + step).clone()
+        torch.cuda.synchronize()
+        outs[knob] = [loss.cpu()] + [p.cpu() for p in eng.g_p] + [m.cpu() for m in eng.g_m] + [acts.lse[:B].cpu()]
+    for a, b in zip(outs[0], outs[1 << 22]):
+        assert torch.equal(a, b)
+    # another summation order of the row statistics: lse moves in its last bits, a dlogit may round to the neighbouring bf16,
+    # and Adam turns any gradient difference into a fraction of lr = 1e-3 per step
+    for k, (a, b) in enumerate(zip(outs[0], outs[1 << 21])):
+        if k in (0, len(outs[0]) - 1):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), k
+        else:       # an element whose gradient is within rounding of zero moves by up to lr in either direction
+            assert float((a - b).abs().max()) <= 1e-3 and float((a - b).abs().mean()) <= 2e-6, k
