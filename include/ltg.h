@@ -226,7 +226,9 @@ typedef struct ltg_g_opts {
     /* item-sharded runs: ltg_g_bwd_dec1 already updated W_p1t / b_p1 of this step (issued while the dh2 all-reduce was in
      * flight), ltg_g_bwd_rest must not do it again */
     int32_t dec1_done;
-    int32_t reserved0;
+    /* item-sharded runs: ltg_g_fake_tower already left the fake tower's forward in the workspace (issued on another stream
+     * beside the generator forward and its exchanges), ltg_g_bwd_dec must not run it again.  0 or 1. */
+    int32_t fake_done;
     /* optional third caller-created hipEvent_t (with aux_stream): ltg_g_step then runs the rotating slice of the lazy Adam
      * clock of W_q0 (arithmetic-bound) on aux_stream, beside the HBM-bound decoder kernels, and joins it at the end */
     void* ev_sweep;
@@ -325,6 +327,11 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                    ltg_stream stream);
 /* The part of ltg_g_bwd_rest that does not need the all-reduced dh2: Adam on the local W_p1t / b_p1 rows (reads dlogits and
  * h2 of ltg_g_bwd_dec).  Issue it right after starting the dh2 all-reduce, then call ltg_g_bwd_rest with opts->dec1_done = 1. */
+/* The fake tower's forward of a G step (replicated on every rank; needs only the fake pairs and the discriminator) into the
+ * workspace ltg_g_bwd_dec reads it from: same cfg / n_rows / fake / ws as that call, any stream -- the caller orders it
+ * after the previous step's ltg_g_bwd_dec and before this step's, and sets ltg_g_opts.fake_done = 1. */
+int ltg_g_fake_tower(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const ltg_g_opts* o, int32_t n_rows, void* ws,
+                     size_t ws_bytes, ltg_stream stream);
 int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
                    const ltg_g_opts* opts, const ltg_gen_acts* acts, void* ws, size_t ws_bytes, ltg_stream stream);
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out,

@@ -300,7 +300,10 @@ __device__ __forceinline__ void st_stash_w(unsigned short* __restrict__ Wl, cons
 // at the end the 16 lanes of a row merge theirs and the workgroup writes stat[blockIdx.x][row] = (max, sum exp(. - max)) over
 // ITS tiles -- the softmax statistics come out of the producing epilogue, the [B, I] logits are not read again for them
 // (k_row_stats_merge folds the workgroups' pairs and adds the sparse terms).
-template <bool STATS>
+// PF: W tiles of HBM loads in flight per workgroup (register sets of 20 VGPRs each).  Measured at 200 000 items (85 us): PF = 3
+// changes nothing; without the logits stores 69 us, with 1 of the 19 MFMA / LDS-read rounds 66 us, with neither 56 us (the
+// 243 MB of W at 4.3 TB/s): loads, product and stores add up rather than overlap -- one lock-step workgroup per CU.
+template <bool STATS, int PF = 2>
 __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, const float* __restrict__ h2,
                                                            const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
                                                            float* __restrict__ logits, float* __restrict__ stat) {
@@ -327,12 +330,13 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
     }
     const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
     float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-    StW r0, r1;
+    StW r0, r1, r2;
     int t = blockIdx.x, cur = 0;
     if (t < ntiles) {
         st_fetch_w(Wb, I, t * ST_BN, r0);
         st_stash_w(st_lds, r0);
         st_fetch_w(Wb, I, min(t + G, last) * ST_BN, r1);
+        if constexpr (PF == 3) st_fetch_w(Wb, I, min(t + 2 * G, last) * ST_BN, r2);
     }
     __syncthreads();
     // ST_STEP(RL, RS): LDS[cur] holds tile tc = min(t, last), RS holds tile min(t + G, last) (in flight since the previous
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
         const int tc = min(t, last);                                                                                            \
         const int ia = min(tc * ST_BN + lr, I - 1), ib = min(tc * ST_BN + 16 + lr, I - 1);                                      \
         const float biasa = bp1[ia], biasb = bp1[ib]; /* BEFORE the prefetch: waiting for a younger load drains it */           \
-        st_fetch_w(Wb, I, min(t + 2 * G, last) * ST_BN, RL);                                                                    \
+        st_fetch_w(Wb, I, min(t + PF * G, last) * ST_BN, RL);                                                                   \
         const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
         ltg_f32x4 acc0 = ltg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = ltg_f32x4{0.f, 0.f, 0.f, 0.f};                                   \
         _Pragma("unroll") for (int ks = 0; ks < ST_KS; ++ks) {                                                                  \
@@ -370,11 +374,22 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
         __syncthreads();                                                                                                        \
         cur ^= 1;                                                                                                               \
     }
-    for (; t < ntiles; t += 2 * G) {
-        ST_STEP(r0, r1)
-        t += G;
-        ST_STEP(r1, r0)
-        t -= G;
+    if constexpr (PF == 3) {
+        for (; t < ntiles; t += 3 * G) {
+            ST_STEP(r0, r1)
+            t += G;
+            ST_STEP(r1, r2)
+            t += G;
+            ST_STEP(r2, r0)
+            t -= 2 * G;
+        }
+    } else {
+        for (; t < ntiles; t += 2 * G) {
+            ST_STEP(r0, r1)
+            t += G;
+            ST_STEP(r1, r0)
+            t -= G;
+        }
     }
 #undef ST_STEP
     if constexpr (STATS) {
@@ -2801,6 +2816,7 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
 // (three launches of fk_g_tail) instead of running as one tail launch behind them.
 // Adam step gen->q0_ord + 1 of W_q0 / b_q0 on the lazy clock: the batch's rows with their gradient rows (w.gq0), the bias
 // row, then the rotating slice of untouched rows
+constexpr int G_AUX_SWEEP = 0x40000000;   // library-internal bit of ltg_g_opts.fake_done: ltg_g_step runs the slice on its aux stream
 // the rotating slice of G step gen->q0_ord + 1: rows i = ord (mod period) up to `target`
 static void q0_slice_sweep(const ltg_config* cfg, const ltg_gen_state* gen, int target, hipStream_t st) {
     const int I = cfg->n_items, P = gen->q0_period, start = (gen->q0_ord + 1) % P;
@@ -2810,7 +2826,7 @@ static void q0_lazy_update(const ltg_config* cfg, const ltg_gen_state* gen, cons
                            hipStream_t st) {
     const int I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique, ord = gen->q0_ord + 1;
     hipLaunchKernelGGL(k_q0_step_touched, dim3(nu + 1), dim3(Q0_NT), 0, st, I, H, nu, bt->uptr, bt->csr_pos, bt->indices, w.gq0, ord, *gen, ad);
-    if (!o->reserved0) q0_slice_sweep(cfg, gen, ord, st);   // (reserved0 != 0: ltg_g_step has the slice on its aux stream, up to ord - 1)
+    if (!(o->fake_done & G_AUX_SWEEP)) q0_slice_sweep(cfg, gen, ord, st);   // (else: ltg_g_step has the slice on its aux stream, up to ord - 1)
 }
 
 static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
@@ -2900,7 +2916,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         prs.after(LTG_K_DEC1_BWD_ADAM);
     };
-    if (o->reserved0 && q0_lazy(cfg, gen)) {
+    if ((o->fake_done & G_AUX_SWEEP) && q0_lazy(cfg, gen)) {
         // ltg_g_step, lazy Adam clock of W_q0: the rotating slice becomes eligible on the aux stream together with the decoder
         // weight update (enqueued first: its 256 persistent workgroups take their CUs, the slice's waves fill what is left)
         (void)hipEventRecord(evf, st);
@@ -3001,7 +3017,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         }
     }
     ltg_g_opts o_local = *o;
-    o_local.reserved0 = aux_sweep ? 1 : 0;
+    o_local.fake_done = (o->fake_done & 1) | (aux_sweep ? G_AUX_SWEEP : 0);
     o = &o_local;
     const bool small = small_fast(cfg, B);
     fwd_stage_enc(cfg, gen, bt, &o->fwd, acts, 0, st, small ? w.xd : nullptr, true);
@@ -3078,7 +3094,20 @@ int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_dis
     if (!o->cnt || !fake->row || fake->n < 0) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);
-    return g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, rowpart_all, n_ranks, loss_out, w, dh2_out, (hipStream_t)stream);
+    return g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, rowpart_all, n_ranks, loss_out, w, dh2_out, (hipStream_t)stream, (o->fake_done & 1) != 0);
+}
+
+int ltg_g_fake_tower(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const ltg_g_opts* o, int32_t n_rows, void* ws,
+                     size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !disc || !fake || !o || !ws || n_rows <= 0 || fake->n < 0) return LTG_EINVAL;
+    if (ltg_workspace_bytes(cfg, n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
+    if (fake->n == 0) return LTG_OK;
+    const Workspace w = carve(cfg, n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: y lives there
+    PairView pv{0, fake->n, nullptr, nullptr, fake->pop, fake->niche};
+    DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
+    disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, (hipStream_t)stream);
+    return check_launch();
 }
 
 int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pairs* fake,

@@ -414,6 +414,14 @@ class Engine:
                                           C.byref(gopts), C.byref(acts.c), _ptr(rowpart_all), n_ranks, _ptr(loss_out), _ptr(dh2_out),
                                           _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_dec")
 
+    def g_fake_tower(self, batch, fake, gopts, stream=None):
+        """the fake tower's forward of the step, on `stream` (a torch stream; default: the current one); sets gopts.fake_done"""
+        ws = self.workspace(batch.n_rows, fake.n)
+        st = self.stream() if stream is None else stream.cuda_stream
+        cabi.check(self.lib.ltg_g_fake_tower(C.byref(self.cfg), C.byref(self.disc_c), C.byref(fake.c), C.byref(gopts), batch.n_rows, _ptr(ws),
+                                             ws.numel(), st), "ltg_g_fake_tower")
+        gopts.fake_done = 1
+
     def g_bwd_dec1(self, batch, fake, acts, gopts):
         """Adam on the local W_p1t / b_p1 rows: needs nothing of the dh2 exchange, so it is issued while that all-reduce flies"""
         ws = self.workspace(batch.n_rows, fake.n)

@@ -23,6 +23,8 @@ latency-bound 644-KB all-reduce would take; at the wide sizes (3.5 M parameters,
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -59,6 +61,10 @@ class ShardedTrainer(Trainer):
         self.rowpart = torch.zeros(B * 5, dtype=torch.float32, device=dev)
         self.rowpart_all = torch.zeros(self.R * B * 5, dtype=torch.float32, device=dev)
         self.dh2 = torch.zeros(B, engine.H, dtype=torch.float32, device=dev)
+        self.fake_overlap = os.environ.get("LTGAN_FAKE_OVERLAP", "1") != "0"     # measurement switch
+        self._side = torch.cuda.Stream(dev)
+        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        engine.workspace(B, data.max_pairs)        # sized once: the side stream must never see it reallocated
         self.cand_logit = torch.zeros(max(1, int(data.idx.cand_ptr[-1])), dtype=torch.float32, device=dev)
 
     # -- collectives -------------------------------------------------------------------------------
@@ -135,7 +141,17 @@ class ShardedTrainer(Trainer):
                 B = v["batch"].n_rows
                 pr = self.probe_hook("g", b) if self.probe_hook else None
                 go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step(), probe=pr)
+                if self.fake_overlap and v["fake"].n > 0:
+                    # the fake tower (replicated, needs nothing of the generator) on a side stream, beside the forward and its
+                    # two exchanges; ordered after the previous step's reader of its outputs, joined before this step's
+                    main = torch.cuda.current_stream()
+                    self._ev_fork.record(main)
+                    self._side.wait_event(self._ev_fork)
+                    eng.g_fake_tower(v["batch"], v["fake"], go, stream=self._side)
+                    self._ev_join.record(self._side)
                 rp_all = self._forward(v, v["fake"], go.fwd)
+                if go.fake_done:
+                    torch.cuda.current_stream().wait_event(self._ev_join)
                 eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
                 # exchange 3 flies while the decoder weight update (which needs none of it) runs
                 work = dist.all_reduce(self.dh2[:B], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
