@@ -19,20 +19,23 @@ def main():
     from ltgan.synthetic import synthetic_index
     from ltgan.trainer import Trainer
     workload, users, precision = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-    d_split = len(sys.argv) > 4 and sys.argv[4] == "dsplit"      # pair rows of the discriminator step split over the ranks
+    mode = sys.argv[4] if len(sys.argv) > 4 else ""
+    d_split = mode in ("dsplit", "wide_fp8")                     # pair rows of the discriminator step split over the ranks
+    wide = mode == "wide_fp8"                                    # BASELINE config 5 inside the sharded loop: wide discriminator, fp8 GEMM operands
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda:0"
     idx, _ = synthetic_index(workload, users=users, seed=5)
     I = idx.n_items
-    hs = (16, 24, 40, 32)
+    hs = (512, 256, 256, 128) if wide else (16, 24, 40, 32)
+    dq = "fp8" if wide else "fp32"
     S = 2
     # ---- unsharded reference
-    ref = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev)
+    ref = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev, d_precision=dq)
     ref_tr = Trainer(ref, DeviceData(idx, 100, dev), num_sub_epochs=S, shuffle_seed=1)
     # ---- this rank's shard
     lo, hi = item_slab(I, rank, world)
-    eng = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi)
+    eng = Engine(I, h_sizes=hs, lr=1e-3, precision=precision, seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi, d_precision=dq)
     data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
     tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1, d_split=d_split)
     assert tr.d_split == d_split
@@ -70,10 +73,13 @@ def main():
         assert torch.equal(data.fake_cnt, ref_tr.data.fake_cnt)
         dl_ref = ref_tr.d_phase().cpu().numpy()[:S, 0]
         dl = tr.d_phase().cpu().numpy()[:S, 0]
-        np.testing.assert_allclose(dl, dl_ref, rtol=2e-5 if d_split else 1e-6)     # split: gradient and loss sums meet in another order
+        # split: gradient and loss sums meet in another order; fp8: a weight that differs in its last bit can round to the other e4m3 neighbour
+        np.testing.assert_allclose(dl, dl_ref, rtol=5e-3 if wide else (2e-5 if d_split else 1e-6))
         gl_ref = ref_tr.g_phase().cpu().numpy()[:S, :6]
         gl = tr.g_phase().cpu().numpy()[:S, :6]
         tol = 2e-5 if precision == "fp32" else 2e-3
+        if wide:
+            tol = 1e-2
         np.testing.assert_allclose(gl[:, :2], gl_ref[:, :2], rtol=tol)
         np.testing.assert_allclose(gl[:, 2:], gl_ref[:, 2:], rtol=10 * tol, atol=1e-6)
     torch.cuda.synchronize()
@@ -85,11 +91,11 @@ def main():
         err = (eng.g_p[i] - want).abs().max().item()
         assert err < atol * 50 if i not in (0, 3, 7) else err < atol * 50, ("gen tensor", i, err)
     for i in range(8):
-        assert (eng.d_p[i] - ref.d_p[i]).abs().max().item() < (2e-5 if d_split else 1e-6), ("disc tensor", i)
+        assert (eng.d_p[i] - ref.d_p[i]).abs().max().item() < (2.5e-3 if wide else (2e-5 if d_split else 1e-6)), ("disc tensor", i)   # wide: lr = 1e-3 per step
     assert eng.adam_t == ref.adam_t
     dist.barrier()
     if rank == 0:
-        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s" % (world, workload, precision, d_split))
+        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s d_precision=%s" % (world, workload, precision, d_split, dq))
     dist.destroy_process_group()
 
 

@@ -11,10 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("workload,users,precision,mode", [("custom:1000", 250, "fp32", ""), ("ml20m", 200, "fp32", ""), ("ml20m", 200, "bf16", ""),
-                                                           ("custom:1000", 250, "fp32", "dsplit")])
+                                                           ("custom:1000", 250, "fp32", "dsplit"), ("ml20m", 200, "bf16", "wide_fp8")])
 def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mode):
     """mode "dsplit": the discriminator's pair rows are split over the two ranks too (ltg_d_grad -> gradient all-reduce ->
-    ltg_d_apply) -- same d_loss trajectory and weights as the unsharded step."""
+    ltg_d_apply) -- same d_loss trajectory and weights as the unsharded step.  mode "wide_fp8": BASELINE config 5's shape inside
+    the sharded loop -- a wide discriminator with fp8 GEMM operands (operand-format shadows maintained by the Adam sweep), pair-split,
+    over item slabs large enough for the streaming decoder kernels and the lazy Adam clock of W_q0."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29577", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), precision] + ([mode] if mode else [])
