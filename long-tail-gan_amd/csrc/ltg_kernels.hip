@@ -2545,7 +2545,9 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
 static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLayout& L, int ks, int stride, const float* slab, int n,
                     const float* lrow, const AdamC& ad, float* loss_out, const Probe& pr, hipStream_t st) {
     const int P = L.off[8];
-    bool flat = lrow == nullptr && (stride % 4) == 0;   // one flat float4 sweep when the eight tensors (and moments) lie back to back
+    // one flat float4 sweep when the eight tensors (and moments) lie back to back -- and no operand-format shadows have to follow
+    // the weights (fp8 mode: k_d_adam rewrites the e4m3 copies of the three matrices it updates)
+    bool flat = lrow == nullptr && (stride % 4) == 0 && !(cfg->d_precision == LTG_PREC_FP8 && disc->w1t_fp8);
     for (int i = 0; i < 7; ++i) {
         const size_t sz = (size_t)(L.off[i + 1] - L.off[i]);
         flat = flat && disc->p[i + 1] == disc->p[i] + sz && disc->m[i + 1] == disc->m[i] + sz && disc->v[i + 1] == disc->v[i] + sz;
@@ -2898,7 +2900,10 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->reserved0 & 15) == 0) {
             const int ntl = I / 32;
             if (dlog16_ok(cfg, gen, B)) {   // (the producer, g_stage_bwd_dec, stored dlog as bf16 under the same predicate)
-                const int gmax = 256 - 8 * ((cfg->reserved0 >> 27) & 15);   // tuning knob bits 27-30: workgroups (CUs) left to other streams
+                // persistent workgroups: 224 = 28 per XCD (measured 657 us at 200 000 items; 256: 678, 240: 669, 192: 671) -- and 32 CUs
+                // stay free for whatever runs beside it.  Tuning-knob bits 27-30 = k: 256 - 8 k instead.
+                const int gk = (cfg->reserved0 >> 27) & 15;
+                const int gmax = gk ? 256 - 8 * gk : 224;
                 hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
                 if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
                     hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
@@ -2917,9 +2922,24 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         prs.after(LTG_K_DEC1_BWD_ADAM);
     };
+    if ((o->fake_done & G_AUX_SWEEP) && q0_lazy(cfg, gen) && mid_fast(cfg, B) && !only_dec1 && (cfg->reserved0 & (1 << 26)) == 0) {
+        // ltg_g_step, large item slab, lazy Adam clock of W_q0.  The decoder weight update (HBM-bound, the largest kernel of the
+        // step) needs only dlog and h2; everything else that is left -- dz -> dh1 -> sparse W_q0 gradient -> the other Adam
+        // updates -> the clock's step and its rotating slice -- needs only da2.  The two run side by side: the weight update on
+        // `st` with 224 of its 256 persistent workgroups (28 per XCD; measured FASTER than 256: 657 vs 678 us at 200 000 items),
+        // the chain on the aux stream on the CUs that leaves free.  (Round 1 found no overlap here: the weight update then held
+        // every CU.)  Joined by ev_sweep at the end of ltg_g_step.
+        (void)hipEventRecord(evf, st);
+        (void)hipStreamWaitEvent(aux, evf, 0);
+        if (!o->dec1_done) launch_dw();
+        ltg_g_opts oc = *o;
+        oc.fake_done &= ~G_AUX_SWEEP;   // the slice runs in the chain's own stream order, behind the clock's step
+        g_chain(cfg, gen, bt, &oc, acts, w, ad, nullptr, false, nullptr, aux, true);
+        (void)hipEventRecord((hipEvent_t)o->ev_sweep, aux);
+        return check_launch();
+    }
     if ((o->fake_done & G_AUX_SWEEP) && q0_lazy(cfg, gen)) {
-        // ltg_g_step, lazy Adam clock of W_q0: the rotating slice becomes eligible on the aux stream together with the decoder
-        // weight update (enqueued first: its 256 persistent workgroups take their CUs, the slice's waves fill what is left)
+        // (tuning-knob bit 26) only the rotating slice on the aux stream, eligible together with the decoder weight update
         (void)hipEventRecord(evf, st);
         (void)hipStreamWaitEvent(aux, evf, 0);
         if (!o->dec1_done) launch_dw();

@@ -422,11 +422,13 @@ class Engine:
                                              ws.numel(), st), "ltg_g_fake_tower")
         gopts.fake_done = 1
 
-    def g_bwd_dec1(self, batch, fake, acts, gopts):
-        """Adam on the local W_p1t / b_p1 rows: needs nothing of the dh2 exchange, so it is issued while that all-reduce flies"""
+    def g_bwd_dec1(self, batch, fake, acts, gopts, stream=None):
+        """Adam on the local W_p1t / b_p1 rows: needs nothing of the dh2 exchange, so it is issued while that all-reduce flies
+        (`stream`: a torch side stream -- the caller orders it behind ltg_g_bwd_dec and joins it before the next forward)"""
         ws = self.workspace(batch.n_rows, fake.n)
+        st = self.stream() if stream is None else stream.cuda_stream
         cabi.check(self.lib.ltg_g_bwd_dec1(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fake.c), C.byref(gopts),
-                                           C.byref(acts.c), _ptr(ws), ws.numel(), self.stream()), "ltg_g_bwd_dec1")
+                                           C.byref(acts.c), _ptr(ws), ws.numel(), st), "ltg_g_bwd_dec1")
         gopts.dec1_done = 1
 
     def g_bwd_rest(self, batch, fake, acts, gopts, dh2):

@@ -64,6 +64,8 @@ class ShardedTrainer(Trainer):
         self.fake_overlap = os.environ.get("LTGAN_FAKE_OVERLAP", "1") != "0"     # measurement switch
         self._side = torch.cuda.Stream(dev)
         self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        self.dec1_overlap = os.environ.get("LTGAN_DEC1_OVERLAP", "1") != "0"     # measurement switch
+        self._ev_dlog, self._ev_dec1 = torch.cuda.Event(), torch.cuda.Event()
         engine.workspace(B, data.max_pairs)        # sized once: the side stream must never see it reallocated
         self.cand_logit = torch.zeros(max(1, int(data.idx.cand_ptr[-1])), dtype=torch.float32, device=dev)
 
@@ -153,11 +155,24 @@ class ShardedTrainer(Trainer):
                 if go.fake_done:
                     torch.cuda.current_stream().wait_event(self._ev_join)
                 eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
-                # exchange 3 flies while the decoder weight update (which needs none of it) runs
-                work = dist.all_reduce(self.dh2[:B], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go)
-                work.wait()
-                eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
+                if self.dec1_overlap:
+                    # the decoder weight update (HBM-bound, the largest kernel; needs only dlog and h2) on the side stream with 224
+                    # of its 256 workgroups; exchange 3 and then the rest of the backward chain (which needs only the all-reduced
+                    # dh2) run beside it on the CUs that leaves free.  Joined before the next forward reads W_p1t.
+                    main = torch.cuda.current_stream()
+                    self._ev_dlog.record(main)
+                    self._side.wait_event(self._ev_dlog)
+                    eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go, stream=self._side)
+                    self._ev_dec1.record(self._side)
+                    self._allreduce(self.dh2[:B])
+                    eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
+                    main.wait_event(self._ev_dec1)
+                else:
+                    # exchange 3 flies while the decoder weight update (which needs none of it) runs
+                    work = dist.all_reduce(self.dh2[:B], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go)
+                    work.wait()
+                    eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
             self.last_anneal.append(a)
         eng.q0_defer = False
         eng.g_flush()

@@ -91,7 +91,11 @@ def main():
         err = (eng.g_p[i] - want).abs().max().item()
         assert err < atol * 50 if i not in (0, 3, 7) else err < atol * 50, ("gen tensor", i, err)
     for i in range(8):
-        assert (eng.d_p[i] - ref.d_p[i]).abs().max().item() < (2.5e-3 if wide else (2e-5 if d_split else 1e-6)), ("disc tensor", i)   # wide: lr = 1e-3 per step
+        dd = (eng.d_p[i] - ref.d_p[i]).abs()
+        if wide:     # four D steps; an element whose gradient is within rounding of zero moves by up to 3.2 lr_t per step in either direction
+            assert dd.max().item() < 2e-2 and dd.mean().item() < 1e-4, ("disc tensor", i, dd.max().item(), dd.mean().item())
+        else:
+            assert dd.max().item() < (2e-5 if d_split else 1e-6), ("disc tensor", i)
     assert eng.adam_t == ref.adam_t
     dist.barrier()
     if rank == 0:

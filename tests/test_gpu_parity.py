@@ -236,9 +236,10 @@ def test_d_step_parity(nr, nf):
         _check_adam_move(move_got, move_want, ad.m[k].reshape(-1), ad.lr_t(3), ("theta", k))
 
 
-@pytest.mark.parametrize("hs,nr,nf,cuts", [((100, 150, 250, 300), 900, 950, (0, 463, 925, 1388, 1850)), ((12, 20, 28, 16), 33, 7, (0, 1, 1, 35, 40)),
-                                           ((2048, 1024, 512, 256), 260, 250, (0, 255, 510))])
-def test_d_step_cut_at_the_gradient_exchange_equals_the_step(hs, nr, nf, cuts):
+@pytest.mark.parametrize("hs,nr,nf,cuts,dq", [((100, 150, 250, 300), 900, 950, (0, 463, 925, 1388, 1850), "fp32"), ((12, 20, 28, 16), 33, 7, (0, 1, 1, 35, 40), "fp32"),
+                                              ((2048, 1024, 512, 256), 260, 250, (0, 255, 510), "fp32"), ((2048, 1024, 512, 256), 260, 250, (0, 255, 510), "fp8"),
+                                              ((512, 256, 256, 128), 700, 650, (0, 600, 1350), "fp8")])
+def test_d_step_cut_at_the_gradient_exchange_equals_the_step(hs, nr, nf, cuts, dq):
     """ltg_d_grad over disjoint row ranges of the real | fake pair batch (what each rank of a pair-split run computes: the
     ranges straddle the real / fake boundary, one is empty), the gradient vectors summed (the all-reduce), ltg_d_apply ==
     ltg_d_step on the whole batch: same d_loss, same weights and Adam moments (up to the order of the partial sums)."""
@@ -248,7 +249,7 @@ def test_d_step_cut_at_the_gradient_exchange_equals_the_step(hs, nr, nf, cuts):
     rng = np.random.default_rng(5)
     D = O.init_discriminator(I, *hs, seed=3)
     emb, darr = Hh.disc_to_engine(D)
-    a, b = _engine(I, "fp32", hs=hs, lr=1e-3), _engine(I, "fp32", hs=hs, lr=1e-3)
+    a, b = _engine(I, "fp32", hs=hs, lr=1e-3, d_precision=dq), _engine(I, "fp32", hs=hs, lr=1e-3, d_precision=dq)
     for e in (a, b):
         e.set_discriminator(emb, darr)
         e.adam_t = 6
@@ -275,7 +276,12 @@ def test_d_step_cut_at_the_gradient_exchange_equals_the_step(hs, nr, nf, cuts):
     for i in range(8):
         for xa, xb, what in ((a.d_m[i], b.d_m[i], "m"), (a.d_v[i], b.d_v[i], "v")):
             assert Hh.rel_err(xb.cpu().numpy(), xa.cpu().numpy()) < 2e-5, (what, i)
-        assert (a.d_p[i] - b.d_p[i]).abs().max().item() < 0.02 * 1e-3, ("theta", i)     # 2 % of one Adam move
+        diff = (a.d_p[i] - b.d_p[i]).abs()
+        if dq == "fp8":
+            # quantised operands leave many gradient elements at (or within rounding of) exactly zero; there the first Adam move
+            # is lr_t * sign-like(g) and the order of the partial sums decides it: compare where the gradient is a gradient
+            diff = diff[a.d_m[i].abs() > 1e-4 * a.d_m[i].abs().max()]
+        assert diff.numel() == 0 or diff.max().item() < 0.02 * 1e-3, ("theta", i)     # 2 % of one Adam move
 
 
 # ------------------------------------------------------------------------------------------------
@@ -667,6 +673,10 @@ def test_fp8_operand_shadows_stay_in_step_with_the_master_weights():
         la = float(a.d_step(real, fake, 0.7, rng_step=5 + k)[0].item())
         lb = float(b.d_step(real, fake, 0.7, rng_step=5 + k)[0].item())
         assert abs(la - lb) < 2e-3 * abs(lb), (k, la, lb)      # fp8 pipeline: a flipped rounding moves one operand by 6 %
+    # ... and after a step cut at its gradient exchange (ltg_d_grad -> ltg_d_apply: the pair-split path of a sharded run)
+    g = torch.empty(a.d_grad_floats(), dtype=torch.float32, device=dev)
+    a.d_grad(real, fake, 0, 390, g, keep_prob=0.7, rng_step=9)
+    a.d_apply(g)
     kept = [x.clone() for x in a.d_fp8]
     cabi.check(a.lib.ltg_refresh_d_shadow(C.byref(a.cfg), C.byref(a.disc_c), a.stream()), "ltg_refresh_d_shadow")
     torch.cuda.synchronize()
