@@ -205,7 +205,7 @@ class KernelProfiler:
             if (kind == "d") != (name in self.D_KERNELS):
                 return None
             state["i"] += 1
-            if state["i"] % 32 or not self.pool:
+            if (state["i"] - 1) % 32 or not self.pool:      # the first one, then every 32nd
                 return None
             ev, p = self._probe(name)
             sh = self._shapes(b)
@@ -501,7 +501,7 @@ def main():
     if rank == 0:
         res["roofline"] = prof.roofline(dominant, calib) if dominant else None
         if res["roofline"] is None:
-            res["roofline"] = {"kernel": None, "note": "kernel probes disabled (--no-probe)"}
+            res["roofline"] = {"kernel": None, "note": "kernel probes disabled (--no-probe)" if a.no_probe else "no probed launch fell into the timed region"}
         # whole-step fraction: SURVEY 8/d4 algorithmic bytes of one step / measured step time / (8 TB/s x GPUs)
         sb = step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active)
         res["roofline"]["step_algorithmic_bytes"] = sb
