@@ -2903,7 +2903,10 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
                 // persistent workgroups: 224 = 28 per XCD (measured 657 us at 200 000 items; 256: 678, 240: 669, 192: 671) -- and 32 CUs
                 // stay free for whatever runs beside it.  Tuning-knob bits 27-30 = k: 256 - 8 k instead.
                 const int gk = (cfg->reserved0 >> 27) & 15;
-                const int gmax = gk ? 256 - 8 * gk : 224;
+                int gmax = gk ? 256 - 8 * gk : 224;
+                // ... and no more workgroups than the same number of rounds needs (782 tiles of a 25 024-item slab: 4 rounds with
+                // 224 or with 196 workgroups -- 60 CUs left to the chain and the collective running beside it)
+                if (!gk && ntl > gmax) gmax = (ntl + (ntl + gmax - 1) / gmax - 1) / ((ntl + gmax - 1) / gmax);
                 hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
                 if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
                     hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
