@@ -188,6 +188,11 @@ typedef struct ltg_fwd_opts {
     const uint8_t* drop_keep; /* optional keep flags, indexed like indices[] (drop_keep[e] belongs to indices[e]) */
     const float* eps;         /* optional [n_rows][Z] */
     const ltg_probe* probe;   /* optional */
+    /* ltg_vae_forward over SEVERAL batches at once (phase C / evaluation need no weight update in between): rows
+     * [k * rows_per_step, (k + 1) * rows_per_step) draw their dropout with counter rng_step + k and row index r - k * rows_per_step,
+     * i.e. exactly what k separate calls with consecutive rng_step values draw.  0 = one batch.  Needs is_training == 0. */
+    int32_t rows_per_step;
+    int32_t reserved0;
 } ltg_fwd_opts;
 
 /* Fake/real (popular, niche) id pairs.  Rows with id < 0 are holes (dropped pairs, Q9/Q10). */
@@ -249,6 +254,10 @@ typedef struct ltg_sample_inputs {
     const float* u_gumbel;    /* optional [n_cand total] uniforms aligned with cand_idx */
     const float* u_pick;      /* optional [n_slots] uniforms aligned with slots */
     const float* cand_logit;  /* optional, aligned with cand_idx: replaces the [B,I] logits (item-sharded runs) */
+    /* several batches in one call (see ltg_fwd_opts.rows_per_step): rows of group k = r / rows_per_step draw with counter
+     * rng_step + k and row index r % rows_per_step, and add their valid pairs to cnt_out[k].  0 = one batch. */
+    int32_t rows_per_step;
+    int32_t reserved0;
 } ltg_sample_inputs;
 
 int32_t ltg_abi_version(void);

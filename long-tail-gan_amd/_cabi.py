@@ -62,7 +62,7 @@ KERNEL_IDS = {"enc0_fwd": 1, "enc1": 2, "dec0": 3, "dec1_fwd": 4, "d_l1": 5, "d_
 
 class ltg_fwd_opts(C.Structure):
     _fields_ = [("keep_prob", C.c_float), ("is_training", C.c_float), ("rng_step", C.c_uint64), ("drop_keep", vp),
-                ("eps", vp), ("probe", C.POINTER(ltg_probe))]
+                ("eps", vp), ("probe", C.POINTER(ltg_probe)), ("rows_per_step", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ltg_pairs(C.Structure):
@@ -83,7 +83,7 @@ class ltg_g_opts(C.Structure):
 class ltg_sample_inputs(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("max_cand", C.c_int32), ("cand_ptr", vp), ("cand_idx", vp), ("pop_ptr", vp),
                 ("pop_idx", vp), ("n_sample", vp), ("slot_ptr", vp), ("valid_item", vp), ("rng_step", C.c_uint64),
-                ("u_gumbel", vp), ("u_pick", vp), ("cand_logit", vp)]
+                ("u_gumbel", vp), ("u_pick", vp), ("cand_logit", vp), ("rows_per_step", C.c_int32), ("reserved0", C.c_int32)]
 
 
 # every symbol include/ltg.h declares: name -> (restype, argtypes)

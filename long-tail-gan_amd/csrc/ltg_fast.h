@@ -155,7 +155,7 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
                                                       uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
                                                       const float* __restrict__ bq0, float* __restrict__ h1, float* __restrict__ row_scale,
                                                       const float* __restrict__ row_norm2, int item_lo, int Ig, int pre_only,
-                                                      float* __restrict__ xd) {
+                                                      float* __restrict__ xd, int rps) {
     // xd (optional, small item slabs): the dense row  xd[b][i] = keep_bi * x_bi / (keep * ||x_b||)  of the operand this
     // layer multiplies -- the backward forms dW_q0 = xd^T . da1 as a dense MFMA product with the very same dropout draw
     extern __shared__ __attribute__((aligned(16))) float s_row[];   // [I] when xd, else nothing
@@ -164,6 +164,9 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
     __shared__ float s_val[ENC_NT];
     __shared__ float red[ENC_NW];
     const int b = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // several batches in one launch (ltg_fwd_opts.rows_per_step): the RNG sees the row's own batch counter and its row there
+    const uint64_t kb = rps > 0 ? (uint64_t)(b % rps) : (uint64_t)b;
+    step += rps > 0 ? (uint64_t)(b / rps) : 0;
     const int beg = indptr[b], end = indptr[b + 1];
     float ss = 0.f;
     for (int e = beg + tid; e < end; e += ENC_NT) {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
             const int it = indices[e];
             const float v = values ? values[e] : 1.f;
             const bool kp = drop_keep ? (drop_keep[e] != 0)
-                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
+                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, kb * (uint64_t)Ig + item_lo + it, keep);
             s_idx[tid] = it;
             s_val[tid] = kp ? v : 0.f;
             if (dense) s_row[it] = kp ? v * scale : 0.f;

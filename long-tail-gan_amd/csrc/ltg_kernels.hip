@@ -74,7 +74,7 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
                                                      uint64_t step, const float* __restrict__ Wq0,
                                                      const float* __restrict__ bq0, float* __restrict__ h1,
                                                      float* __restrict__ row_scale, const float* __restrict__ row_norm2,
-                                                     int item_lo, int Ig, int pre_only) {
+                                                     int item_lo, int Ig, int pre_only, int rps) {
     // item shard: `indices` are LOCAL item ids of this rank's slab [item_lo, item_lo + I); the dropout
     // RNG is keyed by the GLOBAL id so every shard draws the mask the unsharded run draws; row_norm2
     // (sum x^2 over the FULL row) replaces the local sum; pre_only writes the partial pre-activation
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
     __shared__ float s_val[ENC_NT];
     __shared__ float red[ENC_NW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t kb = rps > 0 ? (uint64_t)(b % rps) : (uint64_t)b;   // several batches in one launch (ltg_fwd_opts.rows_per_step)
+    step += rps > 0 ? (uint64_t)(b / rps) : 0;
     const int beg = indptr[b], end = indptr[b + 1];
     float ss = 0.f;
     for (int e = beg + tid; e < end; e += ENC_NT) {
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t
             const int it = indices[e];
             const float v = values ? values[e] : 1.f;
             const bool kp = drop_keep ? (drop_keep[e] != 0)
-                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b * (uint64_t)Ig + item_lo + it, keep);
+                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, kb * (uint64_t)Ig + item_lo + it, keep);
             s_idx[tid] = it;
             s_val[tid] = kp ? v : 0.f;
         }
@@ -1920,7 +1922,7 @@ __global__ __launch_bounds__(SP_NT) void k_sample_pairs(int I, const int32_t* __
                                                         uint64_t seed, uint64_t step, const float* __restrict__ logits,
                                                         const float* __restrict__ lse, int32_t* __restrict__ gen_out,
                                                         int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out,
-                                                        const float* __restrict__ cand_logit) {
+                                                        const float* __restrict__ cand_logit, int rps) {
     // I is the GLOBAL item count (RNG index space); cand_logit (optional, aligned with cand_idx) replaces
     // the [B, I] logits matrix when the items are sharded over ranks.
     extern __shared__ __attribute__((aligned(16))) float s_key[];
@@ -1929,6 +1931,10 @@ __global__ __launch_bounds__(SP_NT) void k_sample_pairs(int I, const int32_t* __
     const int ns = n_sample[b];
     const int s0 = slot_ptr[b];
     if (ns <= 0) return;  // uniform for the whole workgroup
+    // several batches in one launch (ltg_sample_inputs.rows_per_step): the row's own batch counter, its row there, its batch's count
+    const uint64_t kb = rps > 0 ? (uint64_t)(b % rps) : (uint64_t)b;
+    step += rps > 0 ? (uint64_t)(b / rps) : 0;
+    cnt_out += rps > 0 ? b / rps : 0;
     const int c0 = cand_ptr[b], nc = cand_ptr[b + 1] - c0;
     const float l = lse[b];
     const float* row = logits + (size_t)b * I;
@@ -1949,7 +1955,7 @@ __global__ __launch_bounds__(SP_NT) void k_sample_pairs(int I, const int32_t* __
         const int it = cand_idx[c0 + j];
         const float lp = (cand_logit ? cand_logit[c0 + j] : row[it]) - l;
         const bool pos = expf(lp) > 0.f;  // softmax underflow == "zero probability" of sample.py:45
-        float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, (uint64_t)b * (uint64_t)I + it);
+        float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, kb * (uint64_t)I + it);
         u = fmaxf(u, 2.98023223876953125e-8f);  // 2^-25
         s_key[j] = pos ? lp - logf(-logf(u)) : -INFINITY;
         nnz_l += pos ? 1 : 0;
@@ -2005,7 +2011,7 @@ __global__ __launch_bounds__(SP_NT) void k_sample_pairs(int I, const int32_t* __
             const int pos = written + before + __popcll(bal & ((1ull << lane) - 1ull));
             const int s = s0 + pos;
             const int gid = cand_idx[c0 + j];
-            const float u = u_pick ? u_pick[s] : ltg_rng_uniform(seed, LTG_STREAM_POP_PICK, step, (uint64_t)b * (uint64_t)I + gid);
+            const float u = u_pick ? u_pick[s] : ltg_rng_uniform(seed, LTG_STREAM_POP_PICK, step, kb * (uint64_t)I + gid);
             const int pi = min((int)(u * (float)np), np - 1);  // np.random.choice(range(n)) train.py:236
             const int pid = pop_idx[pop_ptr[b] + pi];
             const bool ok = valid_item[gid] != 0 && valid_item[pid] != 0;  // train.py:240
@@ -2329,13 +2335,13 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
         LTG_PROBED(pr, LTG_K_ENC0_FWD,
                    hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), xd ? (size_t)I * sizeof(float) : 0, st, H, I, bt->indptr,
                                       bt->indices, bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
-                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd));
+                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd, o->rows_per_step));
         return;
     }
     LTG_PROBED(pr, LTG_K_ENC0_FWD,
                hipLaunchKernelGGL(k_enc0_fwd, dim3(R), dim3(ENC_NT), (size_t)ENC_NW * H * sizeof(float), st, H, I, bt->indptr, bt->indices,
                                   bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
-                                  acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only));
+                                  acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, o->rows_per_step));
 }
 
 // stage 2: (bias + tanh of the all-reduced pre-activation,) enc-1, reparameterisation, dec-0, dec-1 over the local slab
@@ -2515,6 +2521,7 @@ int ltg_vae_forward(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     if (!batch->indptr || !batch->indices || !acts->h1 || !acts->mulv || !acts->z || !acts->h2 || !acts->logits || !acts->lse ||
         !acts->kl_rows || !acts->row_scale)
         return LTG_EINVAL;
+    if (opts->rows_per_step < 0 || (opts->rows_per_step > 0 && (opts->is_training != 0.f || opts->drop_keep))) return LTG_EINVAL;
     return vae_forward_impl(cfg, gen, batch, opts, acts, probs_out, (hipStream_t)stream, ws, ws_bytes);
 }
 
@@ -2529,14 +2536,16 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
     if (!cfg_ok(cfg) || !in || (!logits && !in->cand_logit) || !lse || !gen_out || !pop_out || !cnt_out) return LTG_EINVAL;
     if (in->n_rows < 0 || in->max_cand < 0) return LTG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(cnt_out, 0, sizeof(int32_t), st) != hipSuccess) return LTG_ELAUNCH;
+    if (in->rows_per_step < 0) return LTG_EINVAL;
+    const int groups = in->rows_per_step > 0 ? (in->n_rows + in->rows_per_step - 1) / in->rows_per_step : 1;
+    if (hipMemsetAsync(cnt_out, 0, sizeof(int32_t) * (size_t)(groups > 0 ? groups : 1), st) != hipSuccess) return LTG_ELAUNCH;
     if (in->n_rows == 0) return LTG_OK;
     const int max_cand = in->max_cand > 0 ? in->max_cand : 1;
     const size_t lds = (size_t)max_cand * sizeof(float);
     if (lds > 64 * 1024) return LTG_EINVAL;
     hipLaunchKernelGGL(k_sample_pairs, dim3(in->n_rows), dim3(SP_NT), lds, st, Ig_of(cfg), in->cand_ptr, in->cand_idx, in->pop_ptr,
                        in->pop_idx, in->n_sample, in->slot_ptr, in->valid_item, in->u_gumbel, in->u_pick, cfg->seed, in->rng_step,
-                       logits, lse, gen_out, pop_out, cnt_out, in->cand_logit);
+                       logits, lse, gen_out, pop_out, cnt_out, in->cand_logit, in->rows_per_step);
     return check_launch();
 }
 

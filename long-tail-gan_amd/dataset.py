@@ -200,6 +200,7 @@ class DeviceData:
         cand_len = np.diff(idx.cand_ptr)
         self.max_rows = min(self.BS, N)
         self._views = [self._make_view(b, cand_len) for b in range(self.n_batches)]
+        self._spans = {}
         self.max_pairs = max(v["n_real"] + v["n_slots"] for v in self._views) if self._views else 0
 
     def _make_view(self, b, cand_len):
@@ -222,6 +223,20 @@ class DeviceData:
 
     def view(self, b):
         return self._views[b]
+
+    def span(self, b0, b1):
+        """batches [b0, b1) as ONE forward / sampler input (phase C needs no weight update between batches): the CSR rows and
+        the sampler's per-user arrays of users [b0 BS, min(N, b1 BS))"""
+        key = (b0, b1)
+        if key not in self._spans:
+            lo, hi = b0 * self.BS, min(self.N, b1 * self.BS)
+            batch = CsrRows(self.indptr, self.indices, lo, hi, values=self.values, row_norm2=self.row_norm2)
+            cl = np.diff(self.idx.cand_ptr[lo:hi + 1])
+            samp = cabi.ltg_sample_inputs(hi - lo, max(1, int(cl.max()) if hi > lo else 1), _ptr(self.cand_ptr, lo), _ptr(self.cand_idx),
+                                          _ptr(self.pop_ptr, lo), _ptr(self.pop_idx), _ptr(self.n_sample, lo), _ptr(self.slot_ptr, lo),
+                                          _ptr(self.valid_item), 0, None, None, None, self.BS, 0)
+            self._spans[key] = dict(batch=batch, samp=samp, lo=lo, hi=hi)
+        return self._spans[key]
 
 
 class EvalData:

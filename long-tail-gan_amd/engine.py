@@ -304,10 +304,11 @@ class Engine:
 
     # ------------------------------------------------------------------ the five run signatures
     def forward(self, batch, acts, keep_prob=0.75, is_training=0.0, rng_step=0, probs_out=None, drop_keep=None, eps=None,
-                probe=None):
-        """sess.run(generator_out, {input_ph: X})  -- train.py:200, :339; test.py:146."""
+                probe=None, rows_per_step=0):
+        """sess.run(generator_out, {input_ph: X})  -- train.py:200, :339; test.py:146.
+        rows_per_step > 0: `batch` spans several batches of that many rows; batch k draws its dropout with rng_step + k."""
         assert acts.rows >= batch.n_rows
-        o = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
+        o = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe), int(rows_per_step), 0)
         ws = self._fwd_scratch(batch.n_rows)
         rc = self.lib.ltg_vae_forward(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(o),
                                       C.byref(acts.c), _ptr(probs_out), _ptr(ws), ws.numel() if ws is not None else 0, self.stream())

@@ -10,6 +10,7 @@ skipped for the whole epoch (train.py:254-255); batch order is shuffled once per
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -19,10 +20,15 @@ from .dataset import DeviceData, EvalData
 from .engine import Engine
 
 
+CREATE_LOGITS_BYTES = 1 << 30      # logits of one phase-C span (rows x I x 4)
+
+
 class Trainer:
     def __init__(self, engine: Engine, data: DeviceData, num_sub_epochs=10, gan_lambda=1.0, total_anneal_steps=20000,
-                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0):
+                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None):
         self.eng, self.data = engine, data
+        if span_create is None:
+            span_create = os.environ.get("LTGAN_SPAN_CREATE", "1") != "0"    # measurement switch
         self.S = int(num_sub_epochs)
         self.lam = float(gan_lambda)
         self.total_anneal_steps, self.anneal_cap = total_anneal_steps, anneal_cap
@@ -32,6 +38,13 @@ class Trainer:
         self.np_rng = np.random.RandomState(shuffle_seed)
         self.acts = engine.new_acts(data.max_rows)
         engine.workspace(data.max_rows, data.max_pairs)
+        # phase C over spans of batches: as many as fit CREATE_LOGITS_BYTES of logits (1 = batch by batch)
+        self.span_batches = 1
+        # (measured, 64 batches: 1 000 items 5.5 -> 1.1 ms, 20 000 items 5.1 -> 2.6 ms; 200 000 items 8.7 -> 16.8 ms -- there the
+        # streaming decoder kernel of a 100-row batch beats the generic one on 1 300 rows, so large slabs stay batch by batch)
+        if span_create and not engine.sharded and data.n_batches > 1 and engine.I < 65536:
+            self.span_batches = int(max(1, min(data.n_batches, CREATE_LOGITS_BYTES // (4 * engine.I * data.BS))))
+        self.acts_c = engine.new_acts(min(data.N, self.span_batches * data.BS)) if self.span_batches > 1 else self.acts
         self.active = list(range(data.n_batches))
         self.order = np.arange(data.n_batches)
         dev = engine.device
@@ -47,12 +60,24 @@ class Trainer:
     def create_phase(self):
         d, eng = self.data, self.eng
         d.fake_cnt.zero_()
-        for b in range(d.n_batches):
-            v = d.view(b)
-            st = self._step()
-            eng.forward(v["batch"], self.acts, keep_prob=self.vae_keep, is_training=0.0, rng_step=st)
-            v["samp"].rng_step = st
-            eng.sample_pairs(v["samp"], self.acts, d.fake_gen, d.fake_pop, d.fake_cnt[b:])
+        if self.span_batches > 1:
+            # no weight moves in this phase, so consecutive batches go through ONE forward and ONE sampler launch; every batch
+            # keeps its own RNG counter and local row numbers (ltg_fwd_opts.rows_per_step): the same draws as batch by batch
+            for b0 in range(0, d.n_batches, self.span_batches):
+                b1 = min(d.n_batches, b0 + self.span_batches)
+                v = d.span(b0, b1)
+                st = self._step()
+                self.rng_step += b1 - b0 - 1                         # batch b0 + k: counter st + k
+                eng.forward(v["batch"], self.acts_c, keep_prob=self.vae_keep, is_training=0.0, rng_step=st, rows_per_step=d.BS)
+                v["samp"].rng_step = st
+                eng.sample_pairs(v["samp"], self.acts_c, d.fake_gen, d.fake_pop, d.fake_cnt[b0:])
+        else:
+            for b in range(d.n_batches):
+                v = d.view(b)
+                st = self._step()
+                eng.forward(v["batch"], self.acts, keep_prob=self.vae_keep, is_training=0.0, rng_step=st)
+                v["samp"].rng_step = st
+                eng.sample_pairs(v["samp"], self.acts, d.fake_gen, d.fake_pop, d.fake_cnt[b:])
         cnt = d.fake_cnt.cpu().numpy()               # the only host sync of the phase
         self.active = [b for b in range(d.n_batches) if cnt[b] > 0]      # train.py:254-255
         self.order = np.arange(len(self.active))

@@ -31,11 +31,11 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_config) == 80 and cabi.ltg_config.seed.offset == 72
     assert C.sizeof(cabi.ltg_gen_state) == 28 * 8 and cabi.ltg_gen_state.q0_ord.offset == 27 * 8 and C.sizeof(cabi.ltg_disc_state) == 29 * 8 and cabi.ltg_disc_state.emb_fp8.offset == 25 * 8
     assert C.sizeof(cabi.ltg_batch) == 8 + 8 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
-    assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8
+    assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8 + 8 and cabi.ltg_fwd_opts.rows_per_step.offset == 40
     assert C.sizeof(cabi.ltg_pairs) == 8 + 3 * 8
     assert C.sizeof(cabi.ltg_d_opts) == 8 + 8 + 7 * 8
     assert C.sizeof(cabi.ltg_g_opts) == C.sizeof(cabi.ltg_fwd_opts) + 16 + 8 + 8 * 8 + 16 and cabi.ltg_g_opts.dec1_done.offset == C.sizeof(cabi.ltg_g_opts) - 16
-    assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8
+    assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8 + 8
     assert C.sizeof(cabi.ltg_probe) == 8 + 16
 
 
