@@ -58,15 +58,16 @@ class ShardedTrainer(Trainer):
         self.d_split = (self.d_params >= D_SPLIT_MIN_PARAMS) if d_split is None else bool(d_split)
         self.d_grad = torch.zeros(engine.d_grad_floats(), dtype=torch.float32, device=dev)
         B = data.max_rows
-        self.rowpart = torch.zeros(B * 5, dtype=torch.float32, device=dev)
-        self.rowpart_all = torch.zeros(self.R * B * 5, dtype=torch.float32, device=dev)
+        Bc = max(B, self.acts_c.rows)                  # rows of a phase-C span of batches
+        self.rowpart = torch.zeros(Bc * 5, dtype=torch.float32, device=dev)
+        self.rowpart_all = torch.zeros(self.R * Bc * 5, dtype=torch.float32, device=dev)
         self.dh2 = torch.zeros(B, engine.H, dtype=torch.float32, device=dev)
         self.fake_overlap = os.environ.get("LTGAN_FAKE_OVERLAP", "1") != "0"     # measurement switch
         self._side = torch.cuda.Stream(dev)
         self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self.dec1_overlap = os.environ.get("LTGAN_DEC1_OVERLAP", "1") != "0"     # measurement switch
         self._ev_dlog, self._ev_dec1 = torch.cuda.Event(), torch.cuda.Event()
-        engine.workspace(B, data.max_pairs)        # sized once: the side stream must never see it reallocated
+        engine.workspace(Bc, data.max_pairs)       # sized once: the side stream must never see it reallocated
         self.cand_logit = torch.zeros(max(1, int(data.idx.cand_ptr[-1])), dtype=torch.float32, device=dev)
 
     # -- collectives -------------------------------------------------------------------------------
@@ -85,29 +86,37 @@ class ShardedTrainer(Trainer):
         return out
 
     # -- forward over the shards ---------------------------------------------------------------------
-    def _forward(self, v, fake, fopts):
+    def _forward(self, v, fake, fopts, acts=None):
+        acts = self.acts if acts is None else acts
         eng, B = self.eng, v["batch"].n_rows
-        eng.g_fwd_enc(v["batch"], self.acts, fopts)
-        self._allreduce(self.acts.h1[:B])
-        eng.g_fwd_rest(v["batch"], fake, self.acts, fopts, self.rowpart)
+        eng.g_fwd_enc(v["batch"], acts, fopts)
+        self._allreduce(acts.h1[:B])
+        eng.g_fwd_rest(v["batch"], fake, acts, fopts, self.rowpart)
         return self._allgather_rowpart(B)
 
     def create_phase(self):
         d, eng = self.data, self.eng
         d.fake_cnt.zero_()
-        for b in range(d.n_batches):
-            v = d.view(b)
+        # spans of batches (Trainer.create_phase): three collectives per SPAN instead of per batch
+        nb = self.span_batches
+        for b0 in range(0, d.n_batches, nb):
+            b1 = min(d.n_batches, b0 + nb)
+            v = d.span(b0, b1) if nb > 1 else d.view(b0)
+            acts = self.acts_c if nb > 1 else self.acts
             st = self._step()
+            self.rng_step += b1 - b0 - 1
             B = v["batch"].n_rows
-            rp_all = self._forward(v, None, eng.fwd_opts(self.vae_keep, 0.0, st))
-            eng.rowstats_combine(rp_all, self.R, B, self.acts.lse)
+            fo = eng.fwd_opts(self.vae_keep, 0.0, st)
+            fo.rows_per_step = d.BS if nb > 1 else 0
+            rp_all = self._forward(v, None, fo, acts)
+            eng.rowstats_combine(rp_all, self.R, B, acts.lse)
             c0, c1 = int(d.idx.cand_ptr[v["lo"]]), int(d.idx.cand_ptr[v["hi"]])
-            eng.gather_cand_logits(v["samp"], self.acts, self.cand_logit)
+            eng.gather_cand_logits(v["samp"], acts, self.cand_logit)
             if c1 > c0:
                 self._allreduce(self.cand_logit[c0:c1])
             v["samp"].rng_step = st
             v["samp"].cand_logit = _ptr(self.cand_logit)
-            eng.sample_pairs(v["samp"], self.acts, d.fake_gen, d.fake_pop, d.fake_cnt[b:])
+            eng.sample_pairs(v["samp"], acts, d.fake_gen, d.fake_pop, d.fake_cnt[b0:])
         cnt = d.fake_cnt.cpu().numpy()
         self.active = [b for b in range(d.n_batches) if cnt[b] > 0]
         self.order = np.arange(len(self.active))

@@ -42,7 +42,7 @@ class Trainer:
         self.span_batches = 1
         # (measured, 64 batches: 1 000 items 5.5 -> 1.1 ms, 20 000 items 5.1 -> 2.6 ms; 200 000 items 8.7 -> 16.8 ms -- there the
         # streaming decoder kernel of a 100-row batch beats the generic one on 1 300 rows, so large slabs stay batch by batch)
-        if span_create and not engine.sharded and data.n_batches > 1 and engine.I < 65536:
+        if span_create and data.n_batches > 1 and engine.I < 65536:
             self.span_batches = int(max(1, min(data.n_batches, CREATE_LOGITS_BYTES // (4 * engine.I * data.BS))))
         self.acts_c = engine.new_acts(min(data.N, self.span_batches * data.BS)) if self.span_batches > 1 else self.acts
         self.active = list(range(data.n_batches))
