@@ -2902,6 +2902,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
     }
     if (have_aux) release_aux();  // dlog, h2, da2 and the dh2 products with the old W_p1t are all enqueued
+    int dw_gmax = 224;   // persistent workgroups of the streaming decoder weight update (see launch_dw)
     auto launch_dw = [&]() {
         const Probe prs{o->probe, s_dw};
         prs.before(LTG_K_DEC1_BWD_ADAM);
@@ -2912,7 +2913,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
                 // persistent workgroups: 224 = 28 per XCD (measured 657 us at 200 000 items; 256: 678, 240: 669, 192: 671) -- and 32 CUs
                 // stay free for whatever runs beside it.  Tuning-knob bits 27-30 = k: 256 - 8 k instead.
                 const int gk = (cfg->reserved0 >> 27) & 15;
-                int gmax = gk ? 256 - 8 * gk : 224;
+                int gmax = gk ? 256 - 8 * gk : dw_gmax;
                 // ... and no more workgroups than the same number of rounds needs (782 tiles of a 25 024-item slab: 4 rounds with
                 // 224 or with 196 workgroups -- 60 CUs left to the chain and the collective running beside it)
                 if (!gk && ntl > gmax) gmax = (ntl + (ntl + gmax - 1) / gmax - 1) / ((ntl + gmax - 1) / gmax);
@@ -2943,6 +2944,10 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         // every CU.)  Joined by ev_sweep at the end of ltg_g_step.
         (void)hipEventRecord(evf, st);
         (void)hipStreamWaitEvent(aux, evf, 0);
+        // 64 CUs to the chain when the update has many rounds anyway: with Adam moments in every row of W_q0 the clock's deferred
+        // arithmetic makes the chain the longer side on 32 CUs (same box, 200 000 items, warm moments: 224 -> 673 ms per 640
+        // steps, 208 -> 666, 192 -> 647, 176 -> 650, 160 -> 659; cold moments 629 vs 632)
+        if (I / 32 >= 2048) dw_gmax = 192;
         if (!o->dec1_done) launch_dw();
         ltg_g_opts oc = *o;
         oc.fake_done &= ~G_AUX_SWEEP;   // the slice runs in the chain's own stream order, behind the clock's step
