@@ -298,14 +298,33 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
                                                       const int32_t* __restrict__ indices, const float* __restrict__ values,
                                                       const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
                                                       const float* __restrict__ row_scale, const float* __restrict__ da1,
-                                                      float* __restrict__ G, int item_lo, int Ig) {
+                                                      float* __restrict__ G, int item_lo, int Ig, ltg_gen_state st, AdamC ad, int lazy_ord) {
+    // lazy_ord > 0 (lazy Adam clock of W_q0, step `lazy_ord`): an item's gradient row is not stored -- the Adam step is applied to
+    // its row of W_q0 / m / v right here (q0_touch brought every row of the batch to lazy_ord - 1 before the forward), the
+    // workgroup of column block 0 moves the row's clock.  The partial bias rows still go to G (fk_g_tail sums them).
     __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][64];
+    auto finish_row = [&](int u, float4 g) {
+        if (lazy_ord > 0 && u < nu) {
+            const int i = indices[csr_pos[uptr[u]]];
+            const size_t off = (size_t)i * (H >> 2) + min(64 * (int)blockIdx.x + (int)(threadIdx.x & 63), (H >> 2) - 1);
+            float4 p = reinterpret_cast<float4*>(st.p[0])[off], mm = reinterpret_cast<float4*>(st.m[0])[off], vv = reinterpret_cast<float4*>(st.v[0])[off];
+            adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
+            adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
+            adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
+            adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
+            reinterpret_cast<float4*>(st.p[0])[off] = p;
+            reinterpret_cast<float4*>(st.m[0])[off] = mm;
+            reinterpret_cast<float4*>(st.v[0])[off] = vv;
+            if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) st.q0_last[i] = lazy_ord;
+        } else {
+            reinterpret_cast<float4*>(G)[(size_t)u * (H >> 2) + min(64 * (int)blockIdx.x + (int)(threadIdx.x & 63), (H >> 2) - 1)] = g;
+        }
+    };
     const int cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H4 = H >> 2, nrows = nu + ENC0_BIAS_PARTS;
     const int c4 = min(64 * cb + lane, H4 - 1);
     const bool cok = 64 * cb + lane < H4;
     const float4* d4 = reinterpret_cast<const float4*>(da1);
-    float4* G4 = reinterpret_cast<float4*>(G);
     const int per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
     // entry ranges of the group's eight rows (every wave computes all eight: the heavy / light split must be uniform)
     int q0[G0_NW], q1[G0_NW];
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
         if (j == w && u < nrows && q1[j] - q0[j] <= G0_LIGHT) {
             const float4 acc = enc0_grad_entries(q0[j], q1[j], 1, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step,
                                                  row_scale, d4, item_lo, Ig);
-            if (cok) G4[(size_t)u * H4 + c4] = acc;
+            if (cok) finish_row(u, acc);
         }
     }
     // heavy rows: all eight waves, one row after the other
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
                     const float4 p = s_g[i][lane];
                     t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
                 }
-                G4[(size_t)u * H4 + c4] = t;
+                finish_row(u, t);
             }
         }
     }
@@ -927,6 +946,7 @@ struct TailArgs {
     const float *dlog, *h2, *z, *da2, *h1, *dmlv, *G;
     const float *xd, *da1;        // xd != NULL: job 4 = the dense product xd^T . da1 + Adam (no sparse rows, no slot map)
     const int32_t* slot;
+    int q0_bias;                  // job 4 = only the bias row of the first encoder layer (lazy Adam clock: the item rows were updated by fk_enc0_grad)
     const float* rowout;
     const int32_t* cnt;
     float anneal, lam;
@@ -974,6 +994,31 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         const int tn = (H + 31) / 32;
         const WgTensors T{st.p[0], st.m[0], st.v[0], st.p[4], st.m[4], st.v[4]};
         wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        return;
+    }
+    if (bid < a.n4 && a.q0_bias) {   // b_q0 from the partial bias rows of fk_enc0_grad + this step's learning rate into the clock's ring
+        const int H4 = H >> 2;
+        if (threadIdx.x == 0) st.q0_lr_hist[(st.q0_ord + 1) & (LTG_Q0_HIST - 1)] = ad.lr_t;
+        float4* b4 = reinterpret_cast<float4*>(st.p[4]);
+        float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
+        float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
+        const float4* G4 = reinterpret_cast<const float4*>(a.G);
+        for (int c = threadIdx.x; c < H4; c += NT) {
+            float4 g = G4[(size_t)a.nu * H4 + c];
+#pragma unroll
+            for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
+                const float4 t = G4[(size_t)(a.nu + j) * H4 + c];
+                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            }
+            float4 p = b4[c], mm = mb4[c], vv = vb4[c];
+            adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
+            adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
+            adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
+            adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
+            b4[c] = p;
+            mb4[c] = mm;
+            vb4[c] = vv;
+        }
         return;
     }
     if (bid < a.n4) {

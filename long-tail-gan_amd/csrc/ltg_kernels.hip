@@ -2766,14 +2766,14 @@ static const int32_t* g_slot_map(const ltg_config* cfg, const ltg_batch* bt, con
 
 // sparse gradient rows of W_q0 (+ partial bias rows) into w.gq0
 static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts, const Workspace& w,
-                        hipStream_t st) {
+                        hipStream_t st, const ltg_gen_state* gen = nullptr, const AdamC* ad = nullptr) {   // gen + ad: fused lazy Adam step
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique;
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_GRAD);
     if (fast_on(cfg))
         hipLaunchKernelGGL(fk_enc0_grad, dim3((H / 4 + 63) / 64, (nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW), dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos,
                            bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0,
-                           cfg->item_lo, Ig_of(cfg));
+                           cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{}, ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0);
     else
         hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), st, B, I, H, nu, bt->uptr, bt->rowidx,
                            bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
@@ -2786,7 +2786,7 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
 //   stage 1: dh1 tiles + W_p0        stage 2: W_q1, W_q0 (dense product when slot == NULL, else sweep + sparse rows), scalars
 static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st,
-                   bool no_q0 = false) {
+                   bool no_q0 = false, bool q0_bias = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     TailArgs a;
     a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
@@ -2806,11 +2806,16 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
             a.n4 = (int)gx;
         }
     }
+    a.q0_bias = 0;
+    if ((stage == 2 || all) && q0_bias) {   // lazy Adam clock: fk_enc0_grad updated the item rows, one block finishes the bias row
+        a.n4 = 1;
+        a.q0_bias = 1;
+    }
     a.n5 = ((stage == 2 || all) && with_dec1) ? 1 : 0;
     a.Wp0 = gen->p[2]; a.Wq1 = gen->p[1]; a.mulv = acts->mulv; a.eps = o->fwd.eps; a.is_training = o->fwd.is_training;
     a.seed = cfg->seed; a.step = o->fwd.rng_step; a.dmlv_out = w.dmlv; a.da1_out = w.da1;
     a.dlog = w.dlog; a.h2 = acts->h2; a.z = acts->z; a.da2 = w.da2; a.h1 = acts->h1; a.dmlv = w.dmlv; a.G = w.gq0;
-    a.xd = slot ? nullptr : w.xd;
+    a.xd = (slot || q0_bias) ? nullptr : w.xd;
     a.da1 = w.da1;
     a.slot = slot; a.rowout = w.rowout; a.cnt = o->cnt; a.anneal = o->anneal; a.lam = o->gan_lambda;
     a.loss_out = w.scal; a.loss_out2 = loss_out;
@@ -2834,9 +2839,10 @@ static void q0_slice_sweep(const ltg_config* cfg, const ltg_gen_state* gen, int 
     if (start < I) hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + P - 1) / P), dim3(Q0_NT), 0, st, I, cfg->h_enc, start, P, target, *gen, make_adam(cfg, 1));
 }
 static void q0_lazy_update(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const Workspace& w, const AdamC& ad,
-                           hipStream_t st) {
+                           hipStream_t st, bool rows_done = false) {
     const int I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique, ord = gen->q0_ord + 1;
-    hipLaunchKernelGGL(k_q0_step_touched, dim3(nu + 1), dim3(Q0_NT), 0, st, I, H, nu, bt->uptr, bt->csr_pos, bt->indices, w.gq0, ord, *gen, ad);
+    // (rows_done: fk_enc0_grad applied the step to the batch's rows and fk_g_tail to the bias row)
+    if (!rows_done) hipLaunchKernelGGL(k_q0_step_touched, dim3(nu + 1), dim3(Q0_NT), 0, st, I, H, nu, bt->uptr, bt->csr_pos, bt->indices, w.gq0, ord, *gen, ad);
     if (!(o->fake_done & G_AUX_SWEEP)) q0_slice_sweep(cfg, gen, ord, st);   // (else: ltg_g_step has the slice on its aux stream, up to ord - 1)
 }
 
@@ -2855,12 +2861,14 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-    if (slot || lazy) g_enc0_grad(cfg, bt, o, acts, w, st);
+    const bool fused = lazy && fast_on(cfg) && (cfg->reserved0 & (1 << 25)) == 0;   // Adam on the batch's rows inside the gradient kernel
+    if (fused) g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad);
+    else if (slot || lazy) g_enc0_grad(cfg, bt, o, acts, w, st);
     const bool own_sweep = (slot && cfg->n_items >= 8192) || lazy;   // HBM-bound sweep: its own launch at full occupancy (measured 490 vs
                                                                      // 525 us at 200 000 items when it rode in the 118-register job kernel)
-    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st, own_sweep);
+    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st, own_sweep, fused);
     if (lazy) {
-        LTG_PROBED(pr, LTG_K_ENC0_BWD_ADAM, q0_lazy_update(cfg, gen, bt, o, w, ad, st));
+        LTG_PROBED(pr, LTG_K_ENC0_BWD_ADAM, q0_lazy_update(cfg, gen, bt, o, w, ad, st, fused));
     } else if (own_sweep) {
         const int I = cfg->n_items;
         const size_t total = (size_t)(I + 1) * (H / 4);
