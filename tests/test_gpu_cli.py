@@ -152,3 +152,18 @@ def test_bench_two_ranks_item_sharded():
     assert d["config"]["backend"].startswith("gloo") or d["config"]["backend"].startswith("nccl")
     assert d["value"] > 0 and d["n1_same_workload"]["value"] > 0 and d["strong_scaling_vs_1gpu"] > 0
     assert d["roofline"]["kernel"] == "dec1_bwd_adam" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["step_frac"] < 1
+
+
+def test_bench_item_sharded_code_path_on_rccl_at_world_size_one():
+    """The item-sharded trainer on the RCCL backend (what an 8-GPU job runs; a one-GPU box can only host world size 1): the three
+    exchanges of a G step, the side streams (fake tower, decoder weight update), the spans of phase C and the lazy Adam clock on a
+    25 024-item slab -- the slab one rank of an 8-GPU run of the 200 000-item configuration owns."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LTGAN_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "custom:25024", "--users", "400", "--steps", "1", "--warmup", "1", "--sub-epochs", "2",
+           "--parallelism", "item-shard", "--no-cpu-baseline", "--no-other-workloads"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["backend"].startswith("nccl") and d["config"]["parallelism"].startswith("item-shard x1")
+    assert d["value"] > 0 and d["roofline"]["kernel"] == "dec1_bwd_adam"
