@@ -126,6 +126,7 @@ class Engine:
         for item slabs of 8192 items or more.  Rows are brought up to date by every forward that reads them; `g_flush()`
         does it for all rows and runs after every G step unless a trainer holds `q0_defer` for the length of its phase."""
         self.lib = cabi.load()
+        self._pinned = None                                          # pin_stream()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
         p_dims = p_dims or [200, 600, n_items]                       # generator.py:13
@@ -256,7 +257,12 @@ class Engine:
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """raw handle of the stream the library launches on: torch's current stream -- or the one a trainer pinned for the length
+        of a phase (`pin_stream`: the lookup costs a few microseconds and a sharded G step makes seven of them)"""
+        return self._pinned if self._pinned is not None else torch.cuda.current_stream(self.device).cuda_stream
+
+    def pin_stream(self, on=True):
+        self._pinned = torch.cuda.current_stream(self.device).cuda_stream if on else None
 
     def workspace(self, rows, pairs):
         rows, pairs = max(1, int(rows)), max(1, int(pairs))

@@ -142,6 +142,7 @@ class ShardedTrainer(Trainer):
         d, eng = self.data, self.eng
         self.last_anneal = []
         eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
+        eng.pin_stream()
         for j in range(self.S):
             a = self.anneal()
             for k in self.order:
@@ -185,6 +186,7 @@ class ShardedTrainer(Trainer):
             self.last_anneal.append(a)
         eng.q0_defer = False
         eng.g_flush()
+        eng.pin_stream(False)
         return self.g_losses
 
 

@@ -88,11 +88,13 @@ class Trainer:
     # ---------------------------------------------------------------- phase D (train.py:287-303)
     def d_phase(self):
         d, eng = self.data, self.eng
+        eng.pin_stream()
         for j in range(self.S):
             for k in self.order:
                 v = d.view(self.active[k])
                 pr = self.probe_hook("d", self.active[k]) if self.probe_hook else None
                 eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j], probe=pr)
+        eng.pin_stream(False)
         return self.d_losses
 
     # ---------------------------------------------------------------- phase G (train.py:307-329)
@@ -105,6 +107,7 @@ class Trainer:
         d, eng = self.data, self.eng
         self.last_anneal = []
         eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
+        eng.pin_stream()
         for j in range(self.S):
             a = self.anneal()
             for k in self.order:
@@ -119,6 +122,7 @@ class Trainer:
             self.last_anneal.append(a)
         eng.q0_defer = False
         eng.g_flush()
+        eng.pin_stream(False)
         return self.g_losses
 
     def epoch(self):
