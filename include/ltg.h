@@ -237,6 +237,9 @@ typedef struct ltg_g_opts {
     /* optional third caller-created hipEvent_t (with aux_stream): ltg_g_step then runs the rotating slice of the lazy Adam
      * clock of W_q0 (arithmetic-bound) on aux_stream, beside the HBM-bound decoder kernels, and joins it at the end */
     void* ev_sweep;
+    /* optional y_generated of this batch's fake pairs [fake->n], computed ahead by ltg_fake_tower_batched with this step's
+     * d_rng_step: the step then runs no fake tower at all */
+    const float* y_pre;
 } ltg_g_opts;
 
 /* Static per-user sampling inputs for a batch (results of the index path, data_processing.py). */
@@ -341,6 +344,16 @@ int ltg_g_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
  * after the previous step's ltg_g_bwd_dec and before this step's, and sets ltg_g_opts.fake_done = 1. */
 int ltg_g_fake_tower(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const ltg_g_opts* o, int32_t n_rows, void* ws,
                      size_t ws_bytes, ltg_stream stream);
+/* The fake tower's forward (discriminator.py:52-55 on x_popular_g / x_generated; the only part of the discriminator the g_trainer
+ * fetch needs, train.py:326) for MANY pair batches in one pass -- the discriminator does not move during phase G (train.py:307-329)
+ * and the fake pairs are fixed for the epoch, so every y_generated of a sub-epoch is known before its first G step.
+ * fake = the concatenated slots of the batches; seg_of[fake->n] = index s of the batch each slot belongs to, seg_row0[s] = first
+ * slot of batch s (the dropout RNG sees a slot's row INSIDE its batch), seg_step[s] = the d_rng_step the G step of batch s will
+ * use: the same draws, the same bits as the tower inside ltg_g_step.  y_out[fake->n] (0 for holes); the G steps take their slice
+ * through ltg_g_opts.y_pre.  ws: ltg_workspace_bytes(cfg, 1, fake->n). */
+int ltg_fake_tower_batched(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const int32_t* seg_of,
+                           const int32_t* seg_row0, const uint64_t* seg_step, float d_keep_prob, float* y_out, void* ws, size_t ws_bytes,
+                           ltg_stream stream);
 int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pairs* fake,
                    const ltg_g_opts* opts, const ltg_gen_acts* acts, void* ws, size_t ws_bytes, ltg_stream stream);
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out,

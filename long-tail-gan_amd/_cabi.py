@@ -77,7 +77,7 @@ class ltg_d_opts(C.Structure):
 class ltg_g_opts(C.Structure):
     _fields_ = [("fwd", ltg_fwd_opts), ("anneal", C.c_float), ("gan_lambda", C.c_float), ("d_keep_prob", C.c_float),
                 ("adam_t", C.c_int32), ("d_rng_step", C.c_uint64), ("drop_fake", vp * 3), ("cnt", vp), ("probe", C.POINTER(ltg_probe)),
-                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("dec1_done", C.c_int32), ("fake_done", C.c_int32), ("ev_sweep", vp)]
+                ("aux_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("dec1_done", C.c_int32), ("fake_done", C.c_int32), ("ev_sweep", vp), ("y_pre", vp)]
 
 
 class ltg_sample_inputs(C.Structure):
@@ -118,6 +118,8 @@ SYMBOLS = {
     "ltg_refresh_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
     "ltg_forward_scratch_bytes": (C.c_size_t, [C.POINTER(ltg_config), C.c_int32]),
     "ltg_g_fake_tower": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.c_int32, vp, C.c_size_t, vp]),
+    "ltg_fake_tower_batched": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), C.POINTER(ltg_pairs), vp, vp, vp, C.c_float, vp, vp,
+                                        C.c_size_t, vp]),
     "ltg_g_flush": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), vp]),
     "ltg_refresh_d_shadow": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_disc_state), vp]),
     "ltg_rank_metrics": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), C.c_int32,

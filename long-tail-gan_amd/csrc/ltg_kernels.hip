@@ -785,8 +785,16 @@ struct DropView {
     int nr;
     int row0;                    // logical pair row of local row 0 (a rank that owns rows [row0, ...) of the pair batch draws the
                                  // mask the whole batch draws: the counter RNG is indexed by the GLOBAL row)
+    // several pair batches in one pass (ltg_fake_tower_batched): row r belongs to batch seg_of[r], which starts at row seg_row0[.]
+    // and draws with counter seg_step[.]
+    const int32_t *seg_of = nullptr, *seg_row0 = nullptr;
+    const uint64_t* seg_step = nullptr;
     __device__ __forceinline__ bool keep(int r, int c, int width, uint64_t seed, uint32_t stream, uint64_t step, float kp) const {
         if (real || fake) return r < nr ? (real[(size_t)r * width + c] != 0) : (fake[(size_t)(r - nr) * width + c] != 0);
+        if (seg_of) {
+            const int sg = seg_of[r];
+            return ltg_rng_keep(seed, stream, seg_step[sg], (uint64_t)(r - seg_row0[sg]) * width + c, kp);
+        }
         return ltg_rng_keep(seed, stream, step, (uint64_t)(r + row0) * width + c, kp);
     }
 };
@@ -2470,7 +2478,9 @@ inline int d_tile(const ltg_config* cfg, int which) {
     } while (0)
 
 void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, DropView dA, DropView dB, DropView dC,
-                  float keep, uint64_t step, const Workspace& w, bool with_bwd, const ltg_probe* probe, hipStream_t st) {
+                  float keep, uint64_t step, const Workspace& w0, bool with_bwd, const ltg_probe* probe, hipStream_t st, float* y_dst = nullptr) {
+    Workspace w = w0;
+    if (y_dst) w.y = y_dst;   // y straight into the caller's buffer
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
@@ -3044,13 +3054,15 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     const int B = bt->n_rows, nf = fake->n;
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const Workspace w = carve(cfg, B, nf, (char*)ws);
+    Workspace w = carve(cfg, B, nf, (char*)ws);
+    const bool have_y = o->y_pre != nullptr;   // y_generated of this batch came from ltg_fake_tower_batched: no tower in this step
+    if (have_y) w.y = const_cast<float*>(o->y_pre);
     // lazy Adam clock of W_q0: the batch's rows up to date first; its rotating slice (rows NOT of this batch: arithmetic-bound,
     // 48 registers -- it fits beside the 2 x 232-register waves of the HBM-bound decoder kernels) then runs on the aux stream
     q0_touch(cfg, gen, bt, st);
     const bool aux_sweep = q0_lazy(cfg, gen) && o->aux_stream && o->ev_fork && o->ev_sweep && (cfg->reserved0 & 512) == 0;
     // fork: the fake tower (independent of the generator forward) runs on the caller's aux stream
-    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0 && (cfg->reserved0 & 512) == 0;
+    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0 && (cfg->reserved0 & 512) == 0 && !have_y;
     if (fork || aux_sweep) {
         hipStream_t aux = (hipStream_t)o->aux_stream;
         if (hipEventRecord((hipEvent_t)o->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)o->ev_fork, 0) != hipSuccess)
@@ -3073,7 +3085,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
         // nine launches per step: enc0, enc1, dec0, dec1 | row softmax + dlogits, dh2, dz, dh1, Adam tail (dW_q0 = xd^T . da1 dense)
         const int I = cfg->n_items, H = cfg->h_enc;
         const Probe pr{o->probe, st};
-        if (nf > 0 && !fork) {
+        if (nf > 0 && !fork && !have_y) {
             PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
             DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
             disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
@@ -3092,7 +3104,7 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     g_row_partial(cfg, bt, fake, acts, w.rowpart, st, w.segpart, nullptr, sgroups);
     if (fork && hipStreamWaitEvent(st, (hipEvent_t)o->ev_join, 0) != hipSuccess) return LTG_ELAUNCH;
     // single GPU: the slab sum writes da2 directly (one launch less than the sharded stage pair)
-    int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork, acts->h2);
+    int rc = g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, w.rowpart, 1, loss_out, w, w.da2, st, fork || have_y, acts->h2);
     if (rc != LTG_OK) return rc;
     rc = g_stage_bwd_rest(cfg, gen, bt, o, acts, w.da2, w, st, true);
     if (aux_sweep && hipStreamWaitEvent(st, (hipEvent_t)o->ev_sweep, 0) != hipSuccess) return LTG_ELAUNCH;   // join
@@ -3139,8 +3151,10 @@ int ltg_g_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_dis
     if (!g_args_ok(cfg, gen, bt, acts) || !disc || !fake || !o || !rowpart_all || n_ranks < 1 || !loss_out || !dh2_out || !ws) return LTG_EINVAL;
     if (!o->cnt || !fake->row || fake->n < 0) return LTG_EINVAL;
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
-    const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);
-    return g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, rowpart_all, n_ranks, loss_out, w, dh2_out, (hipStream_t)stream, (o->fake_done & 1) != 0);
+    Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);
+    if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
+    return g_stage_bwd_dec(cfg, gen, disc, bt, fake, o, acts, rowpart_all, n_ranks, loss_out, w, dh2_out, (hipStream_t)stream,
+                           (o->fake_done & 1) != 0 || o->y_pre != nullptr);
 }
 
 int ltg_g_fake_tower(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const ltg_g_opts* o, int32_t n_rows, void* ws,
@@ -3153,6 +3167,23 @@ int ltg_g_fake_tower(const ltg_config* cfg, const ltg_disc_state* disc, const lt
     PairView pv{0, fake->n, nullptr, nullptr, fake->pop, fake->niche};
     DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
     disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, (hipStream_t)stream);
+    return check_launch();
+}
+
+int ltg_fake_tower_batched(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const int32_t* seg_of,
+                           const int32_t* seg_row0, const uint64_t* seg_step, float d_keep_prob, float* y_out, void* ws, size_t ws_bytes,
+                           ltg_stream stream) {
+    clear_errors();
+    if (!cfg_ok(cfg) || !disc || !fake || !seg_of || !seg_row0 || !seg_step || !y_out || !ws || fake->n < 0 || !fake->pop || !fake->niche) return LTG_EINVAL;
+    if (fake->n == 0) return LTG_OK;
+    if (ltg_workspace_bytes(cfg, 1, fake->n) > ws_bytes) return LTG_EWORKSPACE;
+    const Workspace w = carve(cfg, 1, fake->n, (char*)ws);
+    PairView pv{0, fake->n, nullptr, nullptr, fake->pop, fake->niche};
+    DropView dv{nullptr, nullptr, 0, 0};
+    dv.seg_of = seg_of;
+    dv.seg_row0 = seg_row0;
+    dv.seg_step = seg_step;
+    disc_forward(cfg, disc, pv, dv, dv, dv, d_keep_prob, 0, w, false, nullptr, (hipStream_t)stream, y_out);
     return check_launch();
 }
 

@@ -201,6 +201,7 @@ class DeviceData:
         self.max_rows = min(self.BS, N)
         self._views = [self._make_view(b, cand_len) for b in range(self.n_batches)]
         self._spans = {}
+        self._towers = None
         self.max_pairs = max(v["n_real"] + v["n_slots"] for v in self._views) if self._views else 0
 
     def _make_view(self, b, cand_len):
@@ -223,6 +224,27 @@ class DeviceData:
 
     def view(self, b):
         return self._views[b]
+
+    def tower_chunks(self, max_pairs):
+        """the epoch's fake-pair slots cut at batch boundaries into runs of at most max_pairs slots (a single batch may exceed it):
+        inputs of Engine.fake_tower_batched -- (Pairs over the run, seg_of = batch of each slot, seg_row0 = first slot of every
+        batch RELATIVE to the run, first slot of the run)"""
+        if self._towers is None:
+            slot0 = np.array([v["slot0"] for v in self._views] + [self.n_slots], np.int64)
+            seg_of = np.repeat(np.arange(self.n_batches, dtype=np.int32), np.diff(slot0))
+            self._seg_of = torch.from_numpy(seg_of if len(seg_of) else np.zeros(1, np.int32)).to(self.device)
+            out, b0 = [], 0
+            while b0 < self.n_batches:
+                b1 = b0 + 1
+                while b1 < self.n_batches and slot0[b1 + 1] - slot0[b0] <= max_pairs:
+                    b1 += 1
+                s0, s1 = int(slot0[b0]), int(slot0[b1])
+                if s1 > s0:
+                    row0 = torch.from_numpy((slot0[:-1] - s0).astype(np.int32)).to(self.device)
+                    out.append(dict(fake=Pairs(self.fake_pop, self.fake_gen, None, n=s1 - s0, off=s0), seg_of=self._seg_of, seg_off=s0, seg_row0=row0, s0=s0))
+                b0 = b1
+            self._towers = out
+        return self._towers
 
     def span(self, b0, b1):
         """batches [b0, b1) as ONE forward / sampler input (phase C needs no weight update between batches): the CSR rows and

@@ -359,15 +359,24 @@ class Engine:
         cabi.check(rc, "ltg_d_apply")
         return loss_out
 
+    def fake_tower_batched(self, fake, seg_of, seg_row0, seg_step, y_out, d_keep_prob=0.7, seg_off=0, y_off=0):
+        """y_generated of MANY pair batches in one pass (the discriminator is fixed during phase G): `fake` = the concatenated
+        slots, seg_of (+ seg_off) / seg_row0 / seg_step as in include/ltg.h; the G steps then take their slice through `y_pre`."""
+        ws = self.workspace(1, fake.n)
+        cabi.check(self.lib.ltg_fake_tower_batched(C.byref(self.cfg), C.byref(self.disc_c), C.byref(fake.c), _ptr(seg_of, seg_off), _ptr(seg_row0),
+                                                   _ptr(seg_step), d_keep_prob, _ptr(y_out, y_off), _ptr(ws), ws.numel(), self.stream()),
+                   "ltg_fake_tower_batched")
+
     def g_step(self, batch, fake, acts, cnt, anneal, gan_lambda=1.0, keep_prob=0.75, is_training=1.0, d_keep_prob=0.7,
-               rng_step=0, d_rng_step=0, loss_out=None, drop_keep=None, eps=None, drop_fake=None, probe=None):
-        """sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss], ...)  -- train.py:326."""
+               rng_step=0, d_rng_step=0, loss_out=None, drop_keep=None, eps=None, drop_fake=None, probe=None, y_pre=None, y_off=0):
+        """sess.run([g_trainer, g_loss_mean, g_vae_loss, gan_loss], ...)  -- train.py:326.
+        y_pre (+ y_off): y_generated of this batch's fake pairs from fake_tower_batched (same d_rng_step): no tower in the step."""
         loss_out = self.loss_buf if loss_out is None else loss_out
         ws = self.workspace(batch.n_rows, fake.n)
         f = cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
         o = cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
-                            *self._fork_handles(), 0, 0, self._sweep_event())
+                            *self._fork_handles(), 0, 0, self._sweep_event(), _ptr(y_pre, y_off))
         rc = self.lib.ltg_g_step(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c),
                                  C.byref(fake.c), C.byref(o), C.byref(acts.c), _ptr(loss_out), _ptr(ws), ws.numel(),
                                  self.stream())
@@ -394,11 +403,11 @@ class Engine:
         return cabi.ltg_fwd_opts(keep_prob, is_training, rng_step, _ptr(drop_keep), _ptr(eps), _pp(probe))
 
     def g_opts(self, cnt, anneal, gan_lambda=1.0, keep_prob=0.75, is_training=1.0, d_keep_prob=0.7, rng_step=0, d_rng_step=0,
-               drop_keep=None, eps=None, drop_fake=None, probe=None):
+               drop_keep=None, eps=None, drop_fake=None, probe=None, y_pre=None, y_off=0):
         f = self.fwd_opts(keep_prob, is_training, rng_step, drop_keep, eps, probe)
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
         return cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
-                               *self._fork_handles())      # ltg_g_bwd_rest forks / joins inside the call
+                               *self._fork_handles(), 0, 0, None, _ptr(y_pre, y_off))      # ltg_g_bwd_rest forks / joins inside the call
 
     def g_fwd_enc(self, batch, acts, fopts):
         cabi.check(self.lib.ltg_g_fwd_enc(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fopts), C.byref(acts.c),

@@ -143,6 +143,7 @@ class ShardedTrainer(Trainer):
         self.last_anneal = []
         eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
         eng.pin_stream()
+        self._tower_ahead()        # every fake tower of the phase in a few large launches (replicated on every rank)
         for j in range(self.S):
             a = self.anneal()
             for k in self.order:
@@ -152,8 +153,9 @@ class ShardedTrainer(Trainer):
                 self.update_count += 1
                 B = v["batch"].n_rows
                 pr = self.probe_hook("g", b) if self.probe_hook else None
-                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step(), probe=pr)
-                if self.fake_overlap and v["fake"].n > 0:
+                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step(), probe=pr,
+                                y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
+                if self.fake_overlap and v["fake"].n > 0 and not self.batched_tower:
                     # the fake tower (replicated, needs nothing of the generator) on a side stream, beside the forward and its
                     # two exchanges; ordered after the previous step's reader of its outputs, joined before this step's
                     main = torch.cuda.current_stream()

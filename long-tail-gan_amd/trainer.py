@@ -21,11 +21,12 @@ from .engine import Engine
 
 
 CREATE_LOGITS_BYTES = 1 << 30      # logits of one phase-C span (rows x I x 4)
+TOWER_PAIRS = 1 << 17              # fake pairs per launch of the batched fake tower (activations: pairs x (h1 + h2 + 2 h3) x 4 bytes)
 
 
 class Trainer:
     def __init__(self, engine: Engine, data: DeviceData, num_sub_epochs=10, gan_lambda=1.0, total_anneal_steps=20000,
-                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None):
+                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None, batched_tower=None):
         self.eng, self.data = engine, data
         if span_create is None:
             span_create = os.environ.get("LTGAN_SPAN_CREATE", "1") != "0"    # measurement switch
@@ -45,6 +46,15 @@ class Trainer:
         if span_create and data.n_batches > 1 and engine.I < 65536:
             self.span_batches = int(max(1, min(data.n_batches, CREATE_LOGITS_BYTES // (4 * engine.I * data.BS))))
         self.acts_c = engine.new_acts(min(data.N, self.span_batches * data.BS)) if self.span_batches > 1 else self.acts
+        # phase G: the discriminator is fixed, so the fake tower of every G step of a sub-epoch is evaluated ahead in a few large
+        # launches (Engine.fake_tower_batched) instead of three small ones inside every step
+        self.batched_tower = os.environ.get("LTGAN_BATCHED_TOWER", "1") != "0" if batched_tower is None else bool(batched_tower)
+        self.batched_tower = self.batched_tower and data.n_slots > 0
+        if self.batched_tower:
+            self.y_all = torch.zeros(self.S * data.n_slots, dtype=torch.float32, device=engine.device)       # [sub-epoch][slot]
+            self._seg_step = torch.zeros(self.S, data.n_batches, dtype=torch.int64, device=engine.device)
+            self._towers = data.tower_chunks(TOWER_PAIRS)
+            engine.workspace(data.max_rows, max(data.max_pairs, max(t["fake"].n for t in self._towers)))
         self.active = list(range(data.n_batches))
         self.order = np.arange(data.n_batches)
         dev = engine.device
@@ -103,11 +113,28 @@ class Trainer:
             return min(self.anneal_cap, 1.0 * self.update_count / self.total_anneal_steps)
         return self.anneal_cap
 
+    def _tower_ahead(self):
+        """y_generated of every G step of the coming phase.  The k-th step of sub-epoch j will draw the tower's dropout with the
+        counter rng_step + 2 (j n_active + k) + 2 (every step takes two counters: generator, then tower)."""
+        if not self.batched_tower:
+            return
+        nb, na = self.data.n_batches, len(self.order)
+        steps = np.zeros((self.S, nb), np.int64)
+        for j in range(self.S):
+            for k, pos in enumerate(self.order):
+                steps[j, self.active[pos]] = self.rng_step + 2 * (j * na + k) + 2
+        self._seg_step.copy_(torch.from_numpy(steps))          # the one host -> device copy of the phase
+        for j in range(self.S):
+            for t in self._towers:
+                self.eng.fake_tower_batched(t["fake"], t["seg_of"], t["seg_row0"], self._seg_step[j], self.y_all, self.d_keep,
+                                            seg_off=t["seg_off"], y_off=j * self.data.n_slots + t["s0"])
+
     def g_phase(self):
         d, eng = self.data, self.eng
         self.last_anneal = []
         eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
         eng.pin_stream()
+        self._tower_ahead()
         for j in range(self.S):
             a = self.anneal()
             for k in self.order:
@@ -118,7 +145,8 @@ class Trainer:
                 eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
                            keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=self._step(),
                            d_rng_step=self._step(), loss_out=self.g_losses[j],
-                           probe=self.probe_hook("g", b) if self.probe_hook else None)
+                           probe=self.probe_hook("g", b) if self.probe_hook else None,
+                           y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
             self.last_anneal.append(a)
         eng.q0_defer = False
         eng.g_flush()
