@@ -193,7 +193,9 @@ class KernelProfiler:
                 continue
             fl = np.mean([self.work(name, sh)[0] for _, sh, _ in evs])
             by = np.mean([self.work(name, sh)[1] for _, sh, _ in evs])
-            launches = S * nb * (2 if name in ("d_l1", "d_l2") else 1) + (nb if name in ("enc0_fwd", "enc1", "dec0", "dec1_fwd") else 0)
+            # (the fake tower of the G steps: inside every step, or -- Trainer.batched_tower -- a few large launches per phase)
+            tower = 1 if getattr(self.tr, "batched_tower", False) else 2
+            launches = S * nb * (tower if name in ("d_l1", "d_l2") else 1) + (nb if name in ("enc0_fwd", "enc1", "dec0", "dec1_fwd") else 0)
             out[name] = dict(avg_ms=float(np.mean(ms)), flops=float(fl), bytes=float(by), epoch_ms=float(np.mean(ms)) * launches)
         return out
 
