@@ -59,3 +59,33 @@ def test_two_epoch_trajectory_matches_oracle(tmp_path):
     np.testing.assert_allclose(eng.g_p[7].cpu().numpy()[:64], gold["final_bp1_head"], atol=2e-5)
     # 404 Adam steps of lr 1e-4 travel up to 4e-2; fp32-vs-fp64 drift through the sign-like Adam normalisation stays ~1% of that
     np.testing.assert_allclose(eng.d_p[6].cpu().numpy()[:64], gold["final_w4_head"], atol=5e-4)
+
+
+@pytest.mark.parametrize("workload,users", [("custom:1000", 450), ("custom:8264", 230)])
+def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, users):
+    """Two reorderings of work that no weight update separates: phase C over spans of batches (one forward + one sampler launch,
+    every batch with its own RNG counter and row numbers) and every fake tower of phase G evaluated ahead (the discriminator is
+    fixed during the phase; ltg_fake_tower_batched + ltg_g_opts.y_pre).  Two epochs with both against two epochs batch by batch
+    and tower-in-step: identical fake pairs, losses and parameters, bit for bit (small item slab: nine-launch G step; 8 264
+    items: streaming decoder path + lazy Adam clock)."""
+    import torch
+    from ltgan.dataset import DeviceData
+    from ltgan.engine import Engine
+    from ltgan.synthetic import synthetic_index
+    from ltgan.trainer import Trainer
+    idx, _ = synthetic_index(workload, users=users, seed=9)
+    runs = []
+    for hoist in (False, True):
+        eng = Engine(idx.n_items, h_sizes=(20, 24, 40, 36), lr=1e-3, seed=5, d_seed=2)
+        tr = Trainer(eng, DeviceData(idx, 100, eng.device), num_sub_epochs=2, shuffle_seed=3, span_create=hoist, batched_tower=hoist)
+        assert tr.batched_tower == hoist and (tr.span_batches > 1) == hoist
+        out = []
+        for _ in range(2):
+            tr.create_phase()
+            out += [tr.data.fake_gen.clone(), tr.data.fake_pop.clone(), tr.data.fake_cnt.clone()]
+            out.append(tr.d_phase().clone())
+            out.append(tr.g_phase().clone())
+        torch.cuda.synchronize()
+        runs.append([x.cpu() for x in out + eng.g_p + eng.d_p + eng.g_m])
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert torch.equal(a, b), k
