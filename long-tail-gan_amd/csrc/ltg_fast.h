@@ -1233,6 +1233,151 @@ __global__ __launch_bounds__(NT) void fk8_d_l2(int n, int h12, int h3, const uin
     ltg_rgemm8(n, h3, h12, m0, n0, a_ld, a_mask, b_ld, 1.f / (float)(1 << (FP8_S_ACT + FP8_S_W)), epi);
 }
 
+// ---- LDS-staged e4m3 block for the wide sizes.  The register-resident block above lets every wave fetch its own 32 operand
+// rows: a 64 x 64 workgroup tile pulls each operand byte through the L1 twice and 696 such tiles move 356 MB from the L2s per
+// branch-layer launch (7.4 TB/s at 48 us: L2-bandwidth-bound).  Here a workgroup owns BM x BN outputs, stages 128 bytes of K
+// of both operands in LDS (16-byte global loads in flight under the MFMAs of the block before) and every wave multiplies its
+// (BM / 2) x (BN / 2) quarter from there: 64 x 64 tiles move 178 MB for the same product (each operand byte once per workgroup),
+// and three or four 37-KB workgroups per CU hide each other's load latency.  K % 128 == 0.
+//   a_row(r) / b_row(c): start of operand row r / column c of the tile (k-contiguous e4m3), nullptr = all zero.
+template <int BM, int BN, class ARow, class BRow, class EF>
+__device__ __forceinline__ void ltg_sgemm8(int K, ARow a_row, BRow b_row, float scale, EF epi, uint8_t* __restrict__ lds) {
+    constexpr int BK = 128, LDK = BK + 16, TM = BM / 32, TN = BN / 32, RA = BM / 32, RB = BN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
+    const int lrow = tid >> 3, lkc = (tid & 7) * 16;        // loader: rows lrow + 32 j, byte column lkc of the K block
+    const uint8_t* ap[RA];
+    const uint8_t* bp[RB];
+    unsigned am[RA], bm[RB];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const uint8_t* q = a_row(lrow + 32 * j);
+        am[j] = q ? 0xFFFFFFFFu : 0u;
+        ap[j] = (q ? q : a_row(-1)) + lkc;     // a_row(-1): any valid address (masked to zero)
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const uint8_t* q = b_row(lrow + 32 * j);
+        bm[j] = q ? 0xFFFFFFFFu : 0u;
+        bp[j] = (q ? q : b_row(-1)) + lkc;
+    }
+    uint8_t* As = lds;                       // [2][BM][LDK]
+    uint8_t* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+    ltg_f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    ltg_u32x4 ra[RA], rb[RB];
+    // (macros, not lambdas: register arrays captured by reference end up in scratch)
+#define SG8_FETCH(k0)                                                                                      \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const ltg_u32x4*>(ap[j] + (k0)); \
+        _Pragma("unroll") for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const ltg_u32x4*>(bp[j] + (k0)); \
+    }
+#define SG8_STASH(buf)                                                                                     \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                                   \
+            ltg_u32x4 v = ra[j];                                                                           \
+            v[0] &= am[j]; v[1] &= am[j]; v[2] &= am[j]; v[3] &= am[j];                                    \
+            *reinterpret_cast<ltg_u32x4*>(As + (size_t)((buf) * BM + lrow + 32 * j) * LDK + lkc) = v;      \
+        }                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                   \
+            ltg_u32x4 v = rb[j];                                                                           \
+            v[0] &= bm[j]; v[1] &= bm[j]; v[2] &= bm[j]; v[3] &= bm[j];                                    \
+            *reinterpret_cast<ltg_u32x4*>(Bs + (size_t)((buf) * BN + lrow + 32 * j) * LDK + lkc) = v;      \
+        }                                                                                                  \
+    }
+    SG8_FETCH(0)
+    SG8_STASH(0)
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = k0 + BK < K;   // uniform
+        if (more) SG8_FETCH(k0 + BK)     // the next block's loads fly under this block's MFMAs
+        const uint8_t* Aw = As + (size_t)(buf * BM + wm * (BM / 2) + lr) * LDK + 8 * lq;
+        const uint8_t* Bw = Bs + (size_t)(buf * BN + wn * (BN / 2) + lr) * LDK + 8 * lq;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 32) {
+            long af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(Aw + (size_t)(i * 16) * LDK + ks);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const long*>(Bw + (size_t)(j * 16) * LDK + ks);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) SG8_STASH(buf ^ 1)     // the other buffer: its readers finished before the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) epi(wm * (BM / 2) + i * 16 + 4 * lq + x, wn * (BN / 2) + j * 16 + lr, acc[i][j][x] * scale);
+#undef SG8_FETCH
+#undef SG8_STASH
+}
+
+// branch layers from e4m3 storage, LDS-staged: blockIdx.x = column tile over BOTH branches (popular -> h1, niche -> h2; XCD x keeps
+// the column tiles x, x + 8, ...: its weight rows stay in its L2), blockIdx.y = row tile
+template <int BM, int BN>
+__global__ __launch_bounds__(NT) void fk8s_d_l1(PairView pv, int h0, int h1, int h2, const uint8_t* __restrict__ emb8,
+                                                const uint8_t* __restrict__ w1t8, const float* __restrict__ b1,
+                                                const uint8_t* __restrict__ w2t8, const float* __restrict__ b2, DropView dA, DropView dB,
+                                                float keep, uint64_t seed, uint64_t step, float* __restrict__ A1, uint8_t* __restrict__ A1_8) {
+    __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * 144];
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    const int tn1 = (h1 + BN - 1) / BN;
+    const int ct = blockIdx.x, rt = blockIdx.y;
+    const bool br = ct >= tn1;
+    const int N = br ? h2 : h1;
+    const int m0 = rt * BM, n0 = (br ? ct - tn1 : ct) * BN;
+    const uint8_t* Wt = br ? w2t8 : w1t8;
+    const float* bias = br ? b2 : b1;
+    const int coff = br ? h1 : 0;
+    auto a_row = [=] __device__(int r) -> const uint8_t* {
+        if (r < 0 || m0 + r >= n) return r < 0 ? emb8 : nullptr;
+        const int id = br ? pv.nic(m0 + r) : pv.pop(m0 + r);
+        return id >= 0 ? emb8 + (size_t)id * h0 : nullptr;
+    };
+    auto b_row = [=] __device__(int c) -> const uint8_t* {
+        if (c < 0) return Wt;
+        return n0 + c < N ? Wt + (size_t)(n0 + c) * h0 : nullptr;
+    };
+    auto epi = [=] __device__(int r, int c, float v) {
+        const int m = m0 + r, nn = n0 + c;
+        if (m >= n || nn >= N) return;
+        const float t = ltg_tanh_fast(v + bias[nn]);
+        const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
+        const float a = kp ? t / keep : 0.f;
+        A1[(size_t)m * h12 + coff + nn] = a;
+        A1_8[(size_t)m * h12 + coff + nn] = ltg_f2fp8(a * (float)(1 << FP8_S_ACT));
+    };
+    ltg_sgemm8<BM, BN>(h0, a_row, b_row, 1.f / (float)(1 << (FP8_S_EMB + FP8_S_W)), epi, s8);
+}
+
+// fully connected layer from e4m3 storage, LDS-staged
+template <int BM, int BN>
+__global__ __launch_bounds__(NT) void fk8s_d_l2(int n, int h12, int h3, const uint8_t* __restrict__ A1_8, const uint8_t* __restrict__ w3t8,
+                                                const float* __restrict__ b3, DropView dC, float keep, uint64_t seed, uint64_t step,
+                                                float* __restrict__ A3) {
+    __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * 144];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    auto a_row = [=] __device__(int r) -> const uint8_t* { return (r < 0 || m0 + r >= n) ? (r < 0 ? A1_8 : nullptr) : A1_8 + (size_t)(m0 + r) * h12; };
+    auto b_row = [=] __device__(int c) -> const uint8_t* { return (c < 0 || n0 + c >= h3) ? (c < 0 ? w3t8 : nullptr) : w3t8 + (size_t)(n0 + c) * h12; };
+    auto epi = [=] __device__(int r, int c, float v) {
+        const int m = m0 + r, nn = n0 + c;
+        if (m >= n || nn >= h3) return;
+        const float t = ltg_tanh_fast(v + b3[nn]);
+        A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
+    };
+    ltg_sgemm8<BM, BN>(h12, a_row, b_row, 1.f / (float)(1 << (FP8_S_ACT + FP8_S_W)), epi, s8);
+}
+
 // (re)build the e4m3 operand shadows of the discriminator from the fp32 tensors: emb8 [F][h0] and the TRANSPOSED weights
 __global__ __launch_bounds__(NT) void k_d_shadow(int F, int h0, int h1, int h2, int h3, const float* __restrict__ emb, const float* __restrict__ w1,
                                                  const float* __restrict__ w2, const float* __restrict__ w3, uint8_t* __restrict__ emb8,

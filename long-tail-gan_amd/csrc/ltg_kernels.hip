@@ -2496,10 +2496,20 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? 32 : ts, t2 = ts2 < 0 ? 32 : ts2;
     if (md == 2 && fast_on(cfg) && d->emb_fp8 && d->w1t_fp8 && d->w2t_fp8 && d->w3t_fp8 && (h0 % 64) == 0 && (h12 % 64) == 0) {
         // operand-format storage: both forward layers read e4m3 bytes (embedding table, transposed weight shadows, A1 in e4m3)
+        const bool staged = (h0 % 128) == 0 && (h12 % 128) == 0 && (cfg->reserved0 & (1 << 24)) == 0;   // LDS-staged tiles (knob bit 24: register-resident)
+        if (staged) {
+            // 64 x 64 tiles: 696 workgroups of 37 KB LDS, three or four per CU hide each other's load latency (measured at 1 820 pair
+            // rows: 30-32 us; 128 x 128 tiles = 180 workgroups, one per CU, 54 us; 128 x 64: 60 us; register-resident block: 52 us)
+            LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL((fk8s_d_l1<64, 64>), dim3((h1 + 63) / 64 + (h2 + 63) / 64, (n + 63) / 64), dim3(NT), 0, st, pv, h0, h1, h2,
+                                                          d->emb_fp8, d->w1t_fp8, d->p[1], d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.A1, w.A1_8));
+            LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL((fk8s_d_l2<64, 64>), grid2(h3, n, 64, 64), dim3(NT), 0, st, n, h12, h3, w.A1_8, d->w3t_fp8, d->p[5], dC, keep,
+                                                          cfg->seed, step, w.A3));
+        } else {
         LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk8_d_l1, dim3(8 * (((h1 + 63) / 64 + (h2 + 63) / 64 + 7) / 8) * ((n + 63) / 64)), dim3(NT), 0, st, pv, h0, h1, h2, d->emb_fp8, d->w1t_fp8, d->p[1],
                                                       d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.A1, w.A1_8));
         LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk8_d_l2, grid2(h3, n, 64, 64), dim3(NT), 0, st, n, h12, h3, w.A1_8, d->w3t_fp8, d->p[5], dC, keep,
                                                       cfg->seed, step, w.A3));
+        }
         const dim3 go8((n + NT / 64 - 1) / (NT / 64));
         if (with_bwd) hipLaunchKernelGGL(k_d_out<true>, go8, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
         else hipLaunchKernelGGL(k_d_out<false>, go8, dim3(NT), 0, st, pv, h3, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3);
