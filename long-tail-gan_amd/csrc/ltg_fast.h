@@ -1233,6 +1233,158 @@ __global__ __launch_bounds__(NT) void fk8_d_l2(int n, int h12, int h3, const uin
     ltg_rgemm8(n, h3, h12, m0, n0, a_ld, a_mask, b_ld, 1.f / (float)(1 << (FP8_S_ACT + FP8_S_W)), epi);
 }
 
+// ---- LDS-staged fp32 block for MANY pair rows (the batched fake towers of phase G: 10^5 rows per launch).  The 32 x 32
+// register-resident tiles above are built for one round trip at ~2 000 rows; at 91 000 rows they re-fetch every operand per
+// tile (2.9 GB from the L2s per tower).  64 x 64 outputs per workgroup, 32 floats of K per stage in LDS, global loads of the
+// next stage in flight under the MFMAs of this one; each wave a 32 x 32 quarter with v_mfma_f32_16x16x4_f32.
+//   a_row(r): start of operand row r of the tile (K floats, 16-byte aligned), nullptr = zero row; a_row(-1): any valid address.
+//   B[k][n0 + c] = Bm[k * ldb + n0 + c] (row-major weights), columns >= N are zero.
+template <class ARow, class EF>
+__device__ __forceinline__ void ltg_sgemm32(int K, int N, int n0, ARow a_row, const float* __restrict__ Bm, int ldb, EF epi, float* __restrict__ lds) {
+    constexpr int BM = 64, BN = 64, BK = 32, LDA = BK + 4, LDB = BN + 16;   // strides: conflict-free fragment reads (36 lr + lq, 16 lq + lr)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
+    float* As = lds;                         // [2][BM][LDA]
+    float* Bs = lds + 2 * BM * LDA;          // [2][BK][LDB]
+    const int arow = tid >> 3, akq = (tid & 7) * 4;          // A loader: rows arow + 32 j, floats akq .. akq + 3 of the stage
+    const int bk = tid >> 6, bn = tid & 63;                  // B loader: k rows bk + 4 j, column bn
+    const float* ap[2];
+    bool aok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* q = a_row(arow + 32 * j);
+        aok[j] = q != nullptr;
+        ap[j] = (q ? q : a_row(-1)) + akq;
+    }
+    const bool bok = n0 + bn < N;
+    const float* bp = Bm + min(n0 + bn, N - 1);
+    ltg_f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[2];
+    float rb[8];
+#define SG32_FETCH(k0)                                                                                           \
+    {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const float4*>(ap[j] + min((k0), K - 4 - akq)); \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) rb[j] = bp[(size_t)min((k0) + bk + 4 * j, K - 1) * ldb]; \
+    }
+#define SG32_STASH(buf, k0)                                                                                      \
+    {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+            const bool ok = aok[j] && (k0) + akq < K;   /* K % 4 == 0: a float4 is inside or outside */          \
+            *reinterpret_cast<float4*>(As + (size_t)((buf) * BM + arow + 32 * j) * LDA + akq) = ok ? ra[j] : make_float4(0.f, 0.f, 0.f, 0.f); \
+        }                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                            \
+            Bs[(size_t)((buf) * BK + bk + 4 * j) * LDB + bn] = (bok && (k0) + bk + 4 * j < K) ? rb[j] : 0.f;     \
+    }
+    SG32_FETCH(0)
+    SG32_STASH(0, 0)
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = k0 + BK < K;   // uniform
+        if (more) SG32_FETCH(k0 + BK)
+        const float* Aw = As + (size_t)(buf * BM + wm * 32 + lr) * LDA + lq;
+        const float* Bw = Bs + (size_t)(buf * BK + lq) * LDB + wn * 32 + lr;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = Aw[(size_t)(i * 16) * LDA + kk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bw[(size_t)kk * LDB + j * 16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) SG32_STASH(buf ^ 1, k0 + BK)
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef SG32_FETCH
+#undef SG32_STASH
+    epi(wm, wn, lr, lq, acc);
+}
+constexpr int SG32_LDS_FLOATS = 2 * 64 * 36 + 2 * 32 * 80;
+
+// branch layers for many pair rows (forward only): blockIdx.x = 64-column tile over both branches, blockIdx.y = 64-row tile
+__global__ __launch_bounds__(NT) void fks_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb, const float* __restrict__ w1,
+                                               const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, DropView dA,
+                                               DropView dB, float keep, uint64_t seed, uint64_t step, float* __restrict__ A1) {
+    __shared__ __attribute__((aligned(16))) float lds[SG32_LDS_FLOATS];
+    const int n = pv.nr + pv.nf, h12 = h1 + h2;
+    const int tn1 = (h1 + 63) / 64;
+    const bool br = (int)blockIdx.x >= tn1;
+    const int N = br ? h2 : h1;
+    const int m0 = blockIdx.y * 64, n0 = (br ? blockIdx.x - tn1 : blockIdx.x) * 64;
+    const float* W = br ? w2 : w1;
+    const float* bias = br ? b2 : b1;
+    const int coff = br ? h1 : 0;
+    auto a_row = [=] __device__(int r) -> const float* {
+        if (r < 0 || m0 + r >= n) return r < 0 ? emb : nullptr;
+        const int id = br ? pv.nic(m0 + r) : pv.pop(m0 + r);
+        return id >= 0 ? emb + (size_t)id * h0 : nullptr;
+    };
+    auto epi = [=] __device__(int wm, int wn, int lr, int lq, ltg_f32x4 (&acc)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = n0 + wn * 32 + j * 16 + lr;
+            const float bv = bias[min(nn, N - 1)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int m = m0 + wm * 32 + i * 16 + 4 * lq + x;
+                    if (m < n && nn < N) {
+                        const float t = tanhf(acc[i][j][x] + bv);
+                        const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
+                        A1[(size_t)m * h12 + coff + nn] = kp ? t / keep : 0.f;
+                    }
+                }
+        }
+    };
+    ltg_sgemm32(h0, N, n0, a_row, W, N, epi, lds);
+}
+
+// fully connected layer + the output unit's partial dot products for many pair rows (forward only: A3 is not kept):
+// spart[(2 * tile + wave column)][row] = that 32-column strip's share of A3[row] . w4
+__global__ __launch_bounds__(NT) void fks_d_l2(int n, int h12, int h3, const float* __restrict__ A1, const float* __restrict__ w3,
+                                               const float* __restrict__ b3, const float* __restrict__ w4, DropView dC, float keep, uint64_t seed,
+                                               uint64_t step, float* __restrict__ spart) {
+    __shared__ __attribute__((aligned(16))) float lds[SG32_LDS_FLOATS];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    auto a_row = [=] __device__(int r) -> const float* { return (r < 0 || m0 + r >= n) ? (r < 0 ? A1 : nullptr) : A1 + (size_t)(m0 + r) * h12; };
+    auto epi = [=] __device__(int wm, int wn, int lr, int lq, ltg_f32x4 (&acc)[2][2]) {
+        float bv[2], wv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = n0 + wn * 32 + j * 16 + lr;
+            bv[j] = b3[min(nn, h3 - 1)];
+            wv[j] = nn < h3 ? w4[nn] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int m = m0 + wm * 32 + i * 16 + 4 * lq + x, mc = min(m, n - 1);
+                float pd = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nn = n0 + wn * 32 + j * 16 + lr;
+                    const float t = tanhf(acc[i][j][x] + bv[j]);
+                    const bool kp = nn < h3 && dC.keep(mc, min(nn, h3 - 1), h3, seed, LTG_STREAM_D_DROP_C, step, keep);
+                    pd += (kp ? t / keep : 0.f) * wv[j];
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) pd += __shfl_xor(pd, o);     // the 16 lanes lr of the strip
+                if (lr == 0 && m < n) spart[(size_t)(2 * blockIdx.x + wn) * n + m] = pd;
+            }
+    };
+    ltg_sgemm32(h12, h3, n0, a_row, w3, h3, epi, lds);
+}
+
 // ---- LDS-staged e4m3 block for the wide sizes.  The register-resident block above lets every wave fetch its own 32 operand
 // rows: a 64 x 64 workgroup tile pulls each operand byte through the L1 twice and 696 such tiles move 356 MB from the L2s per
 // branch-layer launch (7.4 TB/s at 48 us: L2-bandwidth-bound).  Here a workgroup owns BM x BN outputs, stages 128 bytes of K

@@ -2248,7 +2248,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
         const size_t ks = (P + D_KCHUNK - 1) / D_KCHUNK;
         w.slab = take(ks * (size_t)d_slab_stride(L.off[8]));
     }
-    w.spart = take(((h3 + 31) / 32) * P);
+    w.spart = take((((h3 + 31) / 32) + 1) * P);   // per-tile partial dot products of the output unit: 32-column tiles, or 2 strips per 64-column tile
     w.G3 = take(P * h3);
     w.rowout = take(R * 4);
     w.xd = take(I <= (size_t)RD_MAXI ? R * I : 1);   // dense operand rows of enc-0 (small item slabs)
@@ -2484,6 +2484,17 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
+    if (d_fast(cfg) && !with_bwd && h0 >= 32 && h12 >= 32 && (h0 % 4) == 0 && (h12 % 4) == 0 && (cfg->reserved0 & (1 << 23)) == 0) {
+        // forward only (the fake tower of the G steps, one batch or -- ltg_fake_tower_batched -- 10^5 pair rows): LDS-staged 64 x 64
+        // tiles.  The choice depends on the layer sizes only, so the tower inside a step and the batched tower run the same
+        // kernels and produce the same bits.  (Tuning-knob bit 23: the register-resident 32 x 32 tiles.)
+        LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fks_d_l1, dim3((h1 + 63) / 64 + (h2 + 63) / 64, (n + 63) / 64), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0],
+                                                      d->p[1], d->p[2], d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
+        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fks_d_l2, dim3((h3 + 63) / 64, (n + 63) / 64), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
+                                                      cfg->seed, step, w.spart));
+        hipLaunchKernelGGL(fk_d_y, dim3((n + NT - 1) / NT), dim3(NT), 0, st, pv, 2 * ((h3 + 63) / 64), w.spart, d->p[7], w.y);
+        return;
+    }
     if (d_fast(cfg)) {
         // A3, G3 (backward only) and the per-tile partial dot products of the output unit; y only when nothing else follows
         LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],

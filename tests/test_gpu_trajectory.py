@@ -61,8 +61,9 @@ def test_two_epoch_trajectory_matches_oracle(tmp_path):
     np.testing.assert_allclose(eng.d_p[6].cpu().numpy()[:64], gold["final_w4_head"], atol=5e-4)
 
 
-@pytest.mark.parametrize("workload,users", [("custom:1000", 450), ("custom:8264", 230)])
-def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, users):
+@pytest.mark.parametrize("workload,users,hs", [("custom:1000", 450, (20, 24, 40, 36)), ("custom:8264", 230, (20, 24, 40, 36)),
+                                               ("custom:1000", 450, (100, 150, 250, 300))])     # config.ini's sizes: the LDS-staged tower kernels
+def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, users, hs):
     """Two reorderings of work that no weight update separates: phase C over spans of batches (one forward + one sampler launch,
     every batch with its own RNG counter and row numbers) and every fake tower of phase G evaluated ahead (the discriminator is
     fixed during the phase; ltg_fake_tower_batched + ltg_g_opts.y_pre).  Two epochs with both against two epochs batch by batch
@@ -76,7 +77,7 @@ def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, 
     idx, _ = synthetic_index(workload, users=users, seed=9)
     runs = []
     for hoist in (False, True):
-        eng = Engine(idx.n_items, h_sizes=(20, 24, 40, 36), lr=1e-3, seed=5, d_seed=2)
+        eng = Engine(idx.n_items, h_sizes=hs, lr=1e-3, seed=5, d_seed=2)
         tr = Trainer(eng, DeviceData(idx, 100, eng.device), num_sub_epochs=2, shuffle_seed=3, span_create=hoist, batched_tower=hoist)
         assert tr.batched_tower == hoist and (tr.span_batches > 1) == hoist
         out = []
