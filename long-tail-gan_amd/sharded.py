@@ -153,7 +153,10 @@ class ShardedTrainer(Trainer):
                 self.update_count += 1
                 B = v["batch"].n_rows
                 pr = self.probe_hook("g", b) if self.probe_hook else None
-                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, self._step(), self._step(), probe=pr,
+                rs, ds = self._step(), self._step()
+                if self.batched_tower and ds != self._tower_steps[j, b]:
+                    raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
+                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, rs, ds, probe=pr,
                                 y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
                 if self.fake_overlap and v["fake"].n > 0 and not self.batched_tower:
                     # the fake tower (replicated, needs nothing of the generator) on a side stream, beside the forward and its

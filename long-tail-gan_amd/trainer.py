@@ -123,6 +123,7 @@ class Trainer:
         for j in range(self.S):
             for k, pos in enumerate(self.order):
                 steps[j, self.active[pos]] = self.rng_step + 2 * (j * na + k) + 2
+        self._tower_steps = steps                              # (host copy: every G step checks the counter it really uses)
         self._seg_step.copy_(torch.from_numpy(steps))          # the one host -> device copy of the phase
         for j in range(self.S):
             for t in self._towers:
@@ -142,9 +143,12 @@ class Trainer:
                 v = d.view(b)
                 a = self.anneal()
                 self.update_count += 1
+                rs, ds = self._step(), self._step()
+                if self.batched_tower and ds != self._tower_steps[j, b]:
+                    raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
                 eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
-                           keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=self._step(),
-                           d_rng_step=self._step(), loss_out=self.g_losses[j],
+                           keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=rs,
+                           d_rng_step=ds, loss_out=self.g_losses[j],
                            probe=self.probe_hook("g", b) if self.probe_hook else None,
                            y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
             self.last_anneal.append(a)
