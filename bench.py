@@ -99,6 +99,7 @@ class KernelProfiler:
         else:
             self.G_KERNELS = ["enc0_fwd", "enc1", "dec0", "dec1_fwd", "dh2", "dec1_bwd_adam", "dz", "wgrad_p0", "dh1", "wgrad_q1", "enc0_bwd_adam"]
         self.samples = []        # (event pair, n_pairs, nnz) recorded in the timed region
+        self.extra_samples = {}  # probe id -> samples of the extra ids of hook()
         self.pool = []           # event pairs created BEFORE the timed region (reserve())
 
     def reserve(self, n):
@@ -199,9 +200,12 @@ class KernelProfiler:
             out[name] = dict(avg_ms=float(np.mean(ms)), flops=float(fl), bytes=float(by), epoch_ms=float(np.mean(ms)) * launches)
         return out
 
-    def hook(self, name):
-        """called by the trainer for every D / G step of the timed region; probes every 32nd one (an event pair costs the stream a few microseconds of bubbles)"""
-        state = {"i": 0}
+    def hook(self, name, extra=()):
+        """called by the trainer for every D / G step of the timed region; probes every 32nd one (an event pair costs the stream a few
+        microseconds of bubbles).  extra: further G-step probe ids (the in-stream exchanges of the one-call sharded step) that take
+        turns with `name` on those steps."""
+        state = {"i": 0, "turn": 0}
+        names = [name] + list(extra)
 
         def h(kind, b):
             if (kind == "d") != (name in self.D_KERNELS):
@@ -209,13 +213,25 @@ class KernelProfiler:
             state["i"] += 1
             if (state["i"] - 1) % 32 or not self.pool:      # the first one, then every 32nd
                 return None
-            ev, p = self._probe(name)
+            nm = names[state["turn"] % len(names)]
+            state["turn"] += 1
+            ev, p = self._probe(nm)
             sh = self._shapes(b)
             v = self.data.view(b)
             sh["n"] = (v["n_real"] + v["n_slots"]) if kind == "d" else v["n_slots"]
-            self.samples.append((ev, sh, p))
+            (self.samples if nm == name else self.extra_samples.setdefault(nm, [])).append((ev, sh, p))
             return p
         return h
+
+    def extra_us(self):
+        """average in-stream duration (us) of the extra probe ids"""
+        out = {}
+        for nm, smp in self.extra_samples.items():
+            ms = [e.elapsed_ms() for e, _, _ in smp]
+            ms = [m for m in ms if m is not None]
+            if ms:
+                out[nm] = {"avg_us": float(np.mean(ms)) * 1e3, "samples": len(ms)}
+        return out
 
     def roofline(self, name, calib):
         ms = [e.elapsed_ms() for e, _, _ in self.samples]
@@ -296,28 +312,48 @@ def copy_ceiling(device, nbytes=1 << 30, reps=5):
     return {"value": best, "unit": "GB/s", "what": "torch D2D copy of 1 GiB, read + write bytes, best of %d" % reps}
 
 
+def visible_gpus():
+    """GPUs this process tree may use, WITHOUT loading the HIP runtime (the self-launching parent must stay a process that never
+    touched the GPU): the visibility variables if set, else the KFD topology in sysfs (GPU nodes have a non-zero simd_count)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n, base = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return 0
+    return n
+
+
 def self_launch(a):
     """`python bench.py --gpus N` (N > 1) outside a launcher: start N FRESH rank processes with torch.distributed.run as a
-    CHILD of this process (which has not touched the GPU and never will), relay their output and exit with their code.
+    CHILD of this process (which never loads the HIP runtime: it imports neither torch nor the library), relay their output and
+    exit with their code.
     The reference is a single command without a launcher too (train.py:359-381)."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    import torch   # device_count() does not initialise the GPU; nothing else of torch.cuda is called in this process
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_gpus()      # from sysfs / the visibility variables: this parent never loads the HIP runtime
     if n_dev < a.gpus and "LTGAN_DIST_BACKEND" not in env:
         # fewer GPUs than ranks (single-GPU test box): RCCL cannot put two ranks on one device -> gloo, ranks share GPUs
         env["LTGAN_DIST_BACKEND"] = "gloo"
         print("bench.py: %d rank(s) on %d visible GPU(s): using the gloo backend (ranks share devices)" % (a.gpus, n_dev), file=sys.stderr, flush=True)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --rdzv-endpoint 127.0.0.1:0 lets the launcher's own store pick a free port (no bind-then-close race in this process)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--rdzv-backend", "c10d",
+           "--rdzv-endpoint", "127.0.0.1:0", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
     last_json = None
     for line in proc.stdout:
-        if line.startswith("{") and line.rstrip().endswith("}"):
+        if line.startswith('{"metric"') and line.rstrip().endswith("}"):
+            if last_json is not None:
+                sys.stderr.write(last_json + "\n")     # an earlier result-shaped line: kept visible, never swallowed
             last_json = line.rstrip()       # rank 0's result line: relayed last, alone
         else:
             sys.stdout.write(line)
@@ -466,9 +502,19 @@ def main():
     else:
         calib = prof.calibrate() if rank == 0 else None
         dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
-    tr.probe_hook = prof.hook(dominant) if (dominant and rank == 0) else None
+    one_call = getattr(tr, "pipe", None) is not None and getattr(tr, "comm", None) is not None
+    exch = ("exch_h1", "exch_rowpart", "exch_dh2") if (mode == "item-shard" and one_call) else ()
+    tr.probe_hook = prof.hook(dominant, exch) if (dominant and rank == 0) else None
     if tr.probe_hook:
         prof.reserve(min(2048, a.steps * a.sub_epochs * data.n_batches // 32 + 1))
+    # who really runs this job: one line per rank (device identity as the runtime reports it), world size as RCCL reports it
+    ranks_info = None
+    if dist.is_initialized():
+        pr_ = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "local_rank": local, "pid": os.getpid(), "gpu_uuid": str(getattr(pr_, "uuid", "")), "gpu": pr_.name,
+              "pci_bus_id": getattr(pr_, "pci_bus_id", None), "cus": pr_.multi_processor_count}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
     barrier()
     t0 = time.perf_counter()
     phases = []
@@ -482,6 +528,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     replicas = mode == "replicas" and world > 1
+    data_users = data.N
     users = data.N * a.steps * (world if replicas else 1)   # replicas: every rank processes the full workload
     value = users / dt
     res = {
@@ -497,10 +544,27 @@ def main():
                    if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
         "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
     }
+    if mode == "item-shard":
+        comm = getattr(tr, "comm", None)
+        res["sharded_step"] = {
+            "one_call": bool(one_call),                          # ltg_g_step_sharded: every launch and the three exchanges from one C call
+            "transport": getattr(comm, "kind", "torch.distributed (%s), step cut at its exchange points" % backend),
+            "rccl_ranks": getattr(comm, "count", None) if getattr(comm, "kind", "") == "rccl-direct" else None,   # ncclCommCount
+            "ranks": ranks_info,
+            "distinct_gpus": len({r["gpu_uuid"] or r["pci_bus_id"] or r["local_rank"] for r in ranks_info}) if ranks_info else 1,
+        }
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if mode == "item-shard":
+            ex = prof.extra_us()
+            nb_, S_ = max(1, len(tr.active)), a.sub_epochs
+            res["sharded_step"]["g_step_us"] = res["phases_ms"]["t_g"] * 1e3 / (nb_ * S_)
+            res["sharded_step"]["d_step_us"] = res["phases_ms"]["t_d"] * 1e3 / (nb_ * S_)
+            res["sharded_step"]["exchanges_us"] = {k: round(v["avg_us"], 2) for k, v in ex.items()}
+            res["sharded_step"]["exchanges_note"] = ("HIP events on the step's stream around each in-stream collective call (every 32nd G step, rank 0): "
+                                                     "time the step's critical path spends in the exchange, queueing behind slower ranks included")
         res["roofline"] = prof.roofline(dominant, calib) if dominant else None
         if res["roofline"] is None:
             res["roofline"] = {"kernel": None, "note": "kernel probes disabled (--no-probe)" if a.no_probe else "no probed launch fell into the timed region"}
@@ -521,6 +585,17 @@ def main():
             del tr, prof, eng, data
             torch.cuda.empty_cache()
             res["other_workloads"] = other_workloads(a, device)
+        # ONE workload across every N: the headline `value` is Askubuntu_Sample at N = 1 (BASELINE's metric configuration) and the
+        # C4-shaped synthetic at N > 1, so a 1 -> 8 curve is read from this key -- the C4-shaped bounded sample (200 000 items,
+        # 6 400 users unless --users) at this run's N
+        c4v = None
+        if workload == "c4":
+            c4v = value
+        elif "other_workloads" in res and "c4" in res["other_workloads"]:
+            c4v = res["other_workloads"]["c4"]["value"]
+        if c4v is not None:
+            res["c4_same_workload"] = {"value": c4v, "unit": "users/s", "n_gpus": world, "workload": "c4 (200000 items; %d users)" %
+                                       (data_users if workload == "c4" else 6400)}
         if not a.no_cpu_baseline and world == 1:
             from oracle.cpu_port import time_cpu_baseline   # oracle/ is only ever the baseline / checker
             res["cpu_baseline"] = time_cpu_baseline(idx, budget_s=a.cpu_seconds, S=a.sub_epochs, batch_size=a.batch_size)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 9
+#define LTG_ABI_VERSION 10
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -173,7 +173,10 @@ typedef struct ltg_gen_acts {
 #define LTG_K_ROW_DLOGITS 17 /* softmax statistics + losses + dlogits of a row (small item slabs) */
 #define LTG_K_ENC0_GRAD 18   /* sparse gradient rows of W_q0 */
 #define LTG_K_G_TAIL 19      /* the generator's Adam updates as jobs of one launch */
-#define LTG_K_COUNT 20
+#define LTG_K_EXCH_H1 20      /* ltg_g_step_sharded: the three in-stream exchanges (events around the collective call on the step's stream) */
+#define LTG_K_EXCH_ROWPART 21
+#define LTG_K_EXCH_DH2 22
+#define LTG_K_COUNT 23
 typedef struct ltg_probe {
     int32_t kernel_id;
     int32_t reserved0;
@@ -358,6 +361,63 @@ int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                    const ltg_g_opts* opts, const ltg_gen_acts* acts, void* ws, size_t ws_bytes, ltg_stream stream);
 int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, const float* logits, float* out,
                            ltg_stream stream);
+
+/* ---- The item-sharded generator step as ONE call (ABI v10): every launch of the step AND its three exchanges issued in-stream,
+ * with the two off-critical-path pieces of step t running beside step t + 1.  Replaces the five-call sequence ltg_g_fwd_enc ..
+ * ltg_g_bwd_rest (one sess.run per step in the reference, train.py:326) for the configuration every large item slab runs in:
+ * bf16 decoder operands with the W_p1t shadow, the lazy Adam clock of W_q0, n_items >= 8192, n_items % 8 == 0, <= 128 rows
+ * (ltg_g_step_sharded_ok tells; other configurations use the cut-point calls above).
+ *
+ * Collectives: the library links no communication library.  The caller hands in its communicator and the two entry points with
+ * the signatures of ncclAllReduce / ncclAllGather (rccl.h:611, :678; enums passed as int: LTG_NCCL_FLOAT32 = ncclFloat32,
+ * LTG_NCCL_SUM = ncclSum) -- on a GPU node the addresses of RCCL's own functions, so the exchanges are RCCL kernels on the
+ * caller's stream between the library's kernels (no host round trip); a test rig may pass host functions that synchronise
+ * the stream and reduce through another backend.  comm == NULL: no exchange (one GPU); a communicator of ONE rank still gets its
+ * three calls (the single-GPU proxy of a rank's step measures them).
+ *
+ * Pipeline (ltg_pipe: ONE caller-created side stream, three events and the exchange buffers; the library allocates nothing).
+ * One fork per step, behind the dh2 product of step t (the last reader of the W_p1t shadow), puts onto the side stream
+ *   (1) the rotating slice of the lazy Adam clock that step t - 1 owes (rows i = ord (mod q0_period) up to ordinal ord = t - 1):
+ *       every row of batch t is already at that ordinal (the catch-up at the start of the step), so the slice skips them whatever
+ *       the rest of step t does to them; joined (ev_slice) at the start of call t + 1, before that batch's catch-up;
+ *   (2) the Adam update of the local W_p1t / b_p1 rows of step t (HBM-bound, the largest kernel; needs only dlogits and h2):
+ *       joined (ev_dec1) before dec-0 of step t + 1 overwrites h2 -- it runs beside the rest of step t's backward and the
+ *       encoder half of step t + 1's forward.
+ * Both joins are stream waits on events recorded by the PREVIOUS call (a never-recorded event does not block).  Before anything
+ * else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs ltg_g_pipe_join on the
+ * stream that will read them.  Results equal ltg_g_step's / the cut-point sequence's bit for bit (same kernels, same order of
+ * additions; the slice only runs later). */
+#define LTG_NCCL_FLOAT32 7
+#define LTG_NCCL_SUM 0
+typedef struct ltg_comm {
+    void* comm;      /* ncclComm_t */
+    int32_t n_ranks; /* >= 1 */
+    int32_t rank;
+    int (*all_reduce)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, ltg_stream stream);
+    int (*all_gather)(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, ltg_stream stream);
+} ltg_comm;
+
+typedef struct ltg_pipe {
+    ltg_stream side_stream;
+    void* ev_fork; /* hipEvent_t x 3, timing disabled */
+    void* ev_dec1;
+    void* ev_slice;
+    float* h1pre;       /* [n_rows][H]  exchange 1: partial encoder pre-activation, all-reduced in place */
+    float* rowpart_all; /* [n_ranks][n_rows][5]  exchange 2: all-gather IN PLACE (this rank writes block `rank`, n_rows = the call's batch) */
+    float* dh2;         /* [n_rows][H]  exchange 3: local dh2, all-reduced in place */
+    int32_t flags;      /* LTG_PIPE_* measurement switches, 0 = the shipped schedule */
+    int32_t reserved0;
+} ltg_pipe;
+#define LTG_PIPE_NO_DEC1_FORK 1  /* everything on the caller's stream, in program order */
+#define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
+/* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
+
+int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);
+int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,
+                       const ltg_pairs* fake, const ltg_g_opts* opts, const ltg_gen_acts* acts, const ltg_comm* comm,
+                       const ltg_pipe* pipe, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream);
+/* `stream` waits for the forked pieces of the last ltg_g_step_sharded call (dec1_stream, q0_stream). */
+int ltg_g_pipe_join(const ltg_pipe* pipe, ltg_stream stream);
 /* (re)build gen->wp1t_bf16 from gen->p[3] (after initialisation or after loading weights). */
 int ltg_refresh_shadow(const ltg_config* cfg, const ltg_gen_state* gen, ltg_stream stream);
 /* lazy Adam clock of W_q0 (ltg_gen_state.q0_last): apply every deferred zero-gradient step, all rows up to gen->q0_ord */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 9
+LTG_ABI_VERSION = 10
 LTG_Q0_HIST = 1024
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
@@ -57,7 +57,7 @@ class ltg_probe(C.Structure):
 
 KERNEL_IDS = {"enc0_fwd": 1, "enc1": 2, "dec0": 3, "dec1_fwd": 4, "d_l1": 5, "d_l2": 6, "d_bwd1": 7, "d_bwd2": 8, "d_adam": 9,
               "dh2": 10, "dec1_bwd_adam": 11, "enc0_bwd_adam": 12, "dz": 13, "dh1": 14, "wgrad_p0": 15, "wgrad_q1": 16,
-              "row_dlogits": 17, "enc0_grad": 18, "g_tail": 19}
+              "row_dlogits": 17, "enc0_grad": 18, "g_tail": 19, "exch_h1": 20, "exch_rowpart": 21, "exch_dh2": 22}
 
 
 class ltg_fwd_opts(C.Structure):
@@ -86,8 +86,29 @@ class ltg_sample_inputs(C.Structure):
                 ("u_gumbel", vp), ("u_pick", vp), ("cand_logit", vp), ("rows_per_step", C.c_int32), ("reserved0", C.c_int32)]
 
 
+# the two collective entry points a caller hands to ltg_g_step_sharded: the signatures of ncclAllReduce / ncclAllGather (rccl.h:611, :678)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
+LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK = 1, 2
+
+
+class ltg_comm(C.Structure):
+    _fields_ = [("comm", vp), ("n_ranks", C.c_int32), ("rank", C.c_int32), ("all_reduce", vp), ("all_gather", vp)]
+
+
+class ltg_pipe(C.Structure):
+    _fields_ = [("side_stream", vp), ("ev_fork", vp), ("ev_dec1", vp), ("ev_slice", vp),
+                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("reserved0", C.c_int32)]
+
+
 # every symbol include/ltg.h declares: name -> (restype, argtypes)
 SYMBOLS = {
+    "ltg_g_step_sharded_ok": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.c_int32]),
+    "ltg_g_step_sharded": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state), C.POINTER(ltg_batch),
+                                     C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), C.POINTER(ltg_comm),
+                                     C.POINTER(ltg_pipe), vp, vp, C.c_size_t, vp]),
+    "ltg_g_pipe_join": (C.c_int, [C.POINTER(ltg_pipe), vp]),
     "ltg_abi_version": (C.c_int32, []),
     "ltg_workspace_bytes": (C.c_size_t, [C.POINTER(ltg_config), C.c_int32, C.c_int32]),
     "ltg_vae_forward": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch),
@@ -148,12 +169,15 @@ def load():
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or make -C long-tail-gan_amd/csrc).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+    ab = bool(os.environ.get("LTG_HIP_LIB"))   # A/B timing against an OLDER build of the same library (scripts/ab.sh): entry points
+    for name, (res, args) in SYMBOLS.items():  # it lacks stay unbound (Engine.sharded_step_ok is then False); struct layouts only ever grew
+        if ab and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
     got = lib.ltg_abi_version()
-    if got != LTG_ABI_VERSION:
+    if got != LTG_ABI_VERSION and not (ab and 9 <= got < LTG_ABI_VERSION):
         raise LtgError("ABI version mismatch: library %d, binding %d" % (got, LTG_ABI_VERSION))
     _lib = lib
     return lib

@@ -1,0 +1,120 @@
+"""The collectives ltg_g_step_sharded issues in-stream (include/ltg.h: ltg_comm).
+
+`RcclComm`   RCCL itself, bound with ctypes to the librccl.so torch has loaded: its own communicator (ncclCommInitRank; the unique
+             id travels over the torch.distributed group that already exists), and the ADDRESSES of ncclAllReduce / ncclAllGather go
+             into ltg_comm -- the library then calls RCCL directly on the step's stream, between its own kernels: no host round
+             trip per exchange (a torch.distributed call costs ~30 us of host time, three of them per G step).
+`HostComm`   test rigs whose ranks share one GPU (RCCL refuses two ranks on a device): the same two entry points as host
+             callbacks that wait for the stream and reduce through the torch.distributed group (gloo).  Same C code path,
+             same results; only the transport differs.
+Nothing here computes: transports only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _cabi as cabi
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]          # NCCL_UNIQUE_ID_BYTES (rccl.h:40)
+
+
+def _librccl():
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
+    lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    lib.ncclGetErrorString.restype = C.c_char_p
+    lib.ncclGetErrorString.argtypes = [C.c_int]
+    lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.ncclCommCuDevice.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    return lib
+
+
+class RcclComm:
+    """A communicator of this process group's ranks created directly on RCCL (one rank per GPU)."""
+
+    def __init__(self, group=None, device=None):
+        self.lib = _librccl()
+        self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]    # (the raw 128 bytes: a c_char array reads as a C string)
+        if self.n_ranks > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        assert len(box[0]) == 128
+        C.memmove(C.byref(uid), box[0], 128)
+        if device is not None:
+            torch.cuda.set_device(device)
+        self.comm = C.c_void_p()
+        self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.n_ranks, uid, self.rank), "ncclCommInitRank")
+        n = C.c_int()
+        self._check(self.lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        self.count = int(n.value)                       # world size as RCCL reports it
+        self.c = cabi.ltg_comm(self.comm, self.n_ranks, self.rank, C.cast(self.lib.ncclAllReduce, C.c_void_p), C.cast(self.lib.ncclAllGather, C.c_void_p))
+        self.kind = "rccl-direct"
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise cabi.LtgError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+class HostComm:
+    """ltg_comm whose entry points are host functions over the torch.distributed group (any backend).  `buffers`: the device
+    tensors the library will hand in (looked up by address; the functions receive raw pointers)."""
+
+    def __init__(self, group, buffers):
+        self.group = group
+        self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.bufs = [(t.data_ptr(), t.numel() * t.element_size(), t.view(-1)) for t in buffers]
+        self._ar = cabi.ALL_REDUCE_FN(self._all_reduce)              # (kept alive with the object)
+        self._ag = cabi.ALL_GATHER_FN(self._all_gather)
+        self.c = cabi.ltg_comm(None, self.n_ranks, self.rank, C.cast(self._ar, C.c_void_p), C.cast(self._ag, C.c_void_p))
+        self.kind = "host (%s)" % dist.get_backend(group)
+        self.count = self.n_ranks
+
+    def _view(self, ptr, count):
+        """the registered device buffer that holds [ptr, ptr + 4 count) as a flat float32 view"""
+        for base, nbytes, t in self.bufs:
+            if base <= ptr and ptr + 4 * count <= base + nbytes:
+                off = (ptr - base) // 4
+                return t[off:off + count]
+        raise KeyError("pointer %x is not inside a registered exchange buffer" % ptr)
+
+    def _all_reduce(self, send, recv, count, dtype, op, comm, stream):
+        try:
+            if dtype != cabi.LTG_NCCL_FLOAT32 or op != cabi.LTG_NCCL_SUM or send != recv:
+                return 1
+            dist.all_reduce(self._view(recv, count), op=dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception:                                             # an exception must not unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 2
+
+    def _all_gather(self, send, recv, sendcount, dtype, comm, stream):
+        try:
+            if dtype != cabi.LTG_NCCL_FLOAT32:
+                return 1
+            src, out = self._view(send, sendcount).clone(), self._view(recv, self.n_ranks * sendcount)    # (in place: the source is a block of `out`)
+            dist.all_gather([out[r * sendcount:(r + 1) * sendcount] for r in range(self.n_ranks)], src, group=self.group)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 2
+
+    def close(self):
+        pass

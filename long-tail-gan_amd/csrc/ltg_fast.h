@@ -20,6 +20,13 @@ __device__ __forceinline__ int xcd_chunk(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// a * b rounded to fp32 on its own: never contracted into an fma with a following addition (HIP compiles with
+// -ffp-contract=fast-honor-pragmas; __fmul_rn is a plain product there)
+__device__ __forceinline__ float ltg_mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 typedef LtgRg<1, 1, 1, 1, 4> Rg16;    // 16 x 16 tile, four K slices
 typedef LtgRg<2, 2, 1, 1, 4> Rg32k;   // 32 x 32 tile, four K slices (each wave the whole tile)
 typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over the whole K
@@ -33,13 +40,33 @@ typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over
 // of logvar): logical tile column c < 16 is column n0 + c, c >= 16 is column Z + n0 + (c - 16), so the epilogue holds both
 // halves of a z value in two lanes 16 apart -- z is computed once per element, eps is drawn once per element.
 typedef LtgRg<1, 2, 1, 1, 4> Rg16x32;   // 16 x 32 tile, four K slices
+// a value and what its transform needs, requested together (operand loaders of ltg_rgemm return it RAW; the a_xf functor folds it)
+struct LtgRaw2 {
+    ltg_f32x4 x, y;
+};
+// PRE (item-sharded step): h1 holds the all-reduced PRE-activation of enc-0; the operand loader applies bias + tanh
+// (MultiVAE.py:152-155) and the column-tile-0 workgroups leave h1 = tanh(pre + b_q0) in h1_out for the backward -- no separate
+// k_bias_tanh launch between the exchange and this layer.
+template <bool PRE>
 __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* __restrict__ h1, const float* __restrict__ Wq1,
                                               const float* __restrict__ bq1, const float* __restrict__ eps_in, float is_training,
-                                              uint64_t seed, uint64_t step, float* __restrict__ mulv, float* __restrict__ z) {
+                                              uint64_t seed, uint64_t step, float* __restrict__ mulv, float* __restrict__ z,
+                                              const float* __restrict__ bq0 = nullptr, float* __restrict__ h1_out = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, Z2 = 2 * Z;
     auto col = [=] __device__(int c) { return min(n0 + (c & 15), Z - 1) + (c >> 4) * Z; };   // logical tile column -> column of mulv
-    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(h1 + (size_t)m * H + k); };
+    auto a_ld = [=] __device__(int, int m, int k) {
+        if constexpr (PRE) return LtgRaw2{ltg_ld4(h1 + (size_t)m * H + k), ltg_ld4(bq0 + k)};
+        else return ltg_ld4(h1 + (size_t)m * H + k);
+    };
+    const bool keep_h1 = PRE && blockIdx.x == 0;
+    auto a_xf = [=] __device__(auto raw, int, int m, int k) {
+        if constexpr (PRE) {
+            const ltg_f32x4 t{tanhf(raw.x[0] + raw.y[0]), tanhf(raw.x[1] + raw.y[1]), tanhf(raw.x[2] + raw.y[2]), tanhf(raw.x[3] + raw.y[3])};
+            if (keep_h1) *reinterpret_cast<ltg_f32x4*>(h1_out + (size_t)m * H + k) = t;   // (clamped duplicates store the same value)
+            return t;
+        } else return raw;
+    };
     auto b_ld = [=] __device__(int, int k, int c) { return ltg_ld4s(Wq1 + (size_t)k * Z2 + col(c), Z2); };
     // the epilogue's own operands are requested BEFORE the product (thread -> output map of ltg_rgemm: id = tid + 256 e,
     // row id / 32, logical column id % 32 = tid % 32), so the epilogue adds no round trip
@@ -65,7 +92,7 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
         }
     };
     // the block sees logical columns [0, 32) of this tile (all "in range"; the real bounds are the functors' business)
-    ltg_rgemm<1, 2, 1, 1, 4, 10>(B, 32, H, m0, 0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 4, 10>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // dec-0 (MultiVAE.py:168-172): h2 = tanh(z . W_p0 + b_p0); the column-tile-0 workgroups also add up the per-row KL
@@ -99,11 +126,27 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)          [B][2Z]
+// DH2 (item-sharded step): `da2` holds the all-reduced dh2; the operand loader applies the tanh derivative with h2
+// (da2 = dh2 (1 - h2^2), MultiVAE.py:168-172 backward) and the column-tile-0 workgroups leave da2 in da2_out for the weight
+// gradients -- no separate k_da2 launch between the exchange and this layer.
+template <bool DH2 = false>
 __device__ __forceinline__ void dz_tile(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
                                         const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training, float anneal,
-                                        uint64_t seed, uint64_t step, float* __restrict__ dmlv, int m0, int n0, float* __restrict__ lds) {
+                                        uint64_t seed, uint64_t step, float* __restrict__ dmlv, int m0, int n0, float* __restrict__ lds,
+                                        const float* __restrict__ h2 = nullptr, float* __restrict__ da2_out = nullptr, bool keep = false) {
     const float invB = 1.f / (float)B;
-    auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(da2 + (size_t)m * H + k); };
+    auto a_ld = [=] __device__(int, int m, int k) {
+        if constexpr (DH2) return LtgRaw2{ltg_ld4(da2 + (size_t)m * H + k), ltg_ld4(h2 + (size_t)m * H + k)};
+        else return ltg_ld4(da2 + (size_t)m * H + k);
+    };
+    auto a_xf = [=] __device__(auto raw, int, int m, int k) {
+        if constexpr (DH2) {
+            const ltg_f32x4 d{raw.x[0] * __builtin_fmaf(-raw.y[0], raw.y[0], 1.f), raw.x[1] * __builtin_fmaf(-raw.y[1], raw.y[1], 1.f),
+                              raw.x[2] * __builtin_fmaf(-raw.y[2], raw.y[2], 1.f), raw.x[3] * __builtin_fmaf(-raw.y[3], raw.y[3], 1.f)};   // (k_da2's expression)
+            if (keep) *reinterpret_cast<ltg_f32x4*>(da2_out + (size_t)m * H + k) = d;
+            return d;
+        } else return raw;
+    };
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wp0 + (size_t)n * H + k); };
     const int pm = min(m0 + (int)(threadIdx.x >> 4), B - 1), pn = min(n0 + (int)(threadIdx.x & 15), Z - 1);   // this thread's output
     const float mu = mulv[(size_t)pm * 2 * Z + pn], lv = mulv[(size_t)pm * 2 * Z + Z + pn];
@@ -116,7 +159,7 @@ __device__ __forceinline__ void dz_tile(int B, int Z, int H, const float* __rest
         dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
         dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, Z, H, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, Z, H, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)                                      [B][H]
@@ -136,6 +179,14 @@ __global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __
                                             float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
     dz_tile(B, Z, H, da2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, blockIdx.y * 16, blockIdx.x * 16, lds);
+}
+__global__ __launch_bounds__(NT) void fk_dz_dh2(int B, int Z, int H, const float* __restrict__ dh2, const float* __restrict__ h2,
+                                                const float* __restrict__ Wp0, const float* __restrict__ mulv, const float* __restrict__ eps_in,
+                                                float is_training, float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv,
+                                                float* __restrict__ da2_out) {
+    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    dz_tile<true>(B, Z, H, dh2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, blockIdx.y * 16, blockIdx.x * 16, lds, h2, da2_out,
+                  blockIdx.x == 0);
 }
 __global__ __launch_bounds__(NT) void fk_dh1(int B, int H, int Z2, const float* __restrict__ dmlv, const float* __restrict__ Wq1,
                                              const float* __restrict__ h1, float* __restrict__ da1) {
@@ -236,7 +287,10 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
         if (pre_only) o = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
         else {
             const float4 bb = *reinterpret_cast<const float4*>(bq0 + c);
-            o = make_float4(tanhf(t.x * scale + bb.x), tanhf(t.y * scale + bb.y), tanhf(t.z * scale + bb.z), tanhf(t.w * scale + bb.w));
+            // (product ROUNDED before the bias is added -- no fma: it is the value an item-sharded run all-reduces, so that the one-call
+            // sharded step, which applies bias + tanh in the next layer's loader, and this kernel yield the same bits)
+            o = make_float4(tanhf(ltg_mul_rounded(t.x, scale) + bb.x), tanhf(ltg_mul_rounded(t.y, scale) + bb.y), tanhf(ltg_mul_rounded(t.z, scale) + bb.z),
+                            tanhf(ltg_mul_rounded(t.w, scale) + bb.w));
         }
         *reinterpret_cast<float4*>(h1 + (size_t)b * H + c) = o;
     }

@@ -20,10 +20,24 @@ struct AdamC {
 // One element, with the rounding PINNED (explicit fma; `b1 m + (1-b1) g` may otherwise contract either way, kernel by
 // kernel): every kernel that applies Adam -- dense sweeps, tile epilogues, the lazy clock of W_q0 -- yields the same bits
 // for the same (p, m, v, g).
+// p - lr_t m / (sqrt(v) + eps).  Default: the hardware's square root and reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp each, the
+// quotient within ~2.5 ulp of the correctly rounded one -- 3e-7 of a step that is itself ~lr of the weight) instead of the IEEE
+// sequences (~25 VALU instructions per element: what bounds the lazy clock's catch-up kernels and a fifth of the streaming weight
+// update's issue slots).  The product with the reciprocal and the subtraction are ONE explicit fma: left to the compiler,
+// `p - lm * r` contracts in one kernel and not in another.  -DLTG_ADAM_IEEE builds the correctly rounded form (A/B:
+// scripts/build_variant.sh).  Every Adam update of the library goes through this one function, so dense sweep == lazy clock
+// bit for bit either way.
+__device__ __forceinline__ float adam_move(const float p, const float lm, const float v, const float eps) {
+#ifdef LTG_ADAM_IEEE
+    return p - lm / (sqrtf(v) + eps);
+#else
+    return __builtin_fmaf(-lm, __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps), p);
+#endif
+}
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, const float g, const float lr_t, const AdamC& c) {
     m = __builtin_fmaf(c.b1, m, (1.f - c.b1) * g);
     v = __builtin_fmaf(c.b2, v, ((1.f - c.b2) * g) * g);
-    p = p - (lr_t * m) / (sqrtf(v) + c.eps);
+    p = adam_move(p, lr_t * m, v, c.eps);
 }
 __device__ __forceinline__ void adam_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                             size_t i, float g, const AdamC c) {
@@ -1521,7 +1535,7 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
         }
         for (; z < nsplit; ++z) s += part[(size_t)z * n + i];
         const float t = h2 ? h2[i] : 0.f;
-        da2[i] = s * (1.f - t * t);
+        da2[i] = s * __builtin_fmaf(-t, t, 1.f);   // (rounding pinned: fk_dz_dh2's operand loader computes the same expression)
     }
 }
 
@@ -1806,7 +1820,7 @@ __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* 
 #define LTG_ADAM0(f)          \
     mm.f = ad.b1 * mm.f;      \
     vv.f = ad.b2 * vv.f;      \
-    p.f = p.f - (lr * mm.f) / (sqrtf(vv.f) + ad.eps);   /* adam1 with g == 0: fma(b1, m, 0) rounds like b1 m */
+    p.f = adam_move(p.f, lr * mm.f, vv.f, ad.eps);   /* adam1 with g == 0: fma(b1, m, 0) rounds like b1 m */
                 LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
 #undef LTG_ADAM0
             }
@@ -2366,7 +2380,7 @@ int fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
         hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
     }
     if (mid_fast(cfg, R)) {
-        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1, grid2(Z, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->h1, gen->p[1], gen->p[5], o->eps, o->is_training,
+        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<false>, grid2(Z, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->h1, gen->p[1], gen->p[5], o->eps, o->is_training,
                                                       cfg->seed, o->rng_step, acts->mulv, acts->z));
         LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6],
                                                       acts->kl_rows, acts->h2));
@@ -2911,7 +2925,7 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
                             const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false,
-                            bool only_dec1 = false) {
+                            bool only_dec1 = false, int dw_groups = 0) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
@@ -2956,6 +2970,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
                 // ... and no more workgroups than the same number of rounds needs (782 tiles of a 25 024-item slab: 4 rounds with
                 // 224 or with 196 workgroups -- 60 CUs left to the chain and the collective running beside it)
                 if (!gk && ntl > gmax) gmax = (ntl + (ntl + gmax - 1) / gmax - 1) / ((ntl + gmax - 1) / gmax);
+                if (dw_groups > 0) gmax = dw_groups;
                 hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
                 if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
                     hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
@@ -3226,6 +3241,124 @@ int ltg_g_bwd_dec1(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
     if (ltg_workspace_bytes(cfg, bt->n_rows, fake->n) > ws_bytes) return LTG_EWORKSPACE;
     const Workspace w = carve(cfg, bt->n_rows, fake->n, (char*)ws);   // same carve as ltg_g_bwd_dec: dlog lives there
     return g_stage_bwd_rest(cfg, gen, bt, o, acts, nullptr, w, (hipStream_t)stream, true, true);
+}
+
+/* ---- the item-sharded step as ONE call, exchanges in-stream, weight update and clock slice beside the next step (include/ltg.h) ---- */
+int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows) {
+    if (!cfg_ok(cfg) || !gen || n_rows <= 0) return 0;
+    return (fast_on(cfg) && mid_fast(cfg, n_rows) && stream_ok(cfg, gen, n_rows) && dw_stream_ok(cfg->h_enc) && dlog16_ok(cfg, gen, n_rows) &&
+            q0_lazy(cfg, gen)) ? 1 : 0;
+}
+
+int ltg_g_pipe_join(const ltg_pipe* pipe, ltg_stream stream) {
+    clear_errors();
+    if (!pipe || !pipe->ev_dec1 || !pipe->ev_slice) return LTG_EINVAL;
+    if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_dec1, 0) != hipSuccess) return LTG_ELAUNCH;
+    if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_slice, 0) != hipSuccess) return LTG_ELAUNCH;
+    return LTG_OK;
+}
+
+int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
+                       const ltg_pairs* fake, const ltg_g_opts* o, const ltg_gen_acts* acts, const ltg_comm* comm,
+                       const ltg_pipe* pp, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream) {
+    clear_errors();
+    if (!g_args_ok(cfg, gen, bt, acts) || !disc || !fake || !o || !pp || !loss_out || !ws || o->adam_t < 1) return LTG_EINVAL;
+    if (!bt->uptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || fake->n < 0) return LTG_EINVAL;
+    if (bt->n_unique < 0 || (size_t)bt->n_unique > gq0_rows(cfg, bt->n_rows)) return LTG_EINVAL;
+    if (!ltg_g_step_sharded_ok(cfg, gen, bt->n_rows)) return LTG_EINVAL;
+    if (!pp->side_stream || !pp->ev_fork || !pp->ev_dec1 || !pp->ev_slice || !pp->h1pre || !pp->rowpart_all || !pp->dh2) return LTG_EINVAL;
+    const int R = comm ? comm->n_ranks : 1, rank = comm ? comm->rank : 0;
+    if (R < 1 || rank < 0 || rank >= R || (comm && (!comm->all_reduce || !comm->all_gather))) return LTG_EINVAL;
+    const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim, nf = fake->n;
+    if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream, sd = (hipStream_t)pp->side_stream;
+    hipEvent_t ev_fork = (hipEvent_t)pp->ev_fork, ev_dec1 = (hipEvent_t)pp->ev_dec1, ev_slice = (hipEvent_t)pp->ev_slice;
+    const bool fork_dec1 = (pp->flags & LTG_PIPE_NO_DEC1_FORK) == 0, fork_slice = fork_dec1 && (pp->flags & LTG_PIPE_NO_SLICE_FORK) == 0;
+    Workspace w = carve(cfg, B, nf, (char*)ws);
+    if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
+    const Probe pr{o->probe, st};
+    const AdamC ad = make_adam(cfg, o->adam_t);
+    float* rowpart = pp->rowpart_all + (size_t)rank * B * RP;   // this rank's block of the all-gather buffer: the exchange is in place
+#define LTG_HIP(x) do { if ((x) != hipSuccess) return LTG_ELAUNCH; } while (0)
+#define LTG_COMM(x) do { if ((x) != 0) return LTG_ELAUNCH; } while (0)
+    // ---- the clock slice forked by the PREVIOUS call is done (it must not meet the catch-up below on a row); the rows this batch reads
+    if (fork_slice) LTG_HIP(hipStreamWaitEvent(st, ev_slice, 0));
+    q0_touch(cfg, gen, bt, st);
+    // ---- forward: enc-0 over the local slab -> exchange 1 -> enc-1 (bias + tanh in its loader), dec-0, local logits + statistics
+    {
+        ltg_gen_acts a1 = *acts;
+        a1.h1 = pp->h1pre;
+        fwd_stage_enc(cfg, gen, bt, &o->fwd, &a1, 1, st, nullptr, true);
+    }
+    if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
+    LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,
+                                                  o->fwd.is_training, cfg->seed, o->fwd.rng_step, acts->mulv, acts->z, gen->p[4], acts->h1));
+    // (dec-0 overwrites h2, which the previous step's weight update is still reading)
+    if (fork_dec1) LTG_HIP(hipStreamWaitEvent(st, ev_dec1, 0));
+    LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
+                                                  acts->h2));
+    {
+        const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
+        LTG_PROBED(pr, LTG_K_DEC1_FWD, hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, acts->h2,
+                                                          gen->wp1t_bf16, gen->p[7], acts->logits, w.segpart));
+        g_row_partial(cfg, bt, nf > 0 ? fake : nullptr, acts, rowpart, st, w.segpart, nullptr, G);
+    }
+    if (comm) LTG_PROBED(pr, LTG_K_EXCH_ROWPART, LTG_COMM(comm->all_gather(rowpart, pp->rowpart_all, (size_t)B * RP, LTG_NCCL_FLOAT32, comm->comm, stream)));
+    // ---- backward: (fake tower when it was not evaluated ahead,) losses + dlogits
+    if (nf > 0 && !o->y_pre && !(o->fake_done & 1)) {
+        PairView pv{0, nf, nullptr, nullptr, fake->pop, fake->niche};
+        DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
+        disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, o->probe, st);
+    }
+    hipLaunchKernelGGL(k_dlogits_combine<true>, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, R, bt->indptr, bt->indices, bt->values, acts->logits,
+                       pp->rowpart_all, acts->kl_rows, nf > 0 ? w.y : (const float*)nullptr, o->cnt, o->anneal, o->gan_lambda, nf, fake->row, fake->niche, fake->pop,
+                       w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo);
+    const int qP = gen->q0_period;
+    {
+        const int kchunk = dh2_stream_chunk(I), nsplit = (I + kchunk - 1) / kchunk;
+        LTG_PROBED(pr, LTG_K_DH2, hipLaunchKernelGGL(k_dh2_stream<true>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog,
+                                                     gen->wp1t_bf16, w.part));
+        // ---- ONE fork, behind the dh2 product (the last reader of this step's W_p1t shadow), onto the side stream:
+        //   (1) the clock slice of the PREVIOUS step -- rows i = q0_ord (mod period) up to q0_ord; every row of this batch is at q0_ord
+        //       already (q0_touch), so the slice skips them whatever the rest of this step does to them; joined at the start of the next
+        //       call, before that batch's catch-up;
+        //   (2) the decoder weight update (needs dlogits and h2 only); joined before the NEXT step's dec-0
+        ltg_g_opts od = *o;
+        od.fake_done = 0;
+        od.dec1_done = 0;
+        const int dw_groups = (pp->flags >> 8) & 0x1FF;   // measurement: persistent workgroups of the weight update (0 = the library's choice)
+        hipStream_t sdw = st;
+        if (fork_dec1) {
+            LTG_HIP(hipEventRecord(ev_fork, st));
+            LTG_HIP(hipStreamWaitEvent(sd, ev_fork, 0));
+            sdw = sd;
+            if (fork_slice) {
+                const int start = gen->q0_ord % qP;
+                if (gen->q0_ord > 0 && start < I)
+                    hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1));
+                LTG_HIP(hipEventRecord(ev_slice, sd));
+            }
+        }
+        const int rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups);
+        if (rc != LTG_OK) return rc;
+        if (fork_dec1) LTG_HIP(hipEventRecord(ev_dec1, sd));
+        const int n = B * H;
+        hipLaunchKernelGGL(k_da2, dim3((n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048), dim3(NT), 0, st, n, nsplit, w.part, (const float*)nullptr, pp->dh2);
+    }
+    if (comm) LTG_PROBED(pr, LTG_K_EXCH_DH2, LTG_COMM(comm->all_reduce(pp->dh2, pp->dh2, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
+    // ---- the replicated rest: dz (tanh derivative in its loader) -> dh1 -> sparse W_q0 gradient + its Adam step -> the other updates
+    LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz_dh2, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, pp->dh2, acts->h2, gen->p[2], acts->mulv, o->fwd.eps,
+                                                o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv, w.da2));
+    LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
+    g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad);
+    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true);
+    if (!fork_slice) {   // the slice of THIS step at its end, in program order (the cut-point schedule)
+        const int ord = gen->q0_ord + 1, start = ord % qP;
+        if (start < I) hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, st, I, H, start, qP, ord, *gen, make_adam(cfg, 1));
+    }
+#undef LTG_HIP
+#undef LTG_COMM
+    return check_launch();
 }
 
 int ltg_refresh_d_shadow(const ltg_config* cfg, const ltg_disc_state* d, ltg_stream stream) {

@@ -19,7 +19,8 @@
 //
 // Operand functors come in pairs (no branches; the block clamps indices into range, mirrors rows / columns beyond M / N onto
 // the last one -- the epilogue skips them -- and zeroes the A fragment of k blocks beyond K):
-//   a_ld(i, m, k) -> RAW {A(m,k), A(m,k+1), A(m,k+2), A(m,k+3)}: memory requests only, no arithmetic on what they return
+//   a_ld(i, m, k) -> RAW {A(m,k), A(m,k+1), A(m,k+2), A(m,k+3)} (or a struct of several such requests that a_xf folds into one
+//   operand, e.g. a value and the activation its derivative needs): memory requests only, no arithmetic on what they return
 //   a_xf(raw, i, m, k) -> the operand values (rounding, scaling, masks, ones-augmentation)           same for b_ld(i, k, n) / b_xf
 //   with k % 4 == 0 and i = the index of the k block within the pass.  The split is what makes "one round trip" real:
 //   phase 1 of a pass holds nothing but address arithmetic and loads, a scheduling barrier closes it, and only then do the
@@ -102,7 +103,8 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
     for (int base = 0; base < per; base += NBLK) {
-        ltg_f32x4 ra[NBLK][TM], rb[NBLK][TN];
+        decltype(a_ld(0, 0, 0)) ra[NBLK][TM];   // RAW operand requests: a float4, or a small struct of them (a_xf folds it)
+        decltype(b_ld(0, 0, 0)) rb[NBLK][TN];
         // phase 1: requests only
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) {

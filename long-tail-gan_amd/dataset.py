@@ -134,6 +134,9 @@ def batch_csc(tr, lo, hi, n_items):
     return slot, uptr, row_of[order].astype(np.int32), pos[order].astype(np.int32)
 
 
+SLOT_CACHE_BYTES = 1 << 30     # budget of the per-batch item -> gradient-row maps (n_batches x I int32)
+
+
 class DeviceData:
     """IndexData uploaded to HBM + per-batch views (ctypes structs with the right offsets)."""
 
@@ -142,7 +145,8 @@ class DeviceData:
         cut (columns [item_lo, item_hi), re-indexed from 0); pair / candidate / popular lists keep global ids
         and are identical on every rank.
         slot_cache: keep the per-batch item -> gradient-row maps (n_batches x I int32) on the device; None = for item slabs
-        below 65 536 items (two launches = ~16 us fewer per G step; 1 GB for 10 000 batches of a 25 000-item slab).  Without
+        below 65 536 items whose maps take at most SLOT_CACHE_BYTES in total (two launches = ~16 us fewer per G step of the
+        dense W_q0 sweep; the maps are first built on the host, so the bound is on host AND device memory).  Without
         it the library rebuilds the map of a batch in its workspace each step -- measured FASTER at I = 200 000 (50.3 vs
         56.5 ms per 32-step epoch: the one map in the workspace stays in L2, 64 cold 800-KB maps do not) and it removes
         the n_batches x I memory (8 GB at 10 000 batches)."""
@@ -167,7 +171,7 @@ class DeviceData:
         self.values = None if ones else up(tr.data, np.float32)
         slots, uptrs, rowidx, cpos, ent_off, uptr_off = [], [], [], [], [0], [0]
         if slot_cache is None:
-            slot_cache = I < 65536
+            slot_cache = I < 65536 and self.n_batches * I * 4 <= SLOT_CACHE_BYTES
         for b in range(self.n_batches):
             lo, hi = b * self.BS, min(N, (b + 1) * self.BS)
             sl, up_, ri, ps = batch_csc(tr, lo, hi, I)

@@ -115,6 +115,26 @@ class Pairs:
         self.c = cabi.ltg_pairs(self.n, 0, _ptr(pop, off), _ptr(niche, off), _ptr(row, off))
 
 
+class Pipe:
+    """Caller-owned side stream, events and exchange buffers of ltg_g_step_sharded (include/ltg.h: ltg_pipe) for batches of up to
+    `rows` rows exchanged between `n_ranks` ranks."""
+
+    def __init__(self, engine, rows, n_ranks=1, flags=0):
+        from ._hip import EventPair
+        dev = engine.device
+        self.side_stream = torch.cuda.Stream(dev)
+        self._ev = (EventPair(timing=False), EventPair(timing=False))     # (fork, dec1), (slice, -)
+        f = dict(dtype=torch.float32, device=dev)
+        self.h1pre = torch.zeros(rows, engine.H, **f)
+        self.rowpart_all = torch.zeros(n_ranks * rows * 5, **f)
+        self.dh2 = torch.zeros(rows, engine.H, **f)
+        self.c = cabi.ltg_pipe(self.side_stream.cuda_stream, self._ev[0].start, self._ev[0].stop, self._ev[1].start, _ptr(self.h1pre),
+                               _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0)
+
+    def buffers(self):
+        return [self.h1pre, self.rowpart_all, self.dh2]
+
+
 class Engine:
     def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
                  precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8,
@@ -149,6 +169,8 @@ class Engine:
             lazy_q0 = os.environ.get("LTGAN_LAZY_Q0", "1") != "0"   # measurement switch: 0 = dense sweep every step
         self.lazy_q0 = bool(lazy_q0) and self.I >= 8192
         self.q0_period = int(q0_period)
+        if self.lazy_q0 and not 1 <= self.q0_period <= cabi.LTG_Q0_HIST // 2:
+            raise ValueError("q0_period must be in [1, %d] (the clock's ring keeps the last %d step sizes)" % (cabi.LTG_Q0_HIST // 2, cabi.LTG_Q0_HIST))
         self.q0_defer = False                                        # True: the caller flushes (end of its G phase)
         self.q0_sweep_overlap = os.environ.get("LTGAN_Q0_OVERLAP", "1") != "0"   # measurement switch
         self._q0_dirty = False
@@ -397,6 +419,10 @@ class Engine:
         if self.lazy_q0 and self._q0_dirty:
             cabi.check(self.lib.ltg_g_flush(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_g_flush")
             self._q0_dirty = False
+            # every row is current: restart the ordinals (the int32 clock never grows without bound; stream order keeps the
+            # memset behind the flush kernel)
+            self.q0_last.zero_()
+            self.gen_c.q0_ord = 0
 
     # ------------------------------------------------------------------ the G step cut at its exchange points
     def fwd_opts(self, keep_prob=0.75, is_training=0.0, rng_step=0, drop_keep=None, eps=None, probe=None):
@@ -408,6 +434,29 @@ class Engine:
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
         return cabi.ltg_g_opts(f, anneal, gan_lambda, d_keep_prob, self.next_adam_t(), d_rng_step, df, _ptr(cnt), _pp(probe),
                                *self._fork_handles(), 0, 0, None, _ptr(y_pre, y_off))      # ltg_g_bwd_rest forks / joins inside the call
+
+    # ------------------------------------------------------------------ the item-sharded G step as ONE call
+    def sharded_step_ok(self, rows):
+        """ltg_g_step_sharded serves this engine's configuration (bf16 + shadow, lazy clock, slab of >= 8192 items, <= 128 rows)"""
+        if not hasattr(self.lib, "ltg_g_step_sharded_ok"):      # an older build loaded through LTG_HIP_LIB (A/B timing)
+            return False
+        return bool(self.lib.ltg_g_step_sharded_ok(C.byref(self.cfg), C.byref(self.gen_c), int(rows)))
+
+    def g_step_sharded(self, batch, fake, acts, gopts, pipe, comm=None, loss_out=None):
+        """every launch of the step and its exchanges from one call (comm: _rccl.RcclComm / HostComm; None = one rank)"""
+        loss_out = self.loss_buf if loss_out is None else loss_out
+        ws = self.workspace(batch.n_rows, fake.n)
+        rc = self.lib.ltg_g_step_sharded(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
+                                         C.byref(gopts), C.byref(acts.c), C.byref(comm.c) if comm is not None else None, C.byref(pipe.c),
+                                         _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
+        cabi.check(rc, "ltg_g_step_sharded")
+        if not self.q0_defer:
+            self.pipe_join(pipe)       # a standalone step: nothing stays in flight behind the call (a trainer joins once per phase)
+        self._q0_stepped()
+        return loss_out
+
+    def pipe_join(self, pipe):
+        cabi.check(self.lib.ltg_g_pipe_join(C.byref(pipe.c), self.stream()), "ltg_g_pipe_join")
 
     def g_fwd_enc(self, batch, acts, fopts):
         cabi.check(self.lib.ltg_g_fwd_enc(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(fopts), C.byref(acts.c),

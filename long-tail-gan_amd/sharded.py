@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine import _ptr
+from .engine import Pipe, _ptr
 from .trainer import Trainer, eval_chunk_rows
 
 D_SPLIT_MIN_PARAMS = 1_000_000
@@ -68,7 +68,34 @@ class ShardedTrainer(Trainer):
         self.dec1_overlap = os.environ.get("LTGAN_DEC1_OVERLAP", "1") != "0"     # measurement switch
         self._ev_dlog, self._ev_dec1 = torch.cuda.Event(), torch.cuda.Event()
         engine.workspace(Bc, data.max_pairs)       # sized once: the side stream must never see it reallocated
+        self._init_sharded_step(engine, B)
         self.cand_logit = torch.zeros(max(1, int(data.idx.cand_ptr[-1])), dtype=torch.float32, device=dev)
+
+    def _init_sharded_step(self, engine, B):
+        """ltg_g_step_sharded (one call per G step, exchanges in-stream) when the library serves this configuration.  Transport:
+        RCCL bound directly (backend "nccl": the library calls ncclAllReduce / ncclAllGather itself on the step's stream), or host
+        callbacks over the group for test rigs whose ranks share a GPU (gloo).  LTGAN_SHARDED_STEP=0: the cut-point sequence."""
+        from ._rccl import HostComm, RcclComm
+        self.pipe, self.comm = None, None
+        if os.environ.get("LTGAN_SHARDED_STEP", "1") == "0" or not engine.sharded_step_ok(B):
+            return
+        self.pipe = Pipe(engine, B, self.R, flags=int(os.environ.get("LTGAN_PIPE_FLAGS", "0")))
+        if dist.get_backend(self.group) == "nccl" and os.environ.get("LTGAN_COMM", "rccl") == "rccl":
+            comm, err = None, ""
+            try:
+                comm = RcclComm(self.group, engine.device)
+            except Exception as e:                # (every rank must take the same branch: agree below)
+                err = repr(e)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=engine.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 1:
+                self.comm = comm
+                return
+            if comm is not None:
+                comm.close()
+            if self.rank == 0:
+                print("ltgan.sharded: direct RCCL communicator unavailable (%s); exchanges go through torch.distributed" % err, flush=True)
+        self.comm = HostComm(self.group, self.pipe.buffers())
 
     # -- collectives -------------------------------------------------------------------------------
     def _allreduce(self, t):
@@ -138,61 +165,52 @@ class ShardedTrainer(Trainer):
                 eng.d_apply(self.d_grad, loss_out=self.d_losses[j])
         return self.d_losses
 
-    def g_phase(self):
+    def _g_one(self, j, b, v, a):
+        """one generator update of batch b over the item shards"""
         d, eng = self.data, self.eng
-        self.last_anneal = []
-        eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
-        eng.pin_stream()
-        self._tower_ahead()        # every fake tower of the phase in a few large launches (replicated on every rank)
-        for j in range(self.S):
-            a = self.anneal()
-            for k in self.order:
-                b = self.active[k]
-                v = d.view(b)
-                a = self.anneal()
-                self.update_count += 1
-                B = v["batch"].n_rows
-                pr = self.probe_hook("g", b) if self.probe_hook else None
-                rs, ds = self._step(), self._step()
-                if self.batched_tower and ds != self._tower_steps[j, b]:
-                    raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
-                go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, rs, ds, probe=pr,
-                                y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
-                if self.fake_overlap and v["fake"].n > 0 and not self.batched_tower:
-                    # the fake tower (replicated, needs nothing of the generator) on a side stream, beside the forward and its
-                    # two exchanges; ordered after the previous step's reader of its outputs, joined before this step's
-                    main = torch.cuda.current_stream()
-                    self._ev_fork.record(main)
-                    self._side.wait_event(self._ev_fork)
-                    eng.g_fake_tower(v["batch"], v["fake"], go, stream=self._side)
-                    self._ev_join.record(self._side)
-                rp_all = self._forward(v, v["fake"], go.fwd)
-                if go.fake_done:
-                    torch.cuda.current_stream().wait_event(self._ev_join)
-                eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
-                if self.dec1_overlap:
-                    # the decoder weight update (HBM-bound, the largest kernel; needs only dlog and h2) on the side stream with 224
-                    # of its 256 workgroups; exchange 3 and then the rest of the backward chain (which needs only the all-reduced
-                    # dh2) run beside it on the CUs that leaves free.  Joined before the next forward reads W_p1t.
-                    main = torch.cuda.current_stream()
-                    self._ev_dlog.record(main)
-                    self._side.wait_event(self._ev_dlog)
-                    eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go, stream=self._side)
-                    self._ev_dec1.record(self._side)
-                    self._allreduce(self.dh2[:B])
-                    eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
-                    main.wait_event(self._ev_dec1)
-                else:
-                    # exchange 3 flies while the decoder weight update (which needs none of it) runs
-                    work = dist.all_reduce(self.dh2[:B], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go)
-                    work.wait()
-                    eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
-            self.last_anneal.append(a)
-        eng.q0_defer = False
-        eng.g_flush()
-        eng.pin_stream(False)
-        return self.g_losses
+        B = v["batch"].n_rows
+        pr = self.probe_hook("g", b) if self.probe_hook else None
+        rs, ds = self._step(), self._step()
+        if self.batched_tower and ds != self._tower_steps[j, b]:
+            raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
+        go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, rs, ds, probe=pr,
+                        y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
+        if self.pipe is not None:
+            # ONE call: every launch of the step and its three exchanges in-stream (ltg_g_step_sharded)
+            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j])
+            return
+        # the step cut at its exchange points, collectives through torch.distributed (configurations ltg_g_step_sharded does not
+        # serve: fp32 decoder operands, small slabs, the dense W_q0 sweep)
+        if self.fake_overlap and v["fake"].n > 0 and not self.batched_tower:
+            # the fake tower (replicated, needs nothing of the generator) on a side stream, beside the forward and its
+            # two exchanges; ordered after the previous step's reader of its outputs, joined before this step's
+            main = torch.cuda.current_stream()
+            self._ev_fork.record(main)
+            self._side.wait_event(self._ev_fork)
+            eng.g_fake_tower(v["batch"], v["fake"], go, stream=self._side)
+            self._ev_join.record(self._side)
+        rp_all = self._forward(v, v["fake"], go.fwd)
+        if go.fake_done:
+            torch.cuda.current_stream().wait_event(self._ev_join)
+        eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
+        if self.dec1_overlap:
+            # the decoder weight update (HBM-bound, the largest kernel; needs only dlog and h2) on the side stream with 224
+            # of its 256 workgroups; exchange 3 and then the rest of the backward chain (which needs only the all-reduced
+            # dh2) run beside it on the CUs that leaves free.  Joined before the next forward reads W_p1t.
+            main = torch.cuda.current_stream()
+            self._ev_dlog.record(main)
+            self._side.wait_event(self._ev_dlog)
+            eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go, stream=self._side)
+            self._ev_dec1.record(self._side)
+            self._allreduce(self.dh2[:B])
+            eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
+            main.wait_event(self._ev_dec1)
+        else:
+            # exchange 3 flies while the decoder weight update (which needs none of it) runs
+            work = dist.all_reduce(self.dh2[:B], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            eng.g_bwd_dec1(v["batch"], v["fake"], self.acts, go)
+            work.wait()
+            eng.g_bwd_rest(v["batch"], v["fake"], self.acts, go, self.dh2)
 
 
 class ShardedEvaluator:

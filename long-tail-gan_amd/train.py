@@ -20,6 +20,8 @@ import glob
 import os
 import sys
 
+import numpy as np
+
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import ltgan  # noqa: F401  (alias of this package directory)
@@ -62,7 +64,20 @@ def _full(ts, eng, world):
     return out
 
 
-CKPT_FORMAT = 2      # 2: every tensor in the reference variable's TF shape (weight_p_1to2 = [600, n_items]); shuffle RNG state saved
+CKPT_FORMAT = 3      # 2: every tensor in the reference variable's TF shape (weight_p_1to2 = [600, n_items]); shuffle RNG state saved
+                     # 3: the shuffle RNG state as plain types (tensor + numbers), so that a file loads with weights_only=True
+
+
+def _rng_state_plain(state):
+    """np.random.RandomState.get_state() -> (name, uint32 keys as an int64 tensor, pos, has_gauss, cached_gaussian): no pickled ndarray"""
+    import torch
+    name, keys, pos, has_gauss, gauss = state
+    return [str(name), torch.from_numpy(np.asarray(keys, dtype=np.int64)), int(pos), int(has_gauss), float(gauss)]
+
+
+def _rng_state_numpy(plain):
+    name, keys, pos, has_gauss, gauss = plain
+    return (str(name), keys.numpy().astype(np.uint32), int(pos), int(has_gauss), float(gauss))
 
 
 def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
@@ -73,7 +88,7 @@ def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
     a truncated model_<i>.pt for `to_restore` to pick up."""
     import torch
     st = {"format": CKPT_FORMAT, "epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step,
-          "shuffle_rng_state": tr.np_rng.get_state(), "d_w1": eng.d_emb.cpu()}
+          "shuffle_rng_state": _rng_state_plain(tr.np_rng.get_state()), "d_w1": eng.d_emb.cpu()}
     eng.g_flush()                                      # lazy Adam clock of W_q0: every row up to date before it is read
     gp, gm, gv = _full(eng.g_p, eng, world), _full(eng.g_m, eng, world), _full(eng.g_v, eng, world)     # collective: every rank
     for i, n in enumerate(G_NAMES):
@@ -88,13 +103,24 @@ def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
 
 
 def load_checkpoint(path, eng, tr):
+    """Files of this build (format 3) hold tensors and plain numbers only and are read with weights_only=True -- a model file
+    is user input (`to_restore`, test.py's argument) and a full unpickle would run whatever it carries.  Older files (format
+    <= 2 pickled the numpy RNG state) need LTGAN_TRUST_CHECKPOINT=1."""
+    import pickle
     import torch
-    st = torch.load(path, map_location="cpu", weights_only=False)
+    try:
+        st = torch.load(path, map_location="cpu", weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if os.environ.get("LTGAN_TRUST_CHECKPOINT", "0") != "1":
+            raise RuntimeError("%s does not load with weights_only=True (a checkpoint of an older build pickles a numpy object); set "
+                               "LTGAN_TRUST_CHECKPOINT=1 to unpickle a file you trust" % path) from e
+        st = torch.load(path, map_location="cpu", weights_only=False)
     if st.get("format", 1) >= 2:                     # TF shape [H, I] -> the engine's item-major [I, H]
         for k in ("weight_p_1to2", "weight_p_1to2/Adam", "weight_p_1to2/Adam_1"):
             st[k] = st[k].t().contiguous()
     if "shuffle_rng_state" in st:
-        tr.np_rng.set_state(st["shuffle_rng_state"])
+        rs = st["shuffle_rng_state"]
+        tr.np_rng.set_state(_rng_state_numpy(rs) if st.get("format", 1) >= 3 else rs)
     eng.set_generator([st[n].numpy() for n in G_NAMES], [st[n + "/Adam"].numpy() for n in G_NAMES],
                       [st[n + "/Adam_1"].numpy() for n in G_NAMES])
     eng.set_discriminator(st["d_w1"].numpy(), [st[n].numpy() for n in D_NAMES], [st[n + "/Adam"].numpy() for n in D_NAMES],

@@ -17,16 +17,17 @@ import numpy as np
 import torch
 
 from .dataset import DeviceData, EvalData
-from .engine import Engine
+from .engine import Engine, Pipe
 
 
 CREATE_LOGITS_BYTES = 1 << 30      # logits of one phase-C span (rows x I x 4)
+PIPE_MAX_ITEMS = 65536             # item slabs below this run the G step through ltg_g_step_sharded (one call, pipelined)
 TOWER_PAIRS = 1 << 17              # fake pairs per launch of the batched fake tower (activations: pairs x (h1 + h2 + 2 h3) x 4 bytes)
 
 
 class Trainer:
     def __init__(self, engine: Engine, data: DeviceData, num_sub_epochs=10, gan_lambda=1.0, total_anneal_steps=20000,
-                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None, batched_tower=None):
+                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None, batched_tower=None, pipe_step=None):
         self.eng, self.data = engine, data
         if span_create is None:
             span_create = os.environ.get("LTGAN_SPAN_CREATE", "1") != "0"    # measurement switch
@@ -57,6 +58,14 @@ class Trainer:
             engine.workspace(data.max_rows, max(data.max_pairs, max(t["fake"].n for t in self._towers)))
         self.active = list(range(data.n_batches))
         self.order = np.arange(data.n_batches)
+        # large item slabs: the whole G step as ONE call with the decoder weight update and the lazy clock's slice running beside
+        # the next step (ltg_g_step_sharded; here without a communicator).  LTGAN_PIPE_STEP: 0 = off, 1 = whenever the library
+        # supports the configuration, default = slabs below PIPE_MAX_ITEMS (above, a step is two HBM sweeps and the chain already
+        # hides beside them inside ltg_g_step)
+        self.pipe, self.comm = None, None
+        mode = os.environ.get("LTGAN_PIPE_STEP", "auto") if pipe_step is None else ("1" if pipe_step else "0")
+        if mode != "0" and engine.sharded_step_ok(data.max_rows) and (mode == "1" or engine.I < PIPE_MAX_ITEMS):
+            self.pipe = Pipe(engine, data.max_rows, 1, flags=int(os.environ.get("LTGAN_PIPE_FLAGS", "0")))
         dev = engine.device
         self.d_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
         self.g_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
@@ -99,12 +108,14 @@ class Trainer:
     def d_phase(self):
         d, eng = self.data, self.eng
         eng.pin_stream()
-        for j in range(self.S):
-            for k in self.order:
-                v = d.view(self.active[k])
-                pr = self.probe_hook("d", self.active[k]) if self.probe_hook else None
-                eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j], probe=pr)
-        eng.pin_stream(False)
+        try:
+            for j in range(self.S):
+                for k in self.order:
+                    v = d.view(self.active[k])
+                    pr = self.probe_hook("d", self.active[k]) if self.probe_hook else None
+                    eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j], probe=pr)
+        finally:
+            eng.pin_stream(False)           # (also when a step raised: nothing may stay pinned to a stale stream handle)
         return self.d_losses
 
     # ---------------------------------------------------------------- phase G (train.py:307-329)
@@ -130,31 +141,71 @@ class Trainer:
                 self.eng.fake_tower_batched(t["fake"], t["seg_of"], t["seg_row0"], self._seg_step[j], self.y_all, self.d_keep,
                                             seg_off=t["seg_off"], y_off=j * self.data.n_slots + t["s0"])
 
-    def g_phase(self):
-        d, eng = self.data, self.eng
+    def _g_begin(self):
         self.last_anneal = []
-        eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
-        eng.pin_stream()
-        self._tower_ahead()
-        for j in range(self.S):
-            a = self.anneal()
-            for k in self.order:
-                b = self.active[k]
-                v = d.view(b)
+        self.eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
+        self._hp_ctx = None
+        if self.pipe is not None and os.environ.get("LTGAN_G_PRIORITY", "0") == "1":
+            # measurement switch: the step's critical chain on a HIGH-priority stream, so that its short kernels are placed ahead of
+            # the forked weight update's workgroups
+            if getattr(self, "_hp_stream", None) is None:
+                self._hp_stream = torch.cuda.Stream(self.eng.device, priority=-1)
+            self._hp_stream.wait_stream(torch.cuda.current_stream(self.eng.device))
+            self._hp_ctx = torch.cuda.stream(self._hp_stream)
+            self._hp_ctx.__enter__()
+        self.eng.pin_stream()
+
+    def _g_end(self, ok):
+        """leaves the engine usable whatever happened inside the phase (a raised LtgError, a failed collective, the RNG-counter check)"""
+        eng = self.eng
+        try:
+            if self.pipe is not None:
+                eng.pipe_join(self.pipe)    # the forked weight update and clock slice of the last step
+            eng.q0_defer = False
+            if ok:
+                eng.g_flush()
+        finally:
+            eng.q0_defer = False
+            eng.pin_stream(False)
+            if self._hp_ctx is not None:
+                self._hp_ctx.__exit__(None, None, None)
+                torch.cuda.current_stream(eng.device).wait_stream(self._hp_stream)
+                self._hp_ctx = None
+
+    def _g_one(self, j, b, v, a):
+        """one generator update (train.py:326) of batch b in sub-epoch j"""
+        d, eng = self.data, self.eng
+        rs, ds = self._step(), self._step()
+        if self.batched_tower and ds != self._tower_steps[j, b]:
+            raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
+        pr = self.probe_hook("g", b) if self.probe_hook else None
+        if self.pipe is not None:
+            go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, rs, ds, probe=pr,
+                            y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
+            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j])
+        else:
+            eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
+                       keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=rs,
+                       d_rng_step=ds, loss_out=self.g_losses[j], probe=pr,
+                       y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
+
+    def g_phase(self):
+        d = self.data
+        self._g_begin()
+        ok = False
+        try:
+            self._tower_ahead()        # every fake tower of the phase in a few large launches
+            for j in range(self.S):
                 a = self.anneal()
-                self.update_count += 1
-                rs, ds = self._step(), self._step()
-                if self.batched_tower and ds != self._tower_steps[j, b]:
-                    raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
-                eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
-                           keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=rs,
-                           d_rng_step=ds, loss_out=self.g_losses[j],
-                           probe=self.probe_hook("g", b) if self.probe_hook else None,
-                           y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
-            self.last_anneal.append(a)
-        eng.q0_defer = False
-        eng.g_flush()
-        eng.pin_stream(False)
+                for k in self.order:
+                    b = self.active[k]
+                    a = self.anneal()
+                    self.update_count += 1
+                    self._g_one(j, b, d.view(b), a)
+                self.last_anneal.append(a)
+            ok = True
+        finally:
+            self._g_end(ok)
         return self.g_losses
 
     def epoch(self):

@@ -20,14 +20,16 @@ def main():
     from ltgan.trainer import Trainer
     workload, users, precision = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     mode = sys.argv[4] if len(sys.argv) > 4 else ""
-    d_split = mode in ("dsplit", "wide_fp8")                     # pair rows of the discriminator step split over the ranks
-    wide = mode == "wide_fp8"                                    # BASELINE config 5 inside the sharded loop: wide discriminator, fp8 GEMM operands
+    d_split = mode in ("dsplit", "wide_fp8", "wide_fp8_full")    # pair rows of the discriminator step split over the ranks
+    wide = mode in ("wide_fp8", "wide_fp8_full")                 # BASELINE config 5 inside the sharded loop: wide discriminator, fp8 GEMM operands
+    if mode == "cutpoints":                                      # the G step cut at its exchange points (torch.distributed collectives)
+        os.environ["LTGAN_SHARDED_STEP"] = "0"                   # instead of the one-call step with in-stream exchanges
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda:0"
     idx, _ = synthetic_index(workload, users=users, seed=5)
     I = idx.n_items
-    hs = (512, 256, 256, 128) if wide else (16, 24, 40, 32)
+    hs = (2048, 1024, 512, 256) if mode == "wide_fp8_full" else ((512, 256, 256, 128) if wide else (16, 24, 40, 32))
     dq = "fp8" if wide else "fp32"
     S = 2
     # ---- unsharded reference
@@ -39,6 +41,9 @@ def main():
     data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
     tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1, d_split=d_split)
     assert tr.d_split == d_split
+    one_call = precision == "bf16" and hi - lo >= 8192 and mode != "cutpoints"
+    assert (tr.pipe is not None) == one_call and (tr.comm is not None) == one_call, (tr.pipe, tr.comm)
+    p0 = [t.clone() for t in ref.g_p]                            # initial variables: the runs are compared by how far they MOVE
     # ---- ranking metrics over the shards (before training: parameters are identical, only the all-reduce order differs)
     import scipy.sparse as sp
     from ltgan.dataset import EvalData
@@ -83,13 +88,27 @@ def main():
         np.testing.assert_allclose(gl[:, :2], gl_ref[:, :2], rtol=tol)
         np.testing.assert_allclose(gl[:, 2:], gl_ref[:, 2:], rtol=10 * tol, atol=1e-6)
     torch.cuda.synchronize()
-    atol = 2e-6 if precision == "fp32" else 3e-4
+    # Generator tensors: 2 epochs x S x (active batches) Adam steps at lr 1e-3 move an element by a few 1e-3 in total, so an absolute
+    # bound near that size cannot fail.  Compare the MOVES: mean |difference| against the mean distance travelled, and the share of
+    # elements that went somewhere else altogether (an element whose gradient is within rounding of zero takes sign-like Adam
+    # steps: it may legitimately go the other way in a run that adds its partial sums in another order).
+    eng.g_flush()
+    ref.g_flush()
+    torch.cuda.synchronize()
     for i in range(8):
-        want = ref.g_p[i]
+        want, init = ref.g_p[i], p0[i]
         if i in (0, 3, 7):
-            want = want[lo:hi]
-        err = (eng.g_p[i] - want).abs().max().item()
-        assert err < atol * 50 if i not in (0, 3, 7) else err < atol * 50, ("gen tensor", i, err)
+            want, init = want[lo:hi], init[lo:hi]
+        mv_ref, mv = (want - init).double(), (eng.g_p[i] - init).double()
+        travel = mv_ref.abs().mean().item()       # (rows of W_q0 no user of the run holds never move: the mean is over all of them)
+        assert mv_ref.abs().max().item() > 1e-4 and travel > 0, ("the reference run did not move tensor", i)
+        diff = (mv - mv_ref).abs()
+        rel_mean = diff.mean().item() / travel
+        astray = (diff > 0.25 * mv_ref.abs().max().item()).double().mean().item()
+        lim = (2e-3, 2e-4) if precision == "fp32" else (3e-2, 3e-3)
+        if wide:
+            lim = (1e-1, 1e-2)
+        assert rel_mean < lim[0] and astray < lim[1], ("gen tensor", i, rel_mean, astray, travel)
     for i in range(8):
         dd = (eng.d_p[i] - ref.d_p[i]).abs()
         if wide:     # four D steps; an element whose gradient is within rounding of zero moves by up to 3.2 lr_t per step in either direction

@@ -12,6 +12,8 @@ so the gate is statistical, as SURVEY 8/d6 defines it.
 
 Pure restatement output: no reference source is read, no GPU is used.
 usage: python tests/golden/make_ndcg_gate.py [threads]     (about 1 minute per global epoch on 8 cores)
+       python tests/golden/make_ndcg_gate.py [threads] long  -> ndcg_gate_long.npz: 2 seeds x 30 global epochs (the gate further
+                                                                  along config.ini's 80-epoch schedule, train.py:369)
 """
 import os
 import sys
@@ -42,6 +44,9 @@ def initial_variables(n_items, seed):
 
 if __name__ == "__main__":
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else None
+    out = "ndcg_gate.npz"
+    if len(sys.argv) > 2 and sys.argv[2] == "long":
+        SEEDS, EPOCHS, out = (11, 12), 30, "ndcg_gate_long.npz"
     d = tempfile.mkdtemp()
     materialize_askubuntu(os.path.join(ROOT, "tests", "golden", "askubuntu_raw.npz"), d)
     idx = IndexData.from_dir(d)
@@ -57,5 +62,9 @@ if __name__ == "__main__":
             port.run(0, nb, S)
             curves[si, e] = port.validate(vtr, vte)
             print("seed", seed, "epoch", e, "ndcg/r20/r50", curves[si, e], "%.0fs" % (time.time() - t0), flush=True)
-        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ndcg_gate.npz"), seeds=np.array(SEEDS[:si + 1]), epochs=EPOCHS, S=S,
+            # (saved after every epoch: a partial curve of the running seed is kept in `partial`)
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", out), seeds=np.array(SEEDS[:si]), epochs=EPOCHS, S=S,
+                                hs=np.array(HS), lr=LR, batch_size=BS, curves=curves[:si], d_seed_offset=1000,
+                                partial=curves[si, :e + 1])
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", out), seeds=np.array(SEEDS[:si + 1]), epochs=EPOCHS, S=S,
                             hs=np.array(HS), lr=LR, batch_size=BS, curves=curves[:si + 1], d_seed_offset=1000)

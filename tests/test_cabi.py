@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     lib = cabi.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 9
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 10
 
 
 def test_struct_layouts_match_header():
@@ -37,6 +37,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_g_opts) == C.sizeof(cabi.ltg_fwd_opts) + 16 + 8 + 8 * 8 + 24 and cabi.ltg_g_opts.dec1_done.offset == C.sizeof(cabi.ltg_g_opts) - 24
     assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8 + 8
     assert C.sizeof(cabi.ltg_probe) == 8 + 16
+    assert C.sizeof(cabi.ltg_comm) == 8 + 8 + 2 * 8 and cabi.ltg_comm.all_reduce.offset == 16
+    assert C.sizeof(cabi.ltg_pipe) == 7 * 8 + 8 and cabi.ltg_pipe.h1pre.offset == 32 and cabi.ltg_pipe.flags.offset == 56
 
 
 def test_argument_validation_returns_codes_without_gpu():
@@ -57,6 +59,28 @@ def test_argument_validation_returns_codes_without_gpu():
     assert lib.ltg_d_grad_floats(C.byref(good)) == (161001 + 1 + 3) // 4 * 4 and lib.ltg_d_grad_floats(C.byref(bad)) == 0
     assert lib.ltg_sample_pairs(C.byref(good), None, None, None, None, None, None, None) == -1
     assert lib.ltg_rank_metrics(C.byref(good), None, None, None, 100, 20, 50, None, None) == -1
+    assert lib.ltg_g_step_sharded(C.byref(good), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ltg_g_step_sharded_ok(C.byref(good), None, 100) == 0 and lib.ltg_g_pipe_join(None, None) == -1
+
+
+def test_checkpoint_rng_state_round_trips_as_plain_types():
+    """format-3 model files hold tensors and plain numbers only (they load with weights_only=True): the batch-shuffle RNG state
+    (train.py:285) goes through (name, int64 tensor of the 624 keys, pos, has_gauss, cached_gaussian)."""
+    import io
+
+    import numpy as np
+    import torch
+    from ltgan.train import _rng_state_numpy, _rng_state_plain
+    r = np.random.RandomState(5)
+    r.shuffle(np.arange(10))
+    r.normal()                                         # leaves a cached gaussian behind
+    buf = io.BytesIO()
+    torch.save({"format": 3, "shuffle_rng_state": _rng_state_plain(r.get_state())}, buf)
+    buf.seek(0)
+    st = torch.load(buf, map_location="cpu", weights_only=True)
+    r2 = np.random.RandomState(0)
+    r2.set_state(_rng_state_numpy(st["shuffle_rng_state"]))
+    assert np.array_equal(r.randint(0, 1 << 30, 50), r2.randint(0, 1 << 30, 50)) and r.normal() == r2.normal()
 
 
 def test_product_path_has_no_cpu_fallback():

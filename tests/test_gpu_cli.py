@@ -96,13 +96,13 @@ def test_train_cli_under_torchrun_item_sharded(tmp_path):
     ndcg = [float(l.split("NDCG:")[1].split()[0]) for l in txt.splitlines() if "Vad: NDCG:" in l]
     assert len(ndcg) == 1 and 0.15 < ndcg[0] < 0.5
     ck = os.path.join(cwd, "chkpt", "Askubuntu_Sample_LT_GAN_1.0", "model_0.pt")
-    st = torch.load(ck, map_location="cpu", weights_only=False)
+    st = torch.load(ck, map_location="cpu", weights_only=True)      # tensors and plain numbers only: no pickled objects in a model file
     assert not [f for f in os.listdir(os.path.dirname(ck)) if ".tmp" in f]          # written to a temporary, renamed into place
     for k in ("weight_q_0to1", "weight_q_0to1/Adam_1"):
         assert tuple(st[k].shape) == (1000, 600), k
     for k in ("weight_p_1to2", "weight_p_1to2/Adam"):                               # TF shape of the reference variable: [600, n_items]
         assert tuple(st[k].shape) == (600, 1000), k
-    assert st["format"] == 2 and st["shuffle_rng_state"][0] == "MT19937"
+    assert st["format"] == 3 and st["shuffle_rng_state"][0] == "MT19937" and tuple(st["shuffle_rng_state"][1].shape) == (624,)
     assert tuple(st["bias_p_2"].shape) == (1000,) and float(st["weight_p_1to2/Adam_1"].abs().sum()) > 0
     open(os.path.join(cwd, "config.ini"), "w").write(CONFIG.format(num_epoch=8, to_restore=1))
     env = dict(os.environ, LTGAN_MAX_EPOCHS="1")

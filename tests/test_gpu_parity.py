@@ -3,6 +3,8 @@ same seeded inputs.  Tolerances: fp32 path 2e-4 relative to the tensor's max mag
 accumulation order differs from the fp64 oracle); bf16 path 1e-3 against the oracle fed the SAME
 bf16-rounded decoder operands, which is north_star's 1e-3 relative bound.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -112,14 +114,22 @@ def _fake_pairs(rng, X, I, per_user=5):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("I,B", [(1000, 100), (333, 17), (8200, 100), (8200, 150), (20000, 100), (200000, 100)])
-def test_g_step_parity(precision, I, B):
+@pytest.mark.parametrize("I,B,path", [(1000, 100, "step"), (333, 17, "step"), (6000, 100, "step"), (6000, 100, "step-config-d"), (8200, 100, "step"),
+                                      (8200, 150, "step"), (8200, 100, "one-call"), (20000, 100, "step"), (25024, 100, "step"),
+                                      (25024, 100, "one-call-config-d"), (200000, 100, "step")])
+def test_g_step_parity(precision, I, B, path):
+    """path "step": ltg_g_step.  "one-call": ltg_g_step_sharded without a communicator (the G step of every large item slab:
+    bias + tanh and the tanh derivative folded into operand loaders, weight update and clock slice forked) -- same oracle, same
+    tolerances.  I = 6 000: the middle-layer fast path without the streaming decoder kernels (4 096 < I < 8 192); I = 25 024: the
+    slab one of eight ranks owns at 200 000 items.  "-config-d": config.ini's discriminator sizes inside the G step."""
     if I >= 20000 and precision != "bf16":
         pytest.skip("BASELINE configs 3 / 4 run the bf16 decoder path")
+    if path.startswith("one-call") and precision != "bf16":
+        pytest.skip("ltg_g_step_sharded serves the bf16 decoder path")
     import torch
-    from ltgan.engine import Pairs
+    from ltgan.engine import Pairs, Pipe
     rng, X, P = _problem(I, B, seed=11 * I + B)
-    hs = (20, 24, 40, 36)
+    hs = (100, 150, 250, 300) if path.endswith("config-d") else (20, 24, 40, 36)
     D = O.init_discriminator(I, *hs, seed=5)
     eng = _engine(I, precision, hs=hs, lr=1e-3)
     eng.set_generator(Hh.gen_to_engine(P))
@@ -135,7 +145,13 @@ def test_g_step_parity(precision, I, B):
     acts = eng.new_acts(B)
     step, dstep, keep, dkeep, anneal, lam = 3, 9, 0.75, 0.7, 0.13, 1.0
     eng.adam_t = 4  # exercise the shared counter: this update is t = 5
-    loss = eng.g_step(batch, fake, acts, cnt_t, anneal, lam, keep, 1.0, dkeep, rng_step=step, d_rng_step=dstep)
+    if path.startswith("one-call"):
+        assert eng.sharded_step_ok(B)
+        pipe = Pipe(eng, B)
+        go = eng.g_opts(cnt_t, anneal, lam, keep, 1.0, dkeep, step, dstep)
+        loss = eng.g_step_sharded(batch, fake, acts, go, pipe)
+    else:
+        loss = eng.g_step(batch, fake, acts, cnt_t, anneal, lam, keep, 1.0, dkeep, rng_step=step, d_rng_step=dstep)
     torch.cuda.synchronize()
     loss = loss.cpu().numpy()
     # ---- oracle
@@ -754,7 +770,10 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
     Xf = Hh.random_history(rng, 40, I, mean_nnz=30)                       # forward-only batch (no distinct-item list)
     fakes = [_fake_pairs(rng, X, I) for X in Xs]
     outs = []
-    for lazy in (False, True):
+    # "one-call": the lazy clock inside ltg_g_step_sharded -- the slice of step t runs on its own stream behind the row catch-up
+    # of step t + 1, the decoder weight update beside the next step's encoder half (bf16 decoder path only)
+    for variant in ("dense", "lazy") + (("one-call",) if precision == "bf16" else ()):
+        lazy = variant != "dense"
         eng = _engine(I, precision, lr=1e-3, lazy_q0=lazy, q0_period=period)
         assert eng.lazy_q0 == lazy
         eng.set_generator(Hh.gen_to_engine(P))
@@ -763,6 +782,11 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
         acts = eng.new_acts(B)
         eng.q0_defer = True
         losses, mids = [], []
+        pipe = None
+        if variant == "one-call":
+            from ltgan.engine import Pipe
+            assert eng.sharded_step_ok(B)
+            pipe = Pipe(eng, B, flags=int(os.environ.get("LTGAN_TEST_PIPE_FLAGS", "0")))
         for s in range(2 * n_batches):
             X = Xs[s % n_batches]
             rows, gen, pop = fakes[s % n_batches]
@@ -771,24 +795,36 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
             fake = Pairs(t(pop), t(gen), t(rows))
             cnt = torch.tensor([int(((gen >= 0) & (pop >= 0)).sum())], dtype=torch.int32, device=dev)
             eng.adam_t += s % 3                                           # the shared counter also moves between G steps (D steps)
-            losses.append(eng.g_step(batch, fake, acts, cnt, 0.05, rng_step=10 + s, d_rng_step=200 + s).clone())
+            if pipe is not None:
+                go = eng.g_opts(cnt, 0.05, rng_step=10 + s, d_rng_step=200 + s)
+                losses.append(eng.g_step_sharded(batch, fake, acts, go, pipe).clone())
+            else:
+                losses.append(eng.g_step(batch, fake, acts, cnt, 0.05, rng_step=10 + s, d_rng_step=200 + s).clone())
             if s == n_batches + 2:                                        # mid-phase forward: rows are caught up as they are read
+                if pipe is not None:
+                    eng.pipe_join(pipe)                                   # (the forked pieces of the last step first)
                 fa = eng.new_acts(40)
                 eng.forward(CsrRows(t(Xf.indptr.astype(np.int32)), t(Xf.indices.astype(np.int32)), 0, 40), fa)
                 mids.append(fa.logits[:40].clone())
                 mids.append(fa.h1[:40].clone())
+        if pipe is not None:
+            eng.pipe_join(pipe)
         if lazy:
             torch.cuda.synchronize()
+            assert eng.gen_c.q0_ord == 2 * n_batches
             assert int(eng.q0_last.min()) < eng.gen_c.q0_ord              # some rows really lag before the flush
-            assert int(eng.q0_last.min()) >= eng.gen_c.q0_ord - period    # ... by no more than the period
+            # ... by no more than the period (the one-call step runs a step's slice one step later)
+            assert int(eng.q0_last.min()) >= eng.gen_c.q0_ord - period - (1 if pipe is not None else 0)
         eng.q0_defer = False
         eng.g_flush()
         torch.cuda.synchronize()
         if lazy:
-            assert int(eng.q0_last.min()) == eng.gen_c.q0_ord == 2 * n_batches
+            assert eng.gen_c.q0_ord == 0 and int(eng.q0_last.max()) == 0    # every row current: the ordinals restart
         outs.append([x.cpu() for x in losses + mids + eng.g_p + eng.g_m + eng.g_v])
-    for k, (a, b) in enumerate(zip(*outs)):
-        assert torch.equal(a, b), k
+    for o in outs[1:]:
+        assert len(o) == len(outs[0])
+        for k, (a, b) in enumerate(zip(outs[0], o)):
+            assert torch.equal(a, b), k
 
 
 def test_sampler_ties_and_long_candidate_lists():
