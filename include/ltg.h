@@ -118,6 +118,11 @@ typedef struct ltg_disc_state {
     uint8_t* w1t_fp8;
     uint8_t* w2t_fp8;
     uint8_t* w3t_fp8;
+    /* optional fifth shadow (ABI v10): w3 in its OWN layout [h1+h2][h3] in e4m3 -- the operand of the backward product
+     * dpre1 = dpre3 . w3^T, which contracts over h3.  With it (and h0, h1+h2, h3 multiples of 128, h1, h2 multiples of 64) every
+     * backward GEMM of the step reads e4m3 bytes in operand format as well (csrc/ltg_fp8bwd.h); without it they convert fp32
+     * operands on the fly.  Same values either way. */
+    uint8_t* w3_fp8;
 } ltg_disc_state;
 
 /* A batch of user rows in CSR form (replaces the dense [B,I] float32 feed of train.py:194-198).

@@ -38,7 +38,7 @@ class ltg_gen_state(C.Structure):
 
 class ltg_disc_state(C.Structure):
     _fields_ = [("emb", vp), ("p", vp * 8), ("m", vp * 8), ("v", vp * 8),
-                ("emb_fp8", vp), ("w1t_fp8", vp), ("w2t_fp8", vp), ("w3t_fp8", vp)]      # optional e4m3 operand shadows
+                ("emb_fp8", vp), ("w1t_fp8", vp), ("w2t_fp8", vp), ("w3t_fp8", vp), ("w3_fp8", vp)]      # optional e4m3 operand shadows
 
 
 class ltg_batch(C.Structure):

@@ -1587,7 +1587,8 @@ __global__ __launch_bounds__(NT) void fk8s_d_l2(int n, int h12, int h3, const ui
 // (re)build the e4m3 operand shadows of the discriminator from the fp32 tensors: emb8 [F][h0] and the TRANSPOSED weights
 __global__ __launch_bounds__(NT) void k_d_shadow(int F, int h0, int h1, int h2, int h3, const float* __restrict__ emb, const float* __restrict__ w1,
                                                  const float* __restrict__ w2, const float* __restrict__ w3, uint8_t* __restrict__ emb8,
-                                                 uint8_t* __restrict__ w1t8, uint8_t* __restrict__ w2t8, uint8_t* __restrict__ w3t8) {
+                                                 uint8_t* __restrict__ w1t8, uint8_t* __restrict__ w2t8, uint8_t* __restrict__ w3t8,
+                                                 uint8_t* __restrict__ w3_8 = nullptr) {
     const size_t nE = (size_t)F * h0, n1 = (size_t)h0 * h1, n2 = (size_t)h0 * h2, n3 = (size_t)(h1 + h2) * h3;
     const size_t total = nE + n1 + n2 + n3;
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
@@ -1601,6 +1602,7 @@ __global__ __launch_bounds__(NT) void k_d_shadow(int F, int h0, int h1, int h2, 
         } else {
             const size_t i = e - nE - n1 - n2, k = i / h3, nn = i % h3;
             w3t8[nn * (size_t)(h1 + h2) + k] = ltg_f2fp8(w3[i] * (float)(1 << FP8_S_W));
+            if (w3_8) w3_8[i] = ltg_f2fp8(w3[i] * (float)(1 << FP8_S_W));
         }
     }
 }

@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, int SP, const 
             const size_t kdim = (size_t)(L.off[t + 1] - L.off[t]) / nn_w;
             uint8_t* dst = t == 0 ? st.w1t_fp8 : (t == 2 ? st.w2t_fp8 : st.w3t_fp8);
             dst[nn * kdim + k] = ltg_f2fp8(st.p[t][i] * (float)(1 << FP8_S_W));
+            if (t == 4 && st.w3_fp8) st.w3_fp8[i] = ltg_f2fp8(st.p[t][i] * (float)(1 << FP8_S_W));   // w3 in its own layout (backward operand)
         }
     }
     if (blockIdx.x == 0) {
@@ -2216,6 +2217,9 @@ struct Workspace {
     // fast path: per-column-tile partial dot products of the output unit, w4 * dA3/dpre, per-row loss terms of the G step
     float *spart, *G3, *rowout, *xd;
     uint8_t* A1_8;      // the branch layers' output in e4m3 (fp8 operand storage of the wide discriminator)
+    // operand-format storage of the fp8 backward (ltg_fp8bwd.h): transposed / row-major e4m3 copies, pair rows padded to np8
+    uint8_t *A1T_8, *dpre3_8, *dpre3T_8, *dpre1T_8, *ET_8;
+    int np8;
     size_t bytes;
 };
 // stride of one discriminator gradient slab: the P gradients + one slot for the chunk's loss sum, padded to whole float4
@@ -2267,6 +2271,17 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     w.rowout = take(R * 4);
     w.xd = take(I <= (size_t)RD_MAXI ? R * I : 1);   // dense operand rows of enc-0 (small item slabs)
     w.A1_8 = reinterpret_cast<uint8_t*>(take((P * h12 + 3) / 4));
+    {
+        const bool f8 = cfg->d_precision == LTG_PREC_FP8;      // (only that mode carries these buffers)
+        const size_t np = ((P + 127) / 128 * 128), h0 = (size_t)cfg->d_h0;
+        auto take8 = [&](size_t nbytes) { return reinterpret_cast<uint8_t*>(take(f8 ? (nbytes + 3) / 4 : 1)); };
+        w.np8 = (int)np;
+        w.A1T_8 = take8((h12 + 1) * np);
+        w.dpre3_8 = take8(P * h3);
+        w.dpre3T_8 = take8(h3 * np);
+        w.dpre1T_8 = take8(h12 * np);
+        w.ET_8 = take8(2 * (h0 + 1) * np);
+    }
     w.bytes = off;
     return w;
 }
@@ -2307,6 +2322,7 @@ inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return di
 }  // namespace
 namespace {
 #include "ltg_fast.h"
+#include "ltg_fp8bwd.h"
 }
 namespace {
 
@@ -2315,6 +2331,13 @@ namespace {
 inline bool fast_on(const ltg_config* c) { return (c->reserved0 & 262144) == 0; }
 inline bool mid_fast(const ltg_config* c, int rows) { return fast_on(c) && (c->z_dim % 4) == 0 && rows <= 256; }
 inline bool d_wide(const ltg_config* c) { return c->d_h0 >= 512 && c->d_h1 + c->d_h2 >= 512 && c->d_h3 >= 128; }
+// fp8 discriminator with EVERY GEMM operand in operand format (ltg_fp8bwd.h).  Tuning-knob bit 24 (register-resident forward
+// tiles) and bit 19 (backward converts on the fly, the round-2 path) switch it off.
+inline bool d_fp8_opfmt(const ltg_config* c, const ltg_disc_state* d) {
+    return fast_on(c) && c->d_precision == LTG_PREC_FP8 && d->emb_fp8 && d->w1t_fp8 && d->w2t_fp8 && d->w3t_fp8 && d->w3_fp8 && (c->d_h0 % 128) == 0 &&
+           ((c->d_h1 + c->d_h2) % 128) == 0 && (c->d_h3 % 128) == 0 && (c->d_h1 % 64) == 0 && (c->d_h2 % 64) == 0 && c->d_h3 <= 64 * D8_OUT_CM &&
+           (c->reserved0 & ((1 << 24) | (1 << 19))) == 0;
+}
 inline bool d_fast(const ltg_config* c) {
     return fast_on(c) && c->d_precision == LTG_PREC_FP32 && !d_wide(c) && c->d_h3 <= 512 && (c->d_h0 % 4) == 0 && ((c->d_h1 + c->d_h2) % 4) == 0 && (c->d_h3 % 4) == 0;
 }
@@ -2366,6 +2389,20 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
                                   acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, o->rows_per_step));
 }
 
+// the streaming decoder forward (stream_ok): logits of R <= 128 rows over the local slab; stat != NULL: per-group softmax statistics
+// as well.  Returns the number of statistic groups.
+// (Measured and not kept, round 3: the same loop as TWO independent 4-wave workgroups per CU -- half the batch rows each, 2 x 77 KB of
+// LDS, 244 VGPRs, bit-identical outputs -- so that one half's loads overlap the other's MFMAs and stores: 110.4 vs 107.9 us per launch
+// at 200 000 items on one box, min 81.8 vs 78.6; whole step 968-970 vs 965-968 us.  The serialisation is not inside the workgroup.)
+int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int R, const ltg_gen_acts* acts, float* stat, hipStream_t st) {
+    const int I = cfg->n_items, H = cfg->h_enc;
+    const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
+    const size_t lds = (size_t)2 * ST_BN * ST_LDW * 2;
+    if (stat) hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat);
+    else hipLaunchKernelGGL(k_dec1_fwd_stream<false>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, (float*)nullptr);
+    return G;
+}
+
 // stage 2: (bias + tanh of the all-reduced pre-activation,) enc-1, reparameterisation, dec-0, dec-1 over the local slab
 // stat (optional scratch of segpart_floats()): the streaming decoder kernel leaves its per-workgroup softmax statistics there;
 // returns the number of workgroups that wrote them (0: the caller reads the logits for the statistics)
@@ -2403,14 +2440,10 @@ int fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
             if (bf) hipLaunchKernelGGL(fk_dec1<true>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
             else hipLaunchKernelGGL(fk_dec1<false>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         } else if (stream_ok(cfg, gen, R)) {
-            const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
-            if (stat && (cfg->reserved0 & (1 << 21)) == 0) {   // (tuning-knob bit 21: statistics from a second pass over the logits)
-                hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H, acts->h2, gen->wp1t_bf16,
-                                   gen->p[7], acts->logits, stat);
-                stat_groups = G;
-            } else
-                hipLaunchKernelGGL(k_dec1_fwd_stream<false>, dim3(G), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, R, I, H, acts->h2, gen->wp1t_bf16,
-                                   gen->p[7], acts->logits, (float*)nullptr);
+            if (stat && (cfg->reserved0 & (1 << 21)) == 0)   // (tuning-knob bit 21: statistics from a second pass over the logits)
+                stat_groups = launch_dec1_fwd_stream(cfg, gen, R, acts, stat, st);
+            else
+                launch_dec1_fwd_stream(cfg, gen, R, acts, nullptr, st);
         } else if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dec1_fwd<true, false, true>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf) hipLaunchKernelGGL((k_dec1_fwd<true, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
@@ -2522,6 +2555,18 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     if (md == 2 && fast_on(cfg) && d->emb_fp8 && d->w1t_fp8 && d->w2t_fp8 && d->w3t_fp8 && (h0 % 64) == 0 && (h12 % 64) == 0) {
         // operand-format storage: both forward layers read e4m3 bytes (embedding table, transposed weight shadows, A1 in e4m3)
         const bool staged = (h0 % 128) == 0 && (h12 % 128) == 0 && (cfg->reserved0 & (1 << 24)) == 0;   // LDS-staged tiles (knob bit 24: register-resident)
+        if (with_bwd && d_fp8_opfmt(cfg, d)) {
+            // the step's own forward: the same products, and every activation the backward multiplies is left behind in e4m3 in the
+            // orientation its GEMM contracts over (ltg_fp8bwd.h)
+            const int NP = d8_np(n);
+            hipLaunchKernelGGL(k8_gather_t, dim3(h0 / 64, NP / 64, 2), dim3(NT), 0, st, pv, h0, NP, d->emb_fp8, w.ET_8);
+            LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL((fk8t_d_l1<64, 64>), dim3((h1 + 63) / 64 + (h2 + 63) / 64, NP / 64), dim3(NT), 0, st, pv, h0, h1, h2, NP,
+                                                          d->emb_fp8, d->w1t_fp8, d->p[1], d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.A1, w.A1_8, w.A1T_8));
+            LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL((fk8s_d_l2<64, 64>), grid2(h3, n, 64, 64), dim3(NT), 0, st, n, h12, h3, w.A1_8, d->w3t_fp8, d->p[5], dC, keep,
+                                                          cfg->seed, step, w.A3));
+            hipLaunchKernelGGL(k8_d_out, dim3(NP / 16), dim3(NT), 0, st, pv, h3, NP, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3_8, w.dpre3T_8);
+            return;
+        }
         if (staged) {
             // 64 x 64 tiles: 696 workgroups of 37 KB LDS, three or four per CU hide each other's load latency (measured at 1 820 pair
             // rows: 30-32 us; 128 x 128 tiles = 180 workgroups, one per CU, 54 us; 128 x 64: 60 us; register-resident block: 52 us)
@@ -2611,6 +2656,15 @@ static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLa
     int ga = ((flat ? P / 4 : P) + NT - 1) / NT;
     if (ga > 1024) ga = 1024;
     if (ga < 1) ga = 1;
+    if (d_fp8_opfmt(cfg, disc)) {
+        // operand-format shadows follow the weights: tile-wise sweep with the transposed e4m3 copies written through LDS
+        const int h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3;
+        const int nt1 = (h0 / 64) * (h1 / 64), nt2 = (h0 / 64) * (h2 / 64), nt3 = ((h1 + h2) / 64) * (h3 / 64);
+        const int nflat = (h1 + h2 + 2 * h3 + 1 + NT - 1) / NT;
+        LTG_PROBED(pr, LTG_K_D_ADAM, hipLaunchKernelGGL(k8_d_adam, dim3(nt1 + nt2 + nt3 + nflat + 1), dim3(NT), 0, st, ks, L, stride, h0, h1, h2, h3, nt1, nt2, nt3, slab,
+                                                        *disc, ad, n, lrow, loss_out));
+        return;
+    }
     pr.before(LTG_K_D_ADAM);
     if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, stride, slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out);
     else hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, stride, slab, *disc, ad, n, lrow, loss_out);
@@ -2639,6 +2693,20 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab));
         if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
         else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st);
+        return check_launch();
+    }
+    if (d_fp8_opfmt(cfg, disc)) {
+        // fp8 operands in operand format (ltg_fp8bwd.h): the forward left A1^T, dpre3, dpre3^T and the gathered embeddings^T behind
+        const int NP = d8_np(n), P = L.off[8], SP = d_slab_stride(P), ks8 = (NP + D8_KCHUNK - 1) / D8_KCHUNK;
+        const int nA = (NP / 64) * ((h12 + 63) / 64);
+        const int nB = ks8 * ((h12 + 1 + 63) / 64) * ((h3 + 63) / 64);
+        const int nC = ks8 * ((h3 + 1 + 31) / 32);
+        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(k8_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, NP, h12, h3, nA, nB, L, SP, w.A1, w.A3, w.ds, w.dpre3_8, w.dpre3T_8,
+                                                        w.A1T_8, disc->w3_fp8, o->keep_prob, w.dpre1T_8, w.slab));
+        const int n2 = ks8 * ((h0 + 1 + 63) / 64) * (h1 / 64 + h2 / 64);
+        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(k8_d_bwd2, dim3(n2), dim3(NT), 0, st, NP, h0, h1, h2, L, SP, w.ET_8, w.dpre1T_8, w.slab));
+        if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks8, P, SP, w.slab, n, w.lrow, grad_out);
+        else d_apply(cfg, disc, L, ks8, SP, w.slab, n, w.lrow, ad, loss_out, pr, st);
         return check_launch();
     }
     // stage 1 (products with the OLD w3) and stage 2 only write gradient slabs; the single Adam sweep runs last
@@ -3298,9 +3366,8 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
                                                   acts->h2));
     {
-        const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
-        LTG_PROBED(pr, LTG_K_DEC1_FWD, hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, acts->h2,
-                                                          gen->wp1t_bf16, gen->p[7], acts->logits, w.segpart));
+        int G = 0;
+        LTG_PROBED(pr, LTG_K_DEC1_FWD, G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st));
         g_row_partial(cfg, bt, nf > 0 ? fake : nullptr, acts, rowpart, st, w.segpart, nullptr, G);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_ROWPART, LTG_COMM(comm->all_gather(rowpart, pp->rowpart_all, (size_t)B * RP, LTG_NCCL_FLOAT32, comm->comm, stream)));
@@ -3365,7 +3432,7 @@ int ltg_refresh_d_shadow(const ltg_config* cfg, const ltg_disc_state* d, ltg_str
     clear_errors();
     if (!cfg_ok(cfg) || !d || !d->emb || !d->emb_fp8 || !d->w1t_fp8 || !d->w2t_fp8 || !d->w3t_fp8) return LTG_EINVAL;
     hipLaunchKernelGGL(k_d_shadow, dim3(2048), dim3(NT), 0, (hipStream_t)stream, cfg->d_feat, cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3, d->emb, d->p[0],
-                       d->p[2], d->p[4], const_cast<uint8_t*>(d->emb_fp8), d->w1t_fp8, d->w2t_fp8, d->w3t_fp8);
+                       d->p[2], d->p[4], const_cast<uint8_t*>(d->emb_fp8), d->w1t_fp8, d->w2t_fp8, d->w3t_fp8, d->w3_fp8);
     return check_launch();
 }
 

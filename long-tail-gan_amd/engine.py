@@ -271,8 +271,8 @@ class Engine:
         h0, h1, h2, h3 = self.h0, self.h1, self.h2, self.h3
         if self.d_precision == cabi.LTG_PREC_FP8 and all(x % 64 == 0 for x in (h0, h1, h2, h3)):
             u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)
-            self.d_fp8 = (u8(self.feature_len * h0), u8(h1 * h0), u8(h2 * h0), u8(h3 * (h1 + h2)))
-        sh = [_ptr(t) for t in self.d_fp8] if self.d_fp8 else [None] * 4
+            self.d_fp8 = (u8(self.feature_len * h0), u8(h1 * h0), u8(h2 * h0), u8(h3 * (h1 + h2)), u8((h1 + h2) * h3))
+        sh = [_ptr(t) for t in self.d_fp8] if self.d_fp8 else [None] * 5
         self.disc_c = cabi.ltg_disc_state(_ptr(self.d_emb), arr(self.d_p), arr(self.d_m), arr(self.d_v), *sh)
         if self.d_fp8:
             cabi.check(self.lib.ltg_refresh_d_shadow(C.byref(self.cfg), C.byref(self.disc_c), self.stream()), "ltg_refresh_d_shadow")

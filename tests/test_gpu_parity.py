@@ -696,9 +696,56 @@ def test_fp8_operand_shadows_stay_in_step_with_the_master_weights():
     kept = [x.clone() for x in a.d_fp8]
     cabi.check(a.lib.ltg_refresh_d_shadow(C.byref(a.cfg), C.byref(a.disc_c), a.stream()), "ltg_refresh_d_shadow")
     torch.cuda.synchronize()
-    for name, x, y in zip(("emb", "w1t", "w2t", "w3t"), kept, a.d_fp8):
+    assert len(kept) == 5
+    for name, x, y in zip(("emb", "w1t", "w2t", "w3t", "w3"), kept, a.d_fp8):
         assert torch.equal(x, y), name
-    assert int((kept[1] != 0).sum()) > 0.9 * kept[1].numel()
+    assert int((kept[1] != 0).sum()) > 0.9 * kept[1].numel() and int((kept[4] != 0).sum()) > 0.9 * kept[4].numel()
+
+
+@pytest.mark.parametrize("hs,nr,nf", [((2048, 1024, 512, 256), 900, 921), ((512, 256, 256, 128), 130, 61), ((256, 128, 128, 128), 1, 0)])
+def test_fp8_backward_in_operand_format_equals_the_on_the_fly_conversion(hs, nr, nf):
+    """BASELINE config 5: with the fifth shadow (w3 in its own layout) every BACKWARD product of the discriminator step reads e4m3
+    bytes in operand format too (csrc/ltg_fp8bwd.h: transposed copies of A1, dpre3, dpre1 and of the gathered embedding rows, pair
+    rows zero-padded to a multiple of 128, 1024-row split-K chunks).  Same static scales and conversion as the path that converts
+    fp32 operands inside the GEMM loaders (tuning-knob bit 19), so both feed the MFMAs identical operand values: d_loss and every
+    Adam moment agree to the round-off of the fp32 accumulation order -- whole step, and cut at its gradient exchange."""
+    import torch
+    from ltgan.engine import Pairs
+    I = 500
+    rng = np.random.default_rng(77)
+    a, b = _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8"), _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8")
+    b.cfg.reserved0 = 1 << 19                     # forward from the shadows, backward converts on the fly (the round-2 path)
+    b.set_discriminator(a.d_emb.cpu().numpy(), [p.cpu().numpy() for p in a.d_p])
+    dev = a.device
+    t = lambda x: torch.from_numpy(x.astype(np.int32)).to(dev)
+    rp, rn, fp, fn = (rng.integers(0, I, k) for k in (nr, nr, nf, nf))
+    if nf > 3:
+        fp[2] = -1                                # holes (dropped pairs, Q9 / Q10)
+        fn[2] = -1
+    real, fake = Pairs(t(rp), t(rn)), Pairs(t(fp), t(fn))
+    for k in range(2):
+        la = float(a.d_step(real, fake, 0.7, rng_step=5 + k)[0].item())
+        lb = float(b.d_step(real, fake, 0.7, rng_step=5 + k)[0].item())
+        assert abs(la - lb) <= 1e-5 * abs(lb) + 1e-6, (k, la, lb)
+        for i in range(8):
+            x, y = a.d_m[i].double(), b.d_m[i].double()
+            assert (x - y).norm().item() <= 2e-4 * y.norm().item() + 1e-12, ("m", k, i)
+            if k == 0:                            # one step from equal weights: v = (1 - b2) g^2 compares the squared gradients
+                assert (a.d_v[i].double() - b.d_v[i].double()).norm().item() <= 4e-4 * b.d_v[i].double().norm().item() + 1e-20, ("v", i)
+    # ... and cut at the gradient exchange (ltg_d_grad over a row range), from IDENTICAL weights again (two steps of round-off in the
+    # weights flip e4m3 roundings of the operands: an fp8 pipeline amplifies that to the percent level)
+    b.set_discriminator(a.d_emb.cpu().numpy(), [p.cpu().numpy() for p in a.d_p])
+    n = nr + nf
+    ga = torch.empty(a.d_grad_floats(), dtype=torch.float32, device=dev)
+    gb = torch.empty_like(ga)
+    lo, hi = n // 3, n - n // 4
+    a.d_grad(real, fake, lo, hi, ga, keep_prob=0.7, rng_step=11)
+    b.d_grad(real, fake, lo, hi, gb, keep_prob=0.7, rng_step=11)
+    torch.cuda.synchronize()
+    L = a.d_grad_floats()
+    P = sum(int(x.numel()) for x in a.d_p)
+    err = (ga[:P].double() - gb[:P].double()).norm().item() / gb[:P].double().norm().item()
+    assert err <= 1e-3 and abs(float(ga[P]) - float(gb[P])) <= 1e-5 * abs(float(gb[P])) + 1e-6, (err, float(ga[P]), float(gb[P]), L, P)
 
 
 def test_gemm_block_operand_modes():
