@@ -707,6 +707,10 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
     ltg_rgemm<1, 2, 1, 1, 4, 4>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
+// (Measured and not kept, round 3: this sweep FUSED into fk_d_bwd2 -- every workgroup releases its slab tile with a device-scope fence
+// and takes a ticket on the tile's counter, the last arriver of a tile adds the chunk slabs and applies Adam, trailing blocks sweep
+// w3 / b3 / w4 / b4.  Bit-identical and one launch fewer, but the ~1 000 release fences (an L2 write-back each) serialise: D step
+// 59.8 -> 145 us on Askubuntu_Sample.  The launch boundary is the cheaper device-wide release.)
 // One Adam sweep over the discriminator's trainable tensors laid out back to back (train.py:163): g = sum of the chunk
 // slabs; 16 bytes per lane.  Block 0 also adds up d_loss (train.py:142) from slot P of the slabs.
 __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const float* __restrict__ slab, float* __restrict__ p,
