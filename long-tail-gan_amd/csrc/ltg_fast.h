@@ -515,6 +515,13 @@ __global__ __launch_bounds__(NT) void fk_d_y(PairView pv, int ntile, const float
     y[r] = yv;
 }
 
+#ifndef LTG_BWD1_NA
+#define LTG_BWD1_NA 5      // 16-deep k blocks a wave of job A / job B keeps in flight per pass (registers: 16 per block).  Measured with
+                           // 3 / 2 instead (two passes, 138 -> ~85 registers, twice the resident workgroups): D step 59.5-60.5 us either way
+#endif
+#ifndef LTG_BWD1_NB
+#define LTG_BWD1_NB 4
+#endif
 // Backward stage 1, ONE launch, three jobs by block index (gradient slabs are summed by the Adam sweep):
 //   job A  dpre1 = ((ds G3) . w3^T) * dact(A1)                               [n][h1+h2]   32 x 32 tiles
 //   job B  slab[z] = A1^T . (ds G3) (+ ones row -> db3), split over row chunks [h12+1][h3]  32 x 32 tiles
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
         auto epi = [=] __device__(int e, int m, int nn, float v, bool ok) {
             if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(a1v[e], keep);
         };
-        ltg_rgemm<2, 2, 1, 1, 4, 5>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
         return;
     }
     bid -= nA;
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_rgemm<2, 2, 1, 1, 4, 4>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
         return;
     }
     bid -= nB;
@@ -905,6 +912,9 @@ struct WgWhere {
 struct WgRegs {
     ltg_f32x4 p, m, v;
 };
+#ifndef LTG_TAIL_BN
+#define LTG_TAIL_BN 32      // columns of a weight-gradient + Adam tile of fk_g_tail (32 or 64; rows: 32)
+#endif
 template <bool RND, bool ONES_L>
 __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const float* __restrict__ Lm, int ldl, const float* __restrict__ Rm,
                                                 int ldr, WgTensors T, int ldw, AdamC ad, int m0, int n0, float* __restrict__ lds) {
@@ -981,7 +991,10 @@ __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const f
             x.v[0] = r.v[0];
         }
     };
-    ltg_rgemm_v4<1, 1, 2, 2, 1, 7>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
+    // 32 x 32 tile, every wave the whole tile over a QUARTER of K (two 16-deep blocks at 100 batch rows): 32 operand registers per
+    // lane instead of 56 (one 16 x 16 product over all of K per wave), so that six workgroups fit a CU and the ~1 600 tiles of an
+    // Askubuntu-sized tail are resident in (almost) one round instead of two
+    ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 2>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
 }
 
 // The Adam updates of the generator step as jobs riding with the backward chain (train.py:164; each is independent once
@@ -1012,46 +1025,36 @@ struct TailArgs {
 };
 template <bool BF>
 __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, AdamC ad) {
-    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS > Rg32::LDS_FLOATS ? Rg16::LDS_FLOATS : Rg32::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LtgRg<2, LTG_TAIL_BN / 16, 1, 1, 4>::LDS_FLOATS];
     int bid = blockIdx.x;
     const int B = a.B, I = a.I, H = a.H, Z = a.Z;
-    if (bid < a.nz) {       // the critical path of the step rides in front: its tiles are placed first
-        const int tn = (Z + 15) / 16;
-        dz_tile(B, Z, H, a.da2, a.Wp0, a.mulv, a.eps, a.is_training, a.anneal, a.seed, a.step, a.dmlv_out, (bid / tn) * 16, (bid % tn) * 16, lds);
-        return;
-    }
-    bid -= a.nz;
-    if (bid < a.nh) {
-        const int tn = (H + 15) / 16;
-        dh1_tile(B, H, 2 * Z, a.dmlv, a.Wq1, a.h1, a.da1_out, (bid / tn) * 16, (bid % tn) * 16, lds);
-        return;
-    }
-    bid -= a.nh;
+    // (The dz / dh1 tiles once rode in front of the jobs -- three launches of this kernel per step, measured +23 us; the variant
+    // is gone: its 80 operand registers set the register count of the whole kernel and with it the tiles' occupancy.)
     if (bid < a.n1) {
-        const int tn = (H + 1 + 31) / 32;
+        const int tn = (H + 1 + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[3], st.m[3], st.v[3], st.p[7], st.m[7], st.v[7]};
-        wgrad_adam_tile<BF, false>(B, I, H, a.dlog, I, a.h2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        wgrad_adam_tile<BF, false>(B, I, H, a.dlog, I, a.h2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
         return;
     }
     bid -= a.n1;
     if (bid < a.n2) {
-        const int tn = (H + 31) / 32;
+        const int tn = (H + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[2], st.m[2], st.v[2], st.p[6], st.m[6], st.v[6]};
-        wgrad_adam_tile<false, true>(B, Z, H, a.z, Z, a.da2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        wgrad_adam_tile<false, true>(B, Z, H, a.z, Z, a.da2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
         return;
     }
     bid -= a.n2;
     if (bid < a.n3) {
-        const int tn = (2 * Z + 31) / 32;
+        const int tn = (2 * Z + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[1], st.m[1], st.v[1], st.p[5], st.m[5], st.v[5]};
-        wgrad_adam_tile<false, true>(B, H, 2 * Z, a.h1, H, a.dmlv, 2 * Z, T, 2 * Z, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        wgrad_adam_tile<false, true>(B, H, 2 * Z, a.h1, H, a.dmlv, 2 * Z, T, 2 * Z, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
         return;
     }
     bid -= a.n3;
     if (bid < a.n4 && a.xd) {
-        const int tn = (H + 31) / 32;
+        const int tn = (H + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[0], st.m[0], st.v[0], st.p[4], st.m[4], st.v[4]};
-        wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * 32, lds);
+        wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
         return;
     }
     if (bid < a.n4 && a.q0_bias) {   // b_q0 from the partial bias rows of fk_enc0_grad + this step's learning rate into the clock's ring

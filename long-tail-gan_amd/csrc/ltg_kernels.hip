@@ -2904,14 +2904,13 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
     TailArgs a;
     a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
     const bool all = stage < 0;     // stage -1: every Adam job in ONE launch (dz / dh1 were launched on their own)
-    a.nz = stage == 0 ? ((B + 15) / 16) * ((Z + 15) / 16) : 0;
-    a.nh = stage == 1 ? ((B + 15) / 16) * ((H + 15) / 16) : 0;
-    a.n1 = ((stage == 0 || all) && with_dec1) ? ((I + 31) / 32) * ((H + 1 + 31) / 32) : 0;
-    a.n2 = (stage == 1 || all) ? ((Z + 1 + 31) / 32) * ((H + 31) / 32) : 0;
-    a.n3 = (stage == 2 || all) ? ((H + 1 + 31) / 32) * ((2 * Z + 31) / 32) : 0;
+    a.nz = a.nh = 0;
+    a.n1 = ((stage == 0 || all) && with_dec1) ? ((I + 31) / 32) * ((H + 1 + LTG_TAIL_BN - 1) / LTG_TAIL_BN) : 0;
+    a.n2 = (stage == 1 || all) ? ((Z + 1 + 31) / 32) * ((H + LTG_TAIL_BN - 1) / LTG_TAIL_BN) : 0;
+    a.n3 = (stage == 2 || all) ? ((H + 1 + 31) / 32) * ((2 * Z + LTG_TAIL_BN - 1) / LTG_TAIL_BN) : 0;
     a.n4 = 0;
     if ((stage == 2 || all) && !no_q0) {
-        if (!slot) a.n4 = ((I + 1 + 31) / 32) * ((H + 31) / 32);
+        if (!slot) a.n4 = ((I + 1 + 31) / 32) * ((H + LTG_TAIL_BN - 1) / LTG_TAIL_BN);
         else {
             const size_t total = (size_t)(I + 1) * (H / 4);
             size_t gx = (total + NT - 1) / NT;
@@ -2941,8 +2940,7 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
     pr.after(kid);
 }
 
-// dz -> dh1 -> (sparse W_q0 gradient) -> Adam updates.  Tuning-knob bit 20: the Adam jobs ride with the dz / dh1 launches
-// (three launches of fk_g_tail) instead of running as one tail launch behind them.
+// dz -> dh1 -> (sparse W_q0 gradient) -> Adam updates as one tail launch.
 // Adam step gen->q0_ord + 1 of W_q0 / b_q0 on the lazy clock: the batch's rows with their gradient rows (w.gq0), the bias
 // row, then the rotating slice of untouched rows
 constexpr int G_AUX_SWEEP = 0x40000000;   // library-internal bit of ltg_g_opts.fake_done: ltg_g_step runs the slice on its aux stream
@@ -2962,14 +2960,6 @@ static void q0_lazy_update(const ltg_config* cfg, const ltg_gen_state* gen, cons
 static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
                     const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st, bool lazy = false) {
     const int B = bt->n_rows, H = cfg->h_enc, Z = cfg->z_dim;
-    const bool ride = (cfg->reserved0 & (1 << 20)) != 0 && !lazy;
-    if (ride) {
-        g_jobs(0, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
-        g_jobs(1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
-        if (slot) g_enc0_grad(cfg, bt, o, acts, w, st);
-        g_jobs(2, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st);
-        return;
-    }
     const Probe pr{o->probe, st};
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
