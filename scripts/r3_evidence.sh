@@ -21,6 +21,15 @@ for wl in "askubuntu:" "c4_3200users:--workload c4 --users 3200" "ml20m_3200user
   cd $R
   f=$(find $O/prof_$name -name "*kernel_stats.csv" | head -1); cp "$f" $O/r3_${name}_kernel_stats.csv; rm -rf $O/prof_$name
 done
+# timeline of two steps of the one-call sharded step (per-rank proxy) and of the Askubuntu_Sample G step
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $R/$O/trace_mid -- python3 $R/bench.py --workload custom:25024 --parallelism item-shard --warm-moments --steps 1 --warmup 1 --no-probe --no-cpu-baseline --no-other-workloads > $R/$O/trace_mid.log 2>&1
+cd $R
+f=$(find $O/trace_mid -name "*kernel_trace.csv" | head -1); python profiles/make_timeline.py "$f" k_q0_touch_unique 2 > $O/r3_mid25k_timeline.txt; rm -rf $O/trace_mid
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $R/$O/trace_ask -- python3 $R/bench.py --steps 1 --warmup 1 --no-probe --no-cpu-baseline --no-other-workloads > $R/$O/trace_ask.log 2>&1
+cd $R
+f=$(find $O/trace_ask -name "*kernel_trace.csv" | head -1); python profiles/make_timeline.py "$f" fk_enc0_fwd 3 > $O/r3_askubuntu_g_step_timeline.txt; rm -rf $O/trace_ask
 for wl in "askubuntu:" "c4:--workload c4 --users 1600"; do
   name=${wl%%:*}; extra=${wl#*:}
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
