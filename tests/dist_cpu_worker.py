@@ -76,6 +76,27 @@ def main():
     np.testing.assert_allclose(dh2.numpy(), F["dh2"], rtol=1e-5, atol=1e-9)
     # the sharded tables need no gradient exchange: the local gradient IS the slab of the full gradient
     np.testing.assert_allclose(F["h2"].T @ dlog, g["Wp1"][:, lo:hi], rtol=1e-5, atol=1e-9)
+    # ---- the two entry points ltg_g_step_sharded calls through ltg_comm (include/ltg.h), in their host-callback form: invoked HERE the way
+    # the library invokes them -- raw pointers into registered buffers, ncclAllReduce / ncclAllGather argument order, in place
+    import ctypes as C
+    from ltgan import _cabi as cabi
+    from ltgan._rccl import HostComm
+    h1pre = torch.full((B, 8), float(rank + 1))
+    rp_all = torch.zeros(R * B * 5)
+    rp_all[rank * B * 5:(rank + 1) * B * 5] = torch.arange(B * 5, dtype=torch.float32) + 1000 * rank       # this rank's block, written in place
+    comm = HostComm(None, [h1pre, rp_all])
+    assert comm.c.n_ranks == R and comm.c.rank == rank
+    ar = C.cast(comm.c.all_reduce, cabi.ALL_REDUCE_FN)
+    ag = C.cast(comm.c.all_gather, cabi.ALL_GATHER_FN)
+    n = 5 * 8 + 3                                              # a prefix of the buffer (the last batch of an epoch is short)
+    assert ar(h1pre.data_ptr(), h1pre.data_ptr(), n, cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, None, None) == 0
+    flat = h1pre.view(-1)
+    assert torch.all(flat[:n] == float(sum(range(1, R + 1)))) and torch.all(flat[n:] == float(rank + 1))
+    send = rp_all.data_ptr() + rank * B * 5 * 4
+    assert ag(send, rp_all.data_ptr(), B * 5, cabi.LTG_NCCL_FLOAT32, None, None) == 0
+    for r in range(R):
+        assert torch.equal(rp_all[r * B * 5:(r + 1) * B * 5], torch.arange(B * 5, dtype=torch.float32) + 1000 * r)
+    assert ar(12345, 12345, 4, cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, None, None) != 0       # not a registered buffer: an error code, no exception
     dist.barrier()
     if rank == 0:
         print("DIST_CPU_OK")
