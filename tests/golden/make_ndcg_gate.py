@@ -14,6 +14,7 @@ Pure restatement output: no reference source is read, no GPU is used.
 usage: python tests/golden/make_ndcg_gate.py [threads]     (about 1 minute per global epoch on 8 cores)
        python tests/golden/make_ndcg_gate.py [threads] long  -> ndcg_gate_long.npz: 2 seeds x 30 global epochs (the gate further
                                                                   along config.ini's 80-epoch schedule, train.py:369)
+       python tests/golden/make_ndcg_gate.py [threads] full  -> ndcg_gate_full.npz: 2 seeds x the whole 80-epoch schedule
 """
 import os
 import sys
@@ -47,6 +48,8 @@ if __name__ == "__main__":
     out = "ndcg_gate.npz"
     if len(sys.argv) > 2 and sys.argv[2] == "long":
         SEEDS, EPOCHS, out = (11, 12), 30, "ndcg_gate_long.npz"
+    if len(sys.argv) > 2 and sys.argv[2] == "full":          # config.ini's whole schedule: NUM_EPOCH = 80 global epochs (train.py:369)
+        SEEDS, EPOCHS, out = (11, 12), 80, "ndcg_gate_full.npz"
     d = tempfile.mkdtemp()
     materialize_askubuntu(os.path.join(ROOT, "tests", "golden", "askubuntu_raw.npz"), d)
     idx = IndexData.from_dir(d)
