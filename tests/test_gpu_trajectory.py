@@ -90,3 +90,34 @@ def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, 
         runs.append([x.cpu() for x in out + eng.g_p + eng.d_p + eng.g_m])
     for k, (a, b) in enumerate(zip(*runs)):
         assert torch.equal(a, b), k
+
+
+def test_pipelined_g_phase_equals_the_step_by_step_loop():
+    """Large item slabs run phase G (train.py:307-329) as one ltg_g_step_sharded call per step -- decoder weight update and lazy-clock slice
+    forked beside the NEXT step -- with every fake tower evaluated ahead.  Two global epochs (C, S x D, S x G) of the real loop on a synthetic
+    9 000-item dataset: identical fake pairs, and every generator tensor, Adam moment and loss equals the loop over ltg_g_step bit for bit."""
+    import torch
+    from ltgan.dataset import DeviceData
+    from ltgan.engine import Engine
+    from ltgan.synthetic import synthetic_index
+    from ltgan.trainer import Trainer
+    idx, _ = synthetic_index("custom:9000", users=430, seed=21)
+    runs = []
+    for pipe in (False, True):
+        eng = Engine(idx.n_items, h_sizes=(20, 24, 40, 36), lr=1e-3, precision="bf16", seed=5, d_seed=9)
+        data = DeviceData(idx, 100, eng.device)
+        tr = Trainer(eng, data, num_sub_epochs=3, shuffle_seed=4, pipe_step=pipe)
+        assert (tr.pipe is not None) == pipe and eng.lazy_q0
+        losses = []
+        for _ in range(2):
+            tr.create_phase()
+            losses.append(tr.d_phase().clone())
+            losses.append(tr.g_phase().clone())
+        torch.cuda.synchronize()
+        runs.append((data.fake_gen.clone(), data.fake_pop.clone(), losses, [t.clone() for t in eng.g_p + eng.g_m + eng.g_v + eng.d_p]))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
+    for k, (x, y) in enumerate(zip(a[3], b[3])):
+        assert torch.equal(x, y), k
