@@ -109,7 +109,10 @@ class HostComm:
             if dtype != cabi.LTG_NCCL_FLOAT32:
                 return 1
             src, out = self._view(send, sendcount).clone(), self._view(recv, self.n_ranks * sendcount)    # (in place: the source is a block of `out`)
-            dist.all_gather([out[r * sendcount:(r + 1) * sendcount] for r in range(self.n_ranks)], src, group=self.group)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(out, src, group=self.group)
+            else:
+                dist.all_gather([out[r * sendcount:(r + 1) * sendcount] for r in range(self.n_ranks)], src, group=self.group)
             return 0
         except Exception:
             import traceback
