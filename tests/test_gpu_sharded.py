@@ -27,3 +27,10 @@ def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mo
            "--master-port", "29577", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), precision] + ([mode] if mode else [])
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "SHARDED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
+
+
+def test_direct_rccl_transport_of_the_one_call_step_at_world_size_one():
+    """The transport a GPU node uses: RCCL bound directly, its entry points called by the library in-stream (tests/dist_rccl_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_worker.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "RCCL_DIRECT_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
