@@ -77,7 +77,12 @@ class ShardedTrainer(Trainer):
         callbacks over the group for test rigs whose ranks share a GPU (gloo).  LTGAN_SHARDED_STEP=0: the cut-point sequence."""
         from ._rccl import HostComm, RcclComm
         self.pipe, self.comm = None, None
-        if os.environ.get("LTGAN_SHARDED_STEP", "1") == "0" or not engine.sharded_step_ok(B):
+        mine = os.environ.get("LTGAN_SHARDED_STEP", "1") != "0" and engine.sharded_step_ok(B)
+        # every rank must take the same path (a rank whose slab the one-call step does not serve -- e.g. a last slab that is not a
+        # multiple of 8 items -- would otherwise wait in torch.distributed collectives the others never issue)
+        agree = torch.tensor([1 if mine else 0], dtype=torch.int32, device=engine.device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=self.group)
+        if int(agree.item()) == 0:
             return
         self.pipe = Pipe(engine, B, self.R, flags=int(os.environ.get("LTGAN_PIPE_FLAGS", "0")))
         if dist.get_backend(self.group) == "nccl" and os.environ.get("LTGAN_COMM", "rccl") == "rccl":
