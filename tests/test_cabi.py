@@ -124,6 +124,28 @@ def test_bench_rejects_gpus_launcher_mismatch():
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
 
 
+def test_bench_parent_counts_gpus_without_the_hip_runtime(monkeypatch):
+    """`python bench.py --gpus N` starts its ranks from a parent that must never load the HIP runtime (a process that touched the GPU may
+    not start another program on this pool): the device count comes from the visibility variables or from sysfs, not from torch."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    was_loaded = "torch" in sys.modules
+    spec.loader.exec_module(bench)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "5")
+    assert bench.visible_gpus() == 1
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    assert bench.visible_gpus() >= 0                      # sysfs (0 in a container without a GPU)
+    assert was_loaded or "torch" not in sys.modules      # importing bench.py and counting devices pulls in no torch
+
+
 def test_default_initialisers_match_the_reference_distributions():
     """a3: MultiVAE.py:199-207,219-225 (Xavier-uniform weights, truncated-normal sigma = 1e-3 biases) and
     discriminator.py:14-41 (truncated-normal sigma = 0.1 matrices, zero biases): shapes, hard bounds and moments."""
