@@ -144,15 +144,6 @@ class Trainer:
     def _g_begin(self):
         self.last_anneal = []
         self.eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
-        self._hp_ctx = None
-        if self.pipe is not None and os.environ.get("LTGAN_G_PRIORITY", "0") == "1":
-            # measurement switch: the step's critical chain on a HIGH-priority stream, so that its short kernels are placed ahead of
-            # the forked weight update's workgroups
-            if getattr(self, "_hp_stream", None) is None:
-                self._hp_stream = torch.cuda.Stream(self.eng.device, priority=-1)
-            self._hp_stream.wait_stream(torch.cuda.current_stream(self.eng.device))
-            self._hp_ctx = torch.cuda.stream(self._hp_stream)
-            self._hp_ctx.__enter__()
         self.eng.pin_stream()
 
     def _g_end(self, ok):
@@ -167,10 +158,6 @@ class Trainer:
         finally:
             eng.q0_defer = False
             eng.pin_stream(False)
-            if self._hp_ctx is not None:
-                self._hp_ctx.__exit__(None, None, None)
-                torch.cuda.current_stream(eng.device).wait_stream(self._hp_stream)
-                self._hp_ctx = None
 
     def _g_one(self, j, b, v, a):
         """one generator update (train.py:326) of batch b in sub-epoch j"""
