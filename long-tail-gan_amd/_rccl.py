@@ -112,7 +112,11 @@ class HostComm:
             if dist.get_backend(self.group) == "nccl":
                 dist.all_gather_into_tensor(out, src, group=self.group)
             else:
-                dist.all_gather([out[r * sendcount:(r + 1) * sendcount] for r in range(self.n_ranks)], src, group=self.group)
+                # (gloo's list all-gather of device tensors takes milliseconds; an all-reduce of the zero-padded buffer gathers the same
+                # values exactly -- x + 0 -- in a fraction of that; test rigs only)
+                out.zero_()
+                out[self.rank * sendcount:(self.rank + 1) * sendcount] = src
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
             return 0
         except Exception:
             import traceback
