@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 10
+#define LTG_ABI_VERSION 11
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -142,6 +142,10 @@ typedef struct ltg_batch {
     const int32_t* rowidx;  /* local row of each transposed entry */
     const int32_t* csr_pos; /* index of that entry in indices[] */
     const float* row_norm2; /* optional [n_rows]: sum x^2 over the FULL row (needed when the items are sharded) */
+    const int32_t* uitem;   /* optional [n_unique] (ABI v11): the distinct items themselves, ascending.  The same value as
+                             * indices[csr_pos[uptr[u]]] -- with it the kernels that walk the distinct items (catch-up of the lazy Adam
+                             * clock, sparse W_q0 gradient) learn the item in ONE dependent load instead of three and can request its
+                             * weight / moment rows before the gather has returned */
 } ltg_batch;
 
 /* Activations of one generator forward; caller-owned, sizes for n_rows rows.
@@ -382,13 +386,14 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  *
  * Pipeline (ltg_pipe: ONE caller-created side stream, three events and the exchange buffers; the library allocates nothing).
  * One fork per step, behind the dh2 product of step t (the last reader of the W_p1t shadow), puts onto the side stream
- *   (1) the rotating slice of the lazy Adam clock that step t - 1 owes (rows i = ord (mod q0_period) up to ordinal ord = t - 1):
- *       every row of batch t is already at that ordinal (the catch-up at the start of the step), so the slice skips them whatever
- *       the rest of step t does to them; joined (ev_slice) at the start of call t + 1, before that batch's catch-up;
- *   (2) the Adam update of the local W_p1t / b_p1 rows of step t (HBM-bound, the largest kernel; needs only dlogits and h2):
- *       joined (ev_dec1) before dec-0 of step t + 1 overwrites h2 -- it runs beside the rest of step t's backward and the
- *       encoder half of step t + 1's forward.
- * Both joins are stream waits on events recorded by the PREVIOUS call (a never-recorded event does not block).  Before anything
+ * the Adam update of the local W_p1t / b_p1 rows of step t (HBM-bound, the largest kernel; needs only dlogits and h2): joined
+ * (ev_dec1) before dec-0 of step t + 1 overwrites h2 -- it runs beside the rest of step t's backward and the encoder half of
+ * step t + 1's forward.  The rotating slice of the lazy Adam clock that step t - 1 owes (rows i = ord (mod q0_period) up to ordinal
+ * ord = t - 1) rides in the catch-up launch of call t (one launch over the batch's rows and the slice's rows, both up to ord; a row in
+ * both sets goes to whichever workgroup's atomic max on its clock comes first).  LTG_PIPE_SLICE_ON_SIDE: the slice on the side stream in
+ * front of the weight update instead (every row of batch t is already at ord, so the slice skips them whatever the rest of step t does
+ * to them), joined (ev_slice) at the start of call t + 1, before that batch's catch-up.
+ * The joins are stream waits on events recorded by the PREVIOUS call (a never-recorded event does not block).  Before anything
  * else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs ltg_g_pipe_join on the
  * stream that will read them.  Results equal ltg_g_step's / the cut-point sequence's bit for bit (same kernels, same order of
  * additions; the slice only runs later). */
@@ -415,6 +420,8 @@ typedef struct ltg_pipe {
 } ltg_pipe;
 #define LTG_PIPE_NO_DEC1_FORK 1  /* everything on the caller's stream, in program order */
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
+#define LTG_PIPE_SLICE_ON_SIDE 4 /* the slice step t - 1 owes on the side stream in front of the weight update (joined by ev_slice) instead of
+                                    in the catch-up launch of call t */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
 int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);

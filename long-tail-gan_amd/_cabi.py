@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 10
+LTG_ABI_VERSION = 11
 LTG_Q0_HIST = 1024
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
@@ -43,7 +43,7 @@ class ltg_disc_state(C.Structure):
 
 class ltg_batch(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("n_unique", C.c_int32), ("indptr", vp), ("indices", vp), ("values", vp),
-                ("slot", vp), ("uptr", vp), ("rowidx", vp), ("csr_pos", vp), ("row_norm2", vp)]
+                ("slot", vp), ("uptr", vp), ("rowidx", vp), ("csr_pos", vp), ("row_norm2", vp), ("uitem", vp)]
 
 
 class ltg_gen_acts(C.Structure):
@@ -90,7 +90,7 @@ class ltg_sample_inputs(C.Structure):
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
 LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
-LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK = 1, 2
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_SLICE_ON_SIDE = 1, 2, 4
 
 
 class ltg_comm(C.Structure):

@@ -312,8 +312,11 @@ __device__ __forceinline__ float4 enc0_grad_entries(int q0, int q1, int stride, 
                                                     const int32_t* __restrict__ csr_pos, const int32_t* __restrict__ indices,
                                                     const float* __restrict__ values, const uint8_t* __restrict__ drop_keep, float keep,
                                                     uint64_t seed, uint64_t step, const float* __restrict__ row_scale,
-                                                    const float4* __restrict__ d4, int item_lo, int Ig) {
+                                                    const float4* __restrict__ d4, int item_lo, int Ig, int item = -1) {
+    // item >= 0: the row's item is known (ltg_batch.uitem) -- with implicit values and the in-kernel dropout draw an entry then needs its
+    // user row only: rowidx -> (row_scale, da1 row) instead of csr_pos -> indices -> ...
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool need_pos = item < 0 || values != nullptr || drop_keep != nullptr;   // uniform
     for (int q = q0; q < q1; q += G0_U * stride) {
         int b[G0_U];
         float sc[G0_U];
@@ -324,8 +327,8 @@ __device__ __forceinline__ float4 enc0_grad_entries(int q0, int q1, int stride, 
             const int qc = ok ? qt : q;
             if (is_item) {   // uniform
                 b[t] = rowidx[qc];
-                const int pos = csr_pos[qc];
-                const int it = indices[pos];
+                const int pos = need_pos ? csr_pos[qc] : 0;
+                const int it = item >= 0 ? item : indices[pos];
                 const bool kp = drop_keep ? (drop_keep[pos] != 0)
                                           : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b[t] * (uint64_t)Ig + item_lo + it, keep);
                 sc[t] = (ok && kp) ? (values ? values[pos] : 1.f) * row_scale[b[t]] : 0.f;
@@ -347,47 +350,63 @@ __device__ __forceinline__ float4 enc0_grad_entries(int q0, int q1, int stride, 
     }
     return acc;
 }
-__global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
+#ifndef LTG_G0_WAVES
+#define LTG_G0_WAVES 6   // waves per SIMD the register allocation aims at (80 registers: three workgroups per CU; four registers spill)
+#endif
+__global__ __launch_bounds__(G0_NT, LTG_G0_WAVES) void fk_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
                                                       const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
                                                       const int32_t* __restrict__ indices, const float* __restrict__ values,
                                                       const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
                                                       const float* __restrict__ row_scale, const float* __restrict__ da1,
-                                                      float* __restrict__ G, int item_lo, int Ig, ltg_gen_state st, AdamC ad, int lazy_ord) {
+                                                      float* __restrict__ G, int item_lo, int Ig, ltg_gen_state st, AdamC ad, int lazy_ord,
+                                                      const int32_t* __restrict__ uitem) {
     // lazy_ord > 0 (lazy Adam clock of W_q0, step `lazy_ord`): an item's gradient row is not stored -- the Adam step is applied to
     // its row of W_q0 / m / v right here (q0_touch brought every row of the batch to lazy_ord - 1 before the forward), the
     // workgroup of column block 0 moves the row's clock.  The partial bias rows still go to G (fk_g_tail sums them).
+    // uitem (optional): the distinct items themselves.  The kernel is a chain of dependent round trips (7 without it: uptr -> rowidx,
+    // csr_pos -> indices -> row_scale, da1 -> [uptr -> csr_pos -> indices ->] W / m / v); with it a light row takes 3 (uptr, uitem ->
+    // rowidx + the row's W / m / v -> row_scale, da1) -- what the kernel costs beside the streaming weight update, where a round trip
+    // queues behind ~20 MB of that kernel's requests.
     __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][64];
-    auto finish_row = [&](int u, float4 g) {
-        if (lazy_ord > 0 && u < nu) {
-            const int i = indices[csr_pos[uptr[u]]];
-            const size_t off = (size_t)i * (H >> 2) + min(64 * (int)blockIdx.x + (int)(threadIdx.x & 63), (H >> 2) - 1);
-            float4 p = reinterpret_cast<float4*>(st.p[0])[off], mm = reinterpret_cast<float4*>(st.m[0])[off], vv = reinterpret_cast<float4*>(st.v[0])[off];
-            adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
-            adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
-            adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
-            adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
-            reinterpret_cast<float4*>(st.p[0])[off] = p;
-            reinterpret_cast<float4*>(st.m[0])[off] = mm;
-            reinterpret_cast<float4*>(st.v[0])[off] = vv;
-            if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) st.q0_last[i] = lazy_ord;
-        } else {
-            reinterpret_cast<float4*>(G)[(size_t)u * (H >> 2) + min(64 * (int)blockIdx.x + (int)(threadIdx.x & 63), (H >> 2) - 1)] = g;
-        }
-    };
     const int cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H4 = H >> 2, nrows = nu + ENC0_BIAS_PARTS;
     const int c4 = min(64 * cb + lane, H4 - 1);
     const bool cok = 64 * cb + lane < H4;
+    struct RowReq { float4 p, m, v; };
+    auto row_off = [&](int i) { return (size_t)i * H4 + c4; };
+    auto row_request = [&](int i) {
+        return RowReq{reinterpret_cast<const float4*>(st.p[0])[row_off(i)], reinterpret_cast<const float4*>(st.m[0])[row_off(i)],
+                      reinterpret_cast<const float4*>(st.v[0])[row_off(i)]};
+    };
+    auto adam_row = [&](int i, RowReq r, float4 g) {
+        adam1(r.p.x, r.m.x, r.v.x, g.x, ad.lr_t, ad);
+        adam1(r.p.y, r.m.y, r.v.y, g.y, ad.lr_t, ad);
+        adam1(r.p.z, r.m.z, r.v.z, g.z, ad.lr_t, ad);
+        adam1(r.p.w, r.m.w, r.v.w, g.w, ad.lr_t, ad);
+        reinterpret_cast<float4*>(st.p[0])[row_off(i)] = r.p;
+        reinterpret_cast<float4*>(st.m[0])[row_off(i)] = r.m;
+        reinterpret_cast<float4*>(st.v[0])[row_off(i)] = r.v;
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) st.q0_last[i] = lazy_ord;
+    };
+    auto finish_row = [&](int u, float4 g, int item) {
+        if (lazy_ord > 0 && u < nu) {
+            const int i = item >= 0 ? item : indices[csr_pos[uptr[u]]];
+            adam_row(i, row_request(i), g);
+        } else {
+            reinterpret_cast<float4*>(G)[(size_t)u * H4 + c4] = g;
+        }
+    };
     const float4* d4 = reinterpret_cast<const float4*>(da1);
     const int per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
     // entry ranges of the group's eight rows (every wave computes all eight: the heavy / light split must be uniform)
-    int q0[G0_NW], q1[G0_NW];
+    int q0[G0_NW], q1[G0_NW], uit[G0_NW];
 #pragma unroll
     for (int j = 0; j < G0_NW; ++j) {
         const int u = min(j * (int)gridDim.y + (int)blockIdx.y, nrows - 1);
         const int bp = u - nu;
         q0[j] = u < nu ? uptr[u] : min(B, bp * per);
         q1[j] = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
+        uit[j] = (uitem && u < nu) ? uitem[u] : -1;
         if (j * (int)gridDim.y + (int)blockIdx.y >= nrows) q1[j] = q0[j];     // beyond the last row: empty
     }
     // light rows: wave j alone
@@ -395,9 +414,15 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
     for (int j = 0; j < G0_NW; ++j) {
         const int u = j * (int)gridDim.y + (int)blockIdx.y;
         if (j == w && u < nrows && q1[j] - q0[j] <= G0_LIGHT) {
+            const bool pre = lazy_ord > 0 && u < nu && uit[j] >= 0;   // (wave-uniform) the row's W / m / v travel while the entries are gathered
+            RowReq r{};
+            if (pre) r = row_request(uit[j]);
             const float4 acc = enc0_grad_entries(q0[j], q1[j], 1, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step,
-                                                 row_scale, d4, item_lo, Ig);
-            if (cok) finish_row(u, acc);
+                                                 row_scale, d4, item_lo, Ig, uit[j]);
+            if (cok) {
+                if (pre) adam_row(uit[j], r, acc);
+                else finish_row(u, acc, uit[j]);
+            }
         }
     }
     // heavy rows: all eight waves, one row after the other
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
         const int u = j * (int)gridDim.y + (int)blockIdx.y;
         if (u < nrows && q1[j] - q0[j] > G0_LIGHT) {     // uniform over the workgroup
             const float4 acc = enc0_grad_entries(q0[j] + w, q1[j], G0_NW, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed,
-                                                 step, row_scale, d4, item_lo, Ig);
+                                                 step, row_scale, d4, item_lo, Ig, uit[j]);
             __syncthreads();
             s_g[w][lane] = acc;
             __syncthreads();
@@ -417,7 +442,7 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad(int B, int I, int H, int n
                     const float4 p = s_g[i][lane];
                     t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
                 }
-                finish_row(u, t);
+                finish_row(u, t, uit[j]);
             }
         }
     }

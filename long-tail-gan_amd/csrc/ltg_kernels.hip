@@ -1804,28 +1804,33 @@ __global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int I, int H, int nu, cons
 
 // One row (H4 float4 columns at W4/m4/v4) from ordinal `from` to ordinal `to`: zero-gradient steps, then -- if G4 is given --
 // the step `to` itself with gradient row G4 and learning rate ad.lr_t (the caller's current step).
+// (q0_row_steps: the zero-gradient steps from + 1 .. nz of one float4 column that is already in registers; true = it changed)
+__device__ __forceinline__ bool q0_row_steps(float4& p, float4& mm, float4& vv, int from, int nz, const float* __restrict__ lr_hist, const AdamC ad) {
+    const bool m0 = mm.x == 0.f && mm.y == 0.f && mm.z == 0.f && mm.w == 0.f;
+    const bool v0 = vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
+    if (m0 && v0) return false;                           // a row no batch has touched yet: every step is the identity
+    if (m0) {                                             // W does not move (0 / (sqrt(v) + eps) == 0): only v decays
+        for (int j = from + 1; j <= nz; ++j) { vv.x *= ad.b2; vv.y *= ad.b2; vv.z *= ad.b2; vv.w *= ad.b2; }
+    } else {
+        for (int j = from + 1; j <= nz; ++j) {
+            const float lr = lr_hist[j & LTG_Q0_MASK];
+#define LTG_ADAM0(f)          \
+    mm.f = ad.b1 * mm.f;      \
+    vv.f = ad.b2 * vv.f;      \
+    p.f = adam_move(p.f, lr * mm.f, vv.f, ad.eps);   /* adam1 with g == 0: fma(b1, m, 0) rounds like b1 m */
+            LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
+#undef LTG_ADAM0
+        }
+    }
+    return true;
+}
 __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* __restrict__ m4, float4* __restrict__ v4, int H4, int from, int to,
                                                const float* __restrict__ lr_hist, const float4* __restrict__ G4, const AdamC ad) {
     const int nz = G4 ? to - 1 : to;   // last zero-gradient step
     for (int c = threadIdx.x; c < H4; c += blockDim.x) {
         float4 p = W4[c], mm = m4[c], vv = v4[c];
-        const bool m0 = mm.x == 0.f && mm.y == 0.f && mm.z == 0.f && mm.w == 0.f;
-        const bool v0 = vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
-        if (!G4 && m0 && v0) continue;                       // a row no batch has touched yet: every step is the identity
-        if (m0) {                                             // W does not move (0 / (sqrt(v) + eps) == 0): only v decays
-            if (!v0)
-                for (int j = from + 1; j <= nz; ++j) { vv.x *= ad.b2; vv.y *= ad.b2; vv.z *= ad.b2; vv.w *= ad.b2; }
-        } else {
-            for (int j = from + 1; j <= nz; ++j) {
-                const float lr = lr_hist[j & LTG_Q0_MASK];
-#define LTG_ADAM0(f)          \
-    mm.f = ad.b1 * mm.f;      \
-    vv.f = ad.b2 * vv.f;      \
-    p.f = adam_move(p.f, lr * mm.f, vv.f, ad.eps);   /* adam1 with g == 0: fma(b1, m, 0) rounds like b1 m */
-                LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
-#undef LTG_ADAM0
-            }
-        }
+        const bool moved = q0_row_steps(p, mm, vv, from, nz, lr_hist, ad);
+        if (!G4 && !moved) continue;
         if (G4) {
             const float4 g = G4[c];
 #define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
@@ -1841,18 +1846,73 @@ __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* 
 #define Q0_NT 192
 // rows of the batch's distinct items (G-step batches carry the list): up to `target`, before enc-0 reads them
 __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
-                                                           const int32_t* __restrict__ indices, int target, ltg_gen_state st, AdamC ad) {
+                                                           const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target,
+                                                           ltg_gen_state st, AdamC ad) {
     const int u = blockIdx.x;
     if (u >= nu) return;
-    const int i = indices[csr_pos[uptr[u]]];
+    const int H4 = H >> 2;
+    if (uitem && H4 <= Q0_NT) {   // the item in one load; its clock and its row requested together (three dependent round trips, not six)
+        const int i = uitem[u];
+        const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
+        const int from = st.q0_last[i];
+        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off], vv = reinterpret_cast<const float4*>(st.v[0])[off];
+        __syncthreads();   // every thread has read q0_last[i]
+        if (from >= target) return;
+        if ((int)threadIdx.x < H4 && q0_row_steps(p, mm, vv, from, target, st.q0_lr_hist, ad)) {
+            reinterpret_cast<float4*>(st.p[0])[off] = p;
+            reinterpret_cast<float4*>(st.m[0])[off] = mm;
+            reinterpret_cast<float4*>(st.v[0])[off] = vv;
+        }
+        if (threadIdx.x == 0) st.q0_last[i] = target;
+        return;
+    }
+    const int i = uitem ? uitem[u] : indices[csr_pos[uptr[u]]];
     const int from = st.q0_last[i];
     if (from >= target) return;
-    const int H4 = H >> 2;
     const size_t off = (size_t)i * H4;
     q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
                    from, target, st.q0_lr_hist, nullptr, ad);
     __syncthreads();   // every thread has read q0_last[i]
     if (threadIdx.x == 0) st.q0_last[i] = target;
+}
+
+// The catch-up of a batch's rows AND the rotating slice (rows start, start + stride, ...) in ONE launch, both up to `target`: a row
+// that is in both sets belongs to the workgroup whose atomic max on its clock comes first (the other one sees `target` and leaves);
+// the consumers are later launches.  The one-call step's form of the two kernels above and below (one launch, no side-stream join).
+__global__ __launch_bounds__(Q0_NT) void k_q0_touch_slice(int I, int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
+                                                          const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target, int start,
+                                                          int stride, ltg_gen_state st, AdamC ad) {
+    __shared__ int s_from;
+    const int b = blockIdx.x;
+    int i;
+    if (b < nu) i = uitem ? uitem[b] : indices[csr_pos[uptr[b]]];
+    else {
+        i = start + (b - nu) * stride;
+        if (i >= I) return;
+    }
+    const int H4 = H >> 2;
+    if (H4 <= Q0_NT) {   // the row requested beside the claim (rows are never written by two launches at once: whoever loses the claim
+                         // only discards what it loaded)
+        if (threadIdx.x == 0) s_from = atomicMax(st.q0_last + i, target);
+        const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
+        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off], vv = reinterpret_cast<const float4*>(st.v[0])[off];
+        __syncthreads();
+        const int from = s_from;
+        if (from >= target) return;
+        if ((int)threadIdx.x < H4 && q0_row_steps(p, mm, vv, from, target, st.q0_lr_hist, ad)) {
+            reinterpret_cast<float4*>(st.p[0])[off] = p;
+            reinterpret_cast<float4*>(st.m[0])[off] = mm;
+            reinterpret_cast<float4*>(st.v[0])[off] = vv;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) s_from = atomicMax(st.q0_last + i, target);
+    __syncthreads();
+    const int from = s_from;
+    if (from >= target) return;
+    const size_t off = (size_t)i * H4;
+    q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
+                   from, target, st.q0_lr_hist, nullptr, ad);
 }
 
 // forward-only batches (no distinct-item list): one workgroup per user row walks its entries; the first workgroup to claim
@@ -2364,7 +2424,8 @@ void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* 
     const AdamC ad = make_adam(cfg, 1);   // b1, b2, eps; the learning rates come from the history ring
     if (bt->uptr && bt->csr_pos) {
         if (bt->n_unique > 0)
-            hipLaunchKernelGGL(k_q0_touch_unique, dim3(bt->n_unique), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, gen->q0_ord, *gen, ad);
+            hipLaunchKernelGGL(k_q0_touch_unique, dim3(bt->n_unique), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
+                               gen->q0_ord, *gen, ad);
     } else {
         hipLaunchKernelGGL(k_q0_touch_rows, dim3(bt->n_rows), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_rows, bt->indptr, bt->indices, gen->q0_ord, *gen, ad);
     }
@@ -2886,7 +2947,7 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
     if (fast_on(cfg))
         hipLaunchKernelGGL(fk_enc0_grad, dim3((H / 4 + 63) / 64, (nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW), dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos,
                            bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0,
-                           cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{}, ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0);
+                           cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{}, ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem);
     else
         hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), st, B, I, H, nu, bt->uptr, bt->rowidx,
                            bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
@@ -3331,7 +3392,10 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream, sd = (hipStream_t)pp->side_stream;
     hipEvent_t ev_fork = (hipEvent_t)pp->ev_fork, ev_dec1 = (hipEvent_t)pp->ev_dec1, ev_slice = (hipEvent_t)pp->ev_slice;
-    const bool fork_dec1 = (pp->flags & LTG_PIPE_NO_DEC1_FORK) == 0, fork_slice = fork_dec1 && (pp->flags & LTG_PIPE_NO_SLICE_FORK) == 0;
+    const bool fork_dec1 = (pp->flags & LTG_PIPE_NO_DEC1_FORK) == 0;
+    // the lazy clock's slice of the previous step: in this call's catch-up launch (default), on the side stream, or at the end of its own step
+    const bool defer_slice = fork_dec1 && (pp->flags & LTG_PIPE_NO_SLICE_FORK) == 0;
+    const bool fork_slice = defer_slice && (pp->flags & LTG_PIPE_SLICE_ON_SIDE) != 0, merge_slice = defer_slice && !fork_slice;
     Workspace w = carve(cfg, B, nf, (char*)ws);
     if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
     const Probe pr{o->probe, st};
@@ -3341,7 +3405,13 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
 #define LTG_COMM(x) do { if ((x) != 0) return LTG_ELAUNCH; } while (0)
     // ---- the clock slice forked by the PREVIOUS call is done (it must not meet the catch-up below on a row); the rows this batch reads
     if (fork_slice) LTG_HIP(hipStreamWaitEvent(st, ev_slice, 0));
-    q0_touch(cfg, gen, bt, st);
+    const int qP = gen->q0_period;
+    if (merge_slice && gen->q0_ord > 0 && gen->q0_ord % qP < I) {
+        const int start = gen->q0_ord % qP, ns = (I - start + qP - 1) / qP;
+        hipLaunchKernelGGL(k_q0_touch_slice, dim3(bt->n_unique + ns), dim3(Q0_NT), 0, st, I, H, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
+                           gen->q0_ord, start, qP, *gen, make_adam(cfg, 1));
+    } else
+        q0_touch(cfg, gen, bt, st);
     // ---- forward: enc-0 over the local slab -> exchange 1 -> enc-1 (bias + tanh in its loader), dec-0, local logits + statistics
     {
         ltg_gen_acts a1 = *acts;
@@ -3370,7 +3440,6 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     hipLaunchKernelGGL(k_dlogits_combine<true>, dim3((I + DL_SEG - 1) / DL_SEG, B), dim3(NT), 0, st, B, I, R, bt->indptr, bt->indices, bt->values, acts->logits,
                        pp->rowpart_all, acts->kl_rows, nf > 0 ? w.y : (const float*)nullptr, o->cnt, o->anneal, o->gan_lambda, nf, fake->row, fake->niche, fake->pop,
                        w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo);
-    const int qP = gen->q0_period;
     {
         const int kchunk = dh2_stream_chunk(I), nsplit = (I + kchunk - 1) / kchunk;
         LTG_PROBED(pr, LTG_K_DH2, hipLaunchKernelGGL(k_dh2_stream<true>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog,
@@ -3409,7 +3478,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
     g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad);
     g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true);
-    if (!fork_slice) {   // the slice of THIS step at its end, in program order (the cut-point schedule)
+    if (!defer_slice) {   // the slice of THIS step at its end, in program order (the cut-point schedule)
         const int ord = gen->q0_ord + 1, start = ord % qP;
         if (start < I) hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, st, I, H, start, qP, ord, *gen, make_adam(cfg, 1));
     }

@@ -5,7 +5,7 @@ user-id ranges, fixed for the whole run).
 
 Per batch b (users [b*BS, min((b+1)*BS, N))):
   X rows          indptr/indices               (replaces the dense float32 [B,I] feed)
-  X^T view        slot[b] / uptr / rowidx / csr_pos (entries grouped by item: sparse gradient of W_q0)
+  X^T view        slot[b] / uptr / uitem / rowidx / csr_pos (entries grouped by item: sparse gradient of W_q0)
   real pairs      x_popular_n / x_niche        (train.py:223-224; static)
   sampler inputs  candidates, popular lists, to_sample, output slots (train.py:213-227)
 """
@@ -169,7 +169,7 @@ class DeviceData:
         self.indices = up(tr.indices, np.int32)
         ones = np.all(tr.data == 1.0)
         self.values = None if ones else up(tr.data, np.float32)
-        slots, uptrs, rowidx, cpos, ent_off, uptr_off = [], [], [], [], [0], [0]
+        slots, uptrs, uitems, rowidx, cpos, ent_off, uptr_off = [], [], [], [], [], [0], [0]
         if slot_cache is None:
             slot_cache = I < 65536 and self.n_batches * I * 4 <= SLOT_CACHE_BYTES
         for b in range(self.n_batches):
@@ -178,12 +178,14 @@ class DeviceData:
             if slot_cache:
                 slots.append(sl)
             uptrs.append(up_)
+            uitems.append(np.append(np.flatnonzero(sl >= 0), -1).astype(np.int32))   # (padded to uptr's length: one offset serves both)
             rowidx.append(ri)
             cpos.append(ps)
             ent_off.append(ent_off[-1] + len(ri))
             uptr_off.append(uptr_off[-1] + len(up_))
         self.slot = up(np.concatenate(slots)) if slot_cache else None
         self.uptr = up(np.concatenate(uptrs))
+        self.uitem = None if os.environ.get("LTGAN_NO_UITEM") else up(np.concatenate(uitems))   # (measurement switch: the longer index chain)
         self.rowidx = up(np.concatenate(rowidx) if ent_off[-1] else np.zeros(1, np.int32))
         self.csr_pos = up(np.concatenate(cpos) if ent_off[-1] else np.zeros(1, np.int32))
         self.ent_off, self.uptr_off = ent_off, uptr_off
@@ -214,7 +216,7 @@ class DeviceData:
         I = self.I
         batch = CsrRows(self.indptr, self.indices, lo, hi, values=self.values, slot=self.slot, uptr=self.uptr, rowidx=self.rowidx,
                         csr_pos=self.csr_pos, n_unique=self.uptr_off[b + 1] - self.uptr_off[b] - 1, slot_off=b * I,
-                        uptr_off=self.uptr_off[b], ent_off=self.ent_off[b], row_norm2=self.row_norm2)
+                        uptr_off=self.uptr_off[b], ent_off=self.ent_off[b], row_norm2=self.row_norm2, uitem=self.uitem)
         # csr_pos holds ABSOLUTE positions and rowidx LOCAL rows: both are already relative to the arrays given
         r0, r1 = int(idx.real_ptr[lo]), int(idx.real_ptr[hi])
         real = Pairs(self.real_pop, self.real_nic, None, n=r1 - r0, off=r0)

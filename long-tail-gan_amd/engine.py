@@ -100,12 +100,12 @@ class CsrRows:
     view (entries grouped by item) that the G step needs."""
 
     def __init__(self, indptr, indices, row_lo, row_hi, values=None, slot=None, uptr=None, rowidx=None, csr_pos=None,
-                 n_unique=0, slot_off=0, uptr_off=0, ent_off=0, row_norm2=None):
-        self.keep = (indptr, indices, values, slot, uptr, rowidx, csr_pos, row_norm2)
+                 n_unique=0, slot_off=0, uptr_off=0, ent_off=0, row_norm2=None, uitem=None, uitem_off=None):
+        self.keep = (indptr, indices, values, slot, uptr, rowidx, csr_pos, row_norm2, uitem)
         self.n_rows = int(row_hi - row_lo)
         self.c = cabi.ltg_batch(self.n_rows, int(n_unique), _ptr(indptr, row_lo), _ptr(indices), _ptr(values),
                                 _ptr(slot, slot_off), _ptr(uptr, uptr_off), _ptr(rowidx, ent_off), _ptr(csr_pos, ent_off),
-                                _ptr(row_norm2, row_lo))
+                                _ptr(row_norm2, row_lo), _ptr(uitem, uptr_off if uitem_off is None else uitem_off))
 
 
 class Pairs:

@@ -74,7 +74,7 @@ class Session:
         if with_csc:
             slot, uptr, rowidx, pos = batch_csc(X, 0, B, self.eng.I)
             kw.update(slot=self._t(slot, np.int32), uptr=self._t(uptr, np.int32), rowidx=self._t(rowidx, np.int32),
-                      csr_pos=self._t(pos, np.int32), n_unique=len(uptr) - 1)
+                      csr_pos=self._t(pos, np.int32), n_unique=len(uptr) - 1, uitem=self._t(np.flatnonzero(slot >= 0), np.int32))
         batch = CsrRows(self._t(X.indptr, np.int32), self._t(X.indices, np.int32), 0, B, **kw)
         if self._acts is None or self._acts.rows < B:
             self._acts = self.eng.new_acts(B)

@@ -23,14 +23,14 @@ def test_header_symbols_are_exported_and_bound():
     lib = cabi.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 10
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 11
 
 
 def test_struct_layouts_match_header():
     from ltgan import _cabi as cabi
     assert C.sizeof(cabi.ltg_config) == 80 and cabi.ltg_config.seed.offset == 72
     assert C.sizeof(cabi.ltg_gen_state) == 28 * 8 and cabi.ltg_gen_state.q0_ord.offset == 27 * 8 and C.sizeof(cabi.ltg_disc_state) == 30 * 8 and cabi.ltg_disc_state.emb_fp8.offset == 25 * 8 and cabi.ltg_disc_state.w3_fp8.offset == 29 * 8
-    assert C.sizeof(cabi.ltg_batch) == 8 + 8 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
+    assert C.sizeof(cabi.ltg_batch) == 8 + 9 * 8 and cabi.ltg_batch.uitem.offset == 8 + 8 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
     assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8 + 8 and cabi.ltg_fwd_opts.rows_per_step.offset == 40
     assert C.sizeof(cabi.ltg_pairs) == 8 + 3 * 8
     assert C.sizeof(cabi.ltg_d_opts) == 8 + 8 + 7 * 8

@@ -802,6 +802,14 @@ def test_g_step_without_slot_cache_is_bit_identical():
         assert torch.equal(a, b)
 
 
+def cabi_flags(*names):
+    from ltgan import _cabi as cabi
+    v = 0
+    for n in names:
+        v |= getattr(cabi, n)
+    return v
+
+
 @pytest.mark.parametrize("precision,period", [("fp32", 3), ("bf16", 5)])
 def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dense_sweep(precision, period):
     """ltg_gen_state.q0_last: TF's Adam (train.py:160-164) moves every row of W_q0 every step; the lazy clock applies a row's
@@ -817,9 +825,14 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
     Xf = Hh.random_history(rng, 40, I, mean_nnz=30)                       # forward-only batch (no distinct-item list)
     fakes = [_fake_pairs(rng, X, I) for X in Xs]
     outs = []
-    # "one-call": the lazy clock inside ltg_g_step_sharded -- the slice of step t runs on its own stream behind the row catch-up
-    # of step t + 1, the decoder weight update beside the next step's encoder half (bf16 decoder path only)
-    for variant in ("dense", "lazy") + (("one-call",) if precision == "bf16" else ()):
+    # "one-call": the lazy clock inside ltg_g_step_sharded -- the slice of step t rides in the catch-up launch of step t + 1 (a row in
+    # both sets goes to whichever workgroup claims it), the decoder weight update runs beside the next step's encoder half (bf16 decoder
+    # path only); "-side-slice": the slice on the side stream instead (round 3's first
+    # schedule)
+    # "-no-uitem": the batch without its list of distinct items (ltg_batch.uitem, ABI v11): the kernels that walk the distinct items then
+    # find an item through uptr -> csr_pos -> indices, as before
+    pipe_flags = {"one-call": 0, "one-call-side-slice": cabi_flags("LTG_PIPE_SLICE_ON_SIDE"), "one-call-no-uitem": 0}
+    for variant in ("dense", "lazy", "lazy-no-uitem") + (tuple(pipe_flags) if precision == "bf16" else ()):
         lazy = variant != "dense"
         eng = _engine(I, precision, lr=1e-3, lazy_q0=lazy, q0_period=period)
         assert eng.lazy_q0 == lazy
@@ -830,15 +843,17 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
         eng.q0_defer = True
         losses, mids = [], []
         pipe = None
-        if variant == "one-call":
+        if variant in pipe_flags:
             from ltgan.engine import Pipe
             assert eng.sharded_step_ok(B)
-            pipe = Pipe(eng, B, flags=int(os.environ.get("LTGAN_TEST_PIPE_FLAGS", "0")))
+            pipe = Pipe(eng, B, flags=pipe_flags[variant] | int(os.environ.get("LTGAN_TEST_PIPE_FLAGS", "0")))
         for s in range(2 * n_batches):
             X = Xs[s % n_batches]
             rows, gen, pop = fakes[s % n_batches]
             slot, uptr, rowidx, pos, nu = Hh.csc_view(X)
-            batch = CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, uptr=t(uptr), rowidx=t(rowidx), csr_pos=t(pos), n_unique=nu)
+            uitem = None if variant.endswith("no-uitem") else t(np.flatnonzero(slot >= 0).astype(np.int32))
+            batch = CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, uptr=t(uptr), rowidx=t(rowidx), csr_pos=t(pos), n_unique=nu,
+                            uitem=uitem, uitem_off=0)
             fake = Pairs(t(pop), t(gen), t(rows))
             cnt = torch.tensor([int(((gen >= 0) & (pop >= 0)).sum())], dtype=torch.int32, device=dev)
             eng.adam_t += s % 3                                           # the shared counter also moves between G steps (D steps)
