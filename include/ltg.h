@@ -422,6 +422,7 @@ typedef struct ltg_pipe {
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
 #define LTG_PIPE_SLICE_ON_SIDE 4 /* the slice step t - 1 owes on the side stream in front of the weight update (joined by ev_slice) instead of
                                     in the catch-up launch of call t */
+#define LTG_PIPE_WIDE_GRAD 8     /* the sparse W_q0 gradient in its column-blocked shape (three times the waves) although it runs beside the update */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
 int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);

@@ -308,20 +308,25 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
 // STRIDED over the row list (row j of group g = j * groups + g): the heavy rows are the lowest ids (popularity order) and
 // would otherwise all sit in the first group and run one after the other (measured: 35 us instead of 14).
 constexpr int G0_NT = 512, G0_NW = 8, G0_U = 8, G0_LIGHT = 16;
-__device__ __forceinline__ float4 enc0_grad_entries(int q0, int q1, int stride, bool is_item, int c4, int H4, const int32_t* __restrict__ rowidx,
-                                                    const int32_t* __restrict__ csr_pos, const int32_t* __restrict__ indices,
-                                                    const float* __restrict__ values, const uint8_t* __restrict__ drop_keep, float keep,
-                                                    uint64_t seed, uint64_t step, const float* __restrict__ row_scale,
-                                                    const float4* __restrict__ d4, int item_lo, int Ig, int item = -1) {
+// entries q0, q0 + stride, ... < q1 of one gradient row, U in flight, over NCB chunks of 64 float4 columns (c4[k] = the lane's column in
+// chunk k): acc[k] += scale * da1[row][c4[k]] in entry order, one fma per element (explicit: both shapes of the kernel must give the
+// same bits, and the compiler's contraction choices differ from kernel to kernel)
+template <int U, int NCB>
+__device__ __forceinline__ void enc0_grad_entries(float4 (&acc)[NCB], int q0, int q1, int stride, bool is_item, const int (&c4)[NCB], int H4,
+                                                  const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
+                                                  const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                  const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
+                                                  const float* __restrict__ row_scale, const float4* __restrict__ d4, int item_lo, int Ig, int item) {
     // item >= 0: the row's item is known (ltg_batch.uitem) -- with implicit values and the in-kernel dropout draw an entry then needs its
     // user row only: rowidx -> (row_scale, da1 row) instead of csr_pos -> indices -> ...
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool need_pos = item < 0 || values != nullptr || drop_keep != nullptr;   // uniform
-    for (int q = q0; q < q1; q += G0_U * stride) {
-        int b[G0_U];
-        float sc[G0_U];
 #pragma unroll
-        for (int t = 0; t < G0_U; ++t) {
+    for (int k = 0; k < NCB; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool need_pos = item < 0 || values != nullptr || drop_keep != nullptr;   // uniform
+    for (int q = q0; q < q1; q += U * stride) {
+        int b[U];
+        float sc[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
             const int qt = q + t * stride;
             const bool ok = qt < q1;
             const int qc = ok ? qt : q;
@@ -337,18 +342,21 @@ __device__ __forceinline__ float4 enc0_grad_entries(int q0, int q1, int stride, 
                 sc[t] = ok ? 1.f : 0.f;
             }
         }
-        float4 d[G0_U];
+        float4 d[U][NCB];
 #pragma unroll
-        for (int t = 0; t < G0_U; ++t) d[t] = d4[(size_t)b[t] * H4 + c4];
+        for (int t = 0; t < U; ++t)
 #pragma unroll
-        for (int t = 0; t < G0_U; ++t) {
-            acc.x += sc[t] * d[t].x;
-            acc.y += sc[t] * d[t].y;
-            acc.z += sc[t] * d[t].z;
-            acc.w += sc[t] * d[t].w;
-        }
+            for (int k = 0; k < NCB; ++k) d[t][k] = d4[(size_t)b[t] * H4 + c4[k]];
+#pragma unroll
+        for (int t = 0; t < U; ++t)
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) {
+                acc[k].x = __builtin_fmaf(sc[t], d[t][k].x, acc[k].x);
+                acc[k].y = __builtin_fmaf(sc[t], d[t][k].y, acc[k].y);
+                acc[k].z = __builtin_fmaf(sc[t], d[t][k].z, acc[k].z);
+                acc[k].w = __builtin_fmaf(sc[t], d[t][k].w, acc[k].w);
+            }
     }
-    return acc;
 }
 #ifndef LTG_G0_WAVES
 #define LTG_G0_WAVES 6   // waves per SIMD the register allocation aims at (80 registers: three workgroups per CU; four registers spill)
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(G0_NT, LTG_G0_WAVES) void fk_enc0_grad(int B, int I
     const int cb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int H4 = H >> 2, nrows = nu + ENC0_BIAS_PARTS;
     const int c4 = min(64 * cb + lane, H4 - 1);
+    const int c4s[1] = {c4};
     const bool cok = 64 * cb + lane < H4;
     struct RowReq { float4 p, m, v; };
     auto row_off = [&](int i) { return (size_t)i * H4 + c4; };
@@ -417,11 +426,12 @@ __global__ __launch_bounds__(G0_NT, LTG_G0_WAVES) void fk_enc0_grad(int B, int I
             const bool pre = lazy_ord > 0 && u < nu && uit[j] >= 0;   // (wave-uniform) the row's W / m / v travel while the entries are gathered
             RowReq r{};
             if (pre) r = row_request(uit[j]);
-            const float4 acc = enc0_grad_entries(q0[j], q1[j], 1, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step,
-                                                 row_scale, d4, item_lo, Ig, uit[j]);
+            float4 acc[1];
+            enc0_grad_entries<G0_U, 1>(acc, q0[j], q1[j], 1, u < nu, c4s, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step, row_scale, d4,
+                                       item_lo, Ig, uit[j]);
             if (cok) {
-                if (pre) adam_row(uit[j], r, acc);
-                else finish_row(u, acc, uit[j]);
+                if (pre) adam_row(uit[j], r, acc[0]);
+                else finish_row(u, acc[0], uit[j]);
             }
         }
     }
@@ -430,10 +440,11 @@ __global__ __launch_bounds__(G0_NT, LTG_G0_WAVES) void fk_enc0_grad(int B, int I
     for (int j = 0; j < G0_NW; ++j) {
         const int u = j * (int)gridDim.y + (int)blockIdx.y;
         if (u < nrows && q1[j] - q0[j] > G0_LIGHT) {     // uniform over the workgroup
-            const float4 acc = enc0_grad_entries(q0[j] + w, q1[j], G0_NW, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed,
-                                                 step, row_scale, d4, item_lo, Ig, uit[j]);
+            float4 acc[1];
+            enc0_grad_entries<G0_U, 1>(acc, q0[j] + w, q1[j], G0_NW, u < nu, c4s, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step, row_scale,
+                                       d4, item_lo, Ig, uit[j]);
             __syncthreads();
-            s_g[w][lane] = acc;
+            s_g[w][lane] = acc[0];
             __syncthreads();
             if (w == 0 && cok) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -444,6 +455,118 @@ __global__ __launch_bounds__(G0_NT, LTG_G0_WAVES) void fk_enc0_grad(int B, int I
                 }
                 finish_row(u, t, uit[j]);
             }
+        }
+    }
+}
+
+// The same gradient rows with ONE wave per row over ALL columns (NCB chunks of 64 float4; H <= 768): a third of the waves of the
+// column-blocked kernel above.  The shape for the one-call step, where the kernel runs beside the streaming decoder weight update: that
+// update holds 196 of the 256 CUs (one 8-wave workgroup of 224 registers and 106 KB of LDS each), and what a kernel of the chain costs
+// beside it is mostly how many ROUNDS its waves take on the 60 CUs left (measured with the update replaced by a dummy of its footprint and
+// no memory traffic: fk_enc0_grad 15.5 -> 35-38 us, with the real update 38-46 us) -- 2 200 waves there, ~750 here.
+// Same bits as fk_enc0_grad (same entry order per column, the heavy rows' eight chains, explicit fmas).
+template <int NCB>
+__global__ __launch_bounds__(G0_NT) void fk_enc0_grad_rows(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
+                                                           const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
+                                                           const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                           const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
+                                                           const float* __restrict__ row_scale, const float* __restrict__ da1,
+                                                           float* __restrict__ G, int item_lo, int Ig, ltg_gen_state st, AdamC ad, int lazy_ord,
+                                                           const int32_t* __restrict__ uitem) {
+    constexpr int U = NCB == 1 ? 8 : (NCB == 2 ? 4 : 3);   // entries in flight per wave (x NCB float4 each)
+    __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][NCB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int H4 = H >> 2, nrows = nu + ENC0_BIAS_PARTS;
+    int c4[NCB];
+    bool cok[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+        c4[k] = min(64 * k + lane, H4 - 1);
+        cok[k] = 64 * k + lane < H4;
+    }
+    const float4* d4 = reinterpret_cast<const float4*>(da1);
+    const int per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+    auto finish = [&](int u, int item, int k, float4 g, bool have, float4 p, float4 mm, float4 vv) {
+        if (lazy_ord > 0 && u < nu) {
+            const int i = item >= 0 ? item : indices[csr_pos[uptr[u]]];
+            const size_t off = (size_t)i * H4 + c4[k];
+            if (!have) {
+                p = reinterpret_cast<const float4*>(st.p[0])[off];
+                mm = reinterpret_cast<const float4*>(st.m[0])[off];
+                vv = reinterpret_cast<const float4*>(st.v[0])[off];
+            }
+            adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
+            adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
+            adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
+            adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
+            reinterpret_cast<float4*>(st.p[0])[off] = p;
+            reinterpret_cast<float4*>(st.m[0])[off] = mm;
+            reinterpret_cast<float4*>(st.v[0])[off] = vv;
+            if (k == 0 && lane == 0) st.q0_last[i] = lazy_ord;
+        } else {
+            reinterpret_cast<float4*>(G)[(size_t)u * H4 + c4[k]] = g;
+        }
+    };
+    // entry ranges of the group's eight rows, strided over the row list as in fk_enc0_grad (every wave computes all eight: the heavy /
+    // light split must be uniform)
+    int q0[G0_NW], q1[G0_NW], uit[G0_NW];
+#pragma unroll
+    for (int j = 0; j < G0_NW; ++j) {
+        const int u = min(j * (int)gridDim.x + (int)blockIdx.x, nrows - 1);
+        const int bp = u - nu;
+        q0[j] = u < nu ? uptr[u] : min(B, bp * per);
+        q1[j] = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
+        uit[j] = (uitem && u < nu) ? uitem[u] : -1;
+        if (j * (int)gridDim.x + (int)blockIdx.x >= nrows) q1[j] = q0[j];     // beyond the last row: empty
+    }
+    // light rows: wave j alone, its W / m / v rows requested before the gather
+#pragma unroll
+    for (int j = 0; j < G0_NW; ++j) {
+        const int u = j * (int)gridDim.x + (int)blockIdx.x;
+        if (j == w && u < nrows && q1[j] - q0[j] <= G0_LIGHT) {
+            const bool pre = lazy_ord > 0 && u < nu && uit[j] >= 0;   // wave-uniform
+            float4 rp[NCB], rm[NCB], rv[NCB];
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) {
+                rp[k] = rm[k] = rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pre) {
+                    const size_t off = (size_t)uit[j] * H4 + c4[k];
+                    rp[k] = reinterpret_cast<const float4*>(st.p[0])[off];
+                    rm[k] = reinterpret_cast<const float4*>(st.m[0])[off];
+                    rv[k] = reinterpret_cast<const float4*>(st.v[0])[off];
+                }
+            }
+            float4 acc[NCB];
+            enc0_grad_entries<U, NCB>(acc, q0[j], q1[j], 1, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step, row_scale, d4,
+                                      item_lo, Ig, uit[j]);
+#pragma unroll
+            for (int k = 0; k < NCB; ++k)
+                if (cok[k]) finish(u, uit[j], k, acc[k], pre, rp[k], rm[k], rv[k]);
+        }
+    }
+    // heavy rows: all eight waves (chain w = entries w, w + 8, ...), one row after the other; chunk k is finished by wave k
+#pragma unroll
+    for (int j = 0; j < G0_NW; ++j) {
+        const int u = j * (int)gridDim.x + (int)blockIdx.x;
+        if (u < nrows && q1[j] - q0[j] > G0_LIGHT) {     // uniform over the workgroup
+            float4 acc[NCB];
+            enc0_grad_entries<U, NCB>(acc, q0[j] + w, q1[j], G0_NW, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step, row_scale,
+                                      d4, item_lo, Ig, uit[j]);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) s_g[w][64 * k + lane] = acc[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NCB; ++k)
+                if (w == k && cok[k]) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < G0_NW; ++i) {
+                        const float4 p = s_g[i][64 * k + lane];
+                        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+                    }
+                    finish(u, uit[j], k, t, false, t, t, t);
+                }
         }
     }
 }

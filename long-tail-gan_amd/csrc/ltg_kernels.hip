@@ -534,6 +534,21 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     __shared__ __attribute__((aligned(16))) float Cs[8 * 32 * DW_LDC];   // per-wave [32][80] gradient blocks
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     float4 *W4 = reinterpret_cast<float4*>(st.p[3]), *M4 = reinterpret_cast<float4*>(st.m[3]), *V4 = reinterpret_cast<float4*>(st.v[3]);
+#if defined(LTG_X_SPIN)
+    // MEASUREMENT BUILD ONLY (results wrong): the kernel's footprint (registers, LDS, one workgroup per CU) for LTG_X_SPIN us, no memory traffic
+    {
+        Dl[0][tid] = 0;
+        Cs[tid] = 0.f;
+        asm volatile("v_mov_b32 v220, 0" ::: "v220");
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)(LTG_X_SPIN) * 100ull) __builtin_amdgcn_s_sleep(16);
+        if (Dl[0][tid] == 1) W4[0].x = Cs[tid];
+        return;
+    }
+#elif defined(LTG_X_NOUPDATE)
+    // MEASUREMENT BUILD ONLY (weights do not move): no update at all -- what the chain costs with nothing beside it
+    if (B >= 0) return;
+#endif
     float *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
     unsigned short* Wb = st.wp1t_bf16;
     // stationary B fragments: B[k = b][n] = h2[b][n] (n < H), 1 (n == H), 0 beyond.  Built through LDS in four
@@ -625,12 +640,23 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     // addressing: (uniform row base, computed on the scalar unit) + (one 32-bit lane offset per pass) -- global_load with
     // an SGPR base, so the unrolled stages do not pin a VGPR pair per access
 #define DW_AT(T, BASE, UB, LB) (*(T __attribute__((address_space(1)))*)(ltg_uniform_ptr(reinterpret_cast<const char*>(BASE) + (UB)) + (LB)))
+    // theta / m / v as NON-TEMPORAL accesses (the nt bit of global_load / global_store): each element is touched exactly once per step, by
+    // this kernel only (the forward reads the bf16 shadow) -- 360 MB per step at 25 024 items that would otherwise push everything else
+    // out of the L2s and the memory-side cache.  Measured (same box, interleaved): per-rank proxy 197-204 -> 194 us per G step, C4-shaped
+    // phase G 272-274 -> 256-262 ms, C3-shaped 117.6 -> 114.7 ms.  -DLTG_DW_TEMPORAL builds the plain accesses.
+#ifndef LTG_DW_TEMPORAL
+#define DW_LDG(P) __builtin_nontemporal_load(P)
+#define DW_STG(V, P) __builtin_nontemporal_store(V, P)
+#else
+#define DW_LDG(P) (*(P))
+#define DW_STG(V, P) (*(P) = (V))
+#endif
 #define DW_LD(S, tt, NJ, J0, LOFF)                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
         const size_t u = (size_t)((tt) * 32 + 4 * w) * rowB + 1024u * ((J0) + jj);      \
-        S##p[jj] = DW_AT(const ltg_f32x4, W4, u, LOFF);                                 \
-        S##m[jj] = DW_AT(const ltg_f32x4, M4, u, LOFF);                                 \
-        S##v[jj] = DW_AT(const ltg_f32x4, V4, u, LOFF);                                 \
+        S##p[jj] = DW_LDG(&DW_AT(const ltg_f32x4, W4, u, LOFF));                        \
+        S##m[jj] = DW_LDG(&DW_AT(const ltg_f32x4, M4, u, LOFF));                        \
+        S##v[jj] = DW_LDG(&DW_AT(const ltg_f32x4, V4, u, LOFF));                        \
     }
 #define DW_AP(S, tt, NJ, J0, LOFF)                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
@@ -640,12 +666,38 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
         ltg_f32x4 p = S##p[jj], mm = S##m[jj], v2 = S##v[jj];                           \
         DW_ADAM1(x) DW_ADAM1(y) DW_ADAM1(z) DW_ADAM1(w)                                 \
         const size_t u = (size_t)((tt) * 32 + 4 * w) * rowB + 1024u * ((J0) + jj);      \
-        DW_AT(ltg_f32x4, W4, u, LOFF) = p;                                              \
-        DW_AT(ltg_f32x4, M4, u, LOFF) = mm;                                             \
-        DW_AT(ltg_f32x4, V4, u, LOFF) = v2;                                             \
+        DW_STG(p, &DW_AT(ltg_f32x4, W4, u, LOFF));                                      \
+        DW_STG(mm, &DW_AT(ltg_f32x4, M4, u, LOFF));                                     \
+        DW_STG(v2, &DW_AT(ltg_f32x4, V4, u, LOFF));                                     \
         const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                    \
         DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + 4 * w) * (ST_KP * 2), (unsigned)(rl * (ST_KP * 2) + 8 * ch)) = ltg_u32x2{pk.x, pk.y}; \
     }
+#define DW_STAGES() \
+        DW_LD(B, t, 2, 2, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(A, t, 2, 0, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(A, t, 2, 4, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(B, t, 2, 2, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(B, t, 2, 6, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(A, t, 2, 4, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(A, t, 1, 8, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(B, t, 2, 6, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(B, t, 1, 9, lo9)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(A, t, 1, 8, lo)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_LD(A, tn, 2, 0, lo) /* first stage of the next tile (of this one again at the end: unused) */             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_AP(B, t, 1, 9, lo9)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);
+#define DW_FIRST(tt) DW_LD(A, tt, 2, 0, lo)
     // one tile: set A holds the first stage of tile t (requested one stage earlier); six stages alternate A, B so the
     // next tile starts on A again -- one loop body, no register-set swap (a swap would have to wait for loads in flight)
 #define DW_BODY()                                                                                              \
@@ -686,30 +738,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
            lane 3, loads here, update at the end of the tile -- no predicate, nothing waits for these loads */       \
         const int ib = t * 32 + 4 * w + min(lane, 3);                                                                \
         float pbv = bb[ib], mbv = mb[ib], vbv = vb[ib];                                                              \
-        DW_LD(B, t, 2, 2, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(A, t, 2, 0, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(A, t, 2, 4, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(B, t, 2, 2, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(B, t, 2, 6, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(A, t, 2, 4, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(A, t, 1, 8, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(B, t, 2, 6, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(B, t, 1, 9, lo9)                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(A, t, 1, 8, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(A, tn, 2, 0, lo) /* first stage of the next tile (of this one again at the end: unused) */             \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(B, t, 1, 9, lo9)                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW_STAGES()                                                                                                  \
         {                                                                                                            \
             const float gbias = Cs[(H / 80) * (32 * DW_LDC) + (4 * w + min(lane, 3)) * DW_LDC + H % 80];             \
             adam1(pbv, mbv, vbv, gbias, ad.lr_t, ad);                                                                \
@@ -720,8 +749,12 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
         __syncthreads();                                                                                             \
         cur ^= 1;                                                                                                    \
     }
-    if (t < ntiles) { DW_LD(A, t, 2, 0, lo) }
+    if (t < ntiles) { DW_FIRST(t) }
     for (; t < ntiles; t += G) DW_BODY()
+#undef DW_STAGES
+#undef DW_FIRST
+#undef DW_LDG
+#undef DW_STG
 #undef DW_AT
 #undef DW_LD
 #undef DW_AP
@@ -1855,7 +1888,8 @@ __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const 
         const int i = uitem[u];
         const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
         const int from = st.q0_last[i];
-        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off], vv = reinterpret_cast<const float4*>(st.v[0])[off];
+        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
+               vv = reinterpret_cast<const float4*>(st.v[0])[off];
         __syncthreads();   // every thread has read q0_last[i]
         if (from >= target) return;
         if ((int)threadIdx.x < H4 && q0_row_steps(p, mm, vv, from, target, st.q0_lr_hist, ad)) {
@@ -1895,7 +1929,8 @@ __global__ __launch_bounds__(Q0_NT) void k_q0_touch_slice(int I, int H, int nu, 
                          // only discards what it loaded)
         if (threadIdx.x == 0) s_from = atomicMax(st.q0_last + i, target);
         const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
-        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off], vv = reinterpret_cast<const float4*>(st.v[0])[off];
+        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
+               vv = reinterpret_cast<const float4*>(st.v[0])[off];
         __syncthreads();
         const int from = s_from;
         if (from >= target) return;
@@ -2940,11 +2975,22 @@ static const int32_t* g_slot_map(const ltg_config* cfg, const ltg_batch* bt, con
 
 // sparse gradient rows of W_q0 (+ partial bias rows) into w.gq0
 static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts, const Workspace& w,
-                        hipStream_t st, const ltg_gen_state* gen = nullptr, const AdamC* ad = nullptr) {   // gen + ad: fused lazy Adam step
+                        hipStream_t st, const ltg_gen_state* gen = nullptr, const AdamC* ad = nullptr, bool row_waves = true) {   // gen + ad: fused lazy Adam step
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique;
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_GRAD);
-    if (fast_on(cfg))
+    if (fast_on(cfg) && row_waves) {   // one wave per row over all columns: a third of the waves (see fk_enc0_grad_rows)
+        const int ncb = (H / 4 + 63) / 64;
+        const dim3 g((nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW);
+#define LTG_G0_ROWS(N)                                                                                                                                   \
+    hipLaunchKernelGGL(fk_enc0_grad_rows<N>, g, dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, \
+                       o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{},     \
+                       ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem)
+        if (ncb == 1) LTG_G0_ROWS(1);
+        else if (ncb == 2) LTG_G0_ROWS(2);
+        else LTG_G0_ROWS(3);
+#undef LTG_G0_ROWS
+    } else if (fast_on(cfg))
         hipLaunchKernelGGL(fk_enc0_grad, dim3((H / 4 + 63) / 64, (nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW), dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos,
                            bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0,
                            cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{}, ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem);
@@ -3026,8 +3072,9 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
     const bool fused = lazy && fast_on(cfg) && (cfg->reserved0 & (1 << 25)) == 0;   // Adam on the batch's rows inside the gradient kernel
-    if (fused) g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad);
-    else if (slot || lazy) g_enc0_grad(cfg, bt, o, acts, w, st);
+    const bool row_waves = (cfg->reserved0 & (1 << 14)) == 0;   // tuning-knob bit 14: the column-blocked shape of the sparse gradient
+    if (fused) g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, row_waves);
+    else if (slot || lazy) g_enc0_grad(cfg, bt, o, acts, w, st, nullptr, nullptr, row_waves);
     const bool own_sweep = (slot && cfg->n_items >= 8192) || lazy;   // HBM-bound sweep: its own launch at full occupancy (measured 490 vs
                                                                      // 525 us at 200 000 items when it rode in the 118-register job kernel)
     g_jobs(-1, cfg, gen, bt, o, acts, w, ad, slot, with_dec1, loss_out, st, own_sweep, fused);
@@ -3476,7 +3523,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz_dh2, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, pp->dh2, acts->h2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv, w.da2));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-    g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad);
+    g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, (pp->flags & LTG_PIPE_WIDE_GRAD) == 0);
     g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true);
     if (!defer_slice) {   // the slice of THIS step at its end, in program order (the cut-point schedule)
         const int ord = gen->q0_ord + 1, start = ord % qP;

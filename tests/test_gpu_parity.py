@@ -831,7 +831,9 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
     # schedule)
     # "-no-uitem": the batch without its list of distinct items (ltg_batch.uitem, ABI v11): the kernels that walk the distinct items then
     # find an item through uptr -> csr_pos -> indices, as before
-    pipe_flags = {"one-call": 0, "one-call-side-slice": cabi_flags("LTG_PIPE_SLICE_ON_SIDE"), "one-call-no-uitem": 0}
+    # "-wide-grad": the sparse gradient in its column-blocked shape (the default of the one-call step is one wave per row over all columns)
+    pipe_flags = {"one-call": 0, "one-call-side-slice": cabi_flags("LTG_PIPE_SLICE_ON_SIDE"), "one-call-no-uitem": 0,
+                  "one-call-wide-grad": cabi_flags("LTG_PIPE_WIDE_GRAD")}
     for variant in ("dense", "lazy", "lazy-no-uitem") + (tuple(pipe_flags) if precision == "bf16" else ()):
         lazy = variant != "dense"
         eng = _engine(I, precision, lr=1e-3, lazy_q0=lazy, q0_period=period)
