@@ -548,6 +548,7 @@ def main():
         comm = getattr(tr, "comm", None)
         res["sharded_step"] = {
             "one_call": bool(one_call),                          # ltg_g_step_sharded: every launch and the three exchanges from one C call
+            "handover": getattr(getattr(tr, "pipe", None), "handover", None),   # fork / join of the weight update: "device-words" | "events"
             "transport": getattr(comm, "kind", "torch.distributed (%s), step cut at its exchange points" % backend),
             "rccl_ranks": getattr(comm, "count", None) if getattr(comm, "kind", "") == "rccl-direct" else None,   # ncclCommCount
             "ranks": ranks_info,

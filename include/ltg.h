@@ -393,7 +393,14 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  * both sets goes to whichever workgroup's atomic max on its clock comes first).  LTG_PIPE_SLICE_ON_SIDE: the slice on the side stream in
  * front of the weight update instead (every row of batch t is already at ord, so the slice skips them whatever the rest of step t does
  * to them), joined (ev_slice) at the start of call t + 1, before that batch's catch-up.
- * The joins are stream waits on events recorded by the PREVIOUS call (a never-recorded event does not block).  Before anything
+ * Hand-over between the two streams: a cross-stream event pair costs ~12 us per direction on this hardware and ~6 us of bubble on the
+ * recording stream (scripts/micro/sync_cost.hip), so fork and join go through two words of device memory (ltg_pipe.sync) instead: the
+ * slab sum behind the dh2 product stores the call's ordinal into word 0 when it starts (stream order: the dh2 product is complete), a
+ * one-wave kernel in front of the weight update on the side stream polls for it; a one-wave kernel behind the update stores the ordinal
+ * into word 1, and dec-0 of the next call polls for it before it touches h2.  No packet waits on the caller's stream at all.  Every poll
+ * is bounded (~1 s; a poll that gives up adds 1 to word 2, which the caller checks when it joins the pipe).  LTG_PIPE_EVENTS (or sync == NULL) selects event pairs: stream waits on events recorded by the PREVIOUS call (a
+ * never-recorded event does not block).  A pipe is used in ONE mode between two joins, seq increases by 1 per call; the two streams of
+ * the device-word mode must be concurrent (ltg_g_pipe_probe).  Before anything
  * else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs ltg_g_pipe_join on the
  * stream that will read them.  Results equal ltg_g_step's / the cut-point sequence's bit for bit (same kernels, same order of
  * additions; the slice only runs later). */
@@ -416,12 +423,15 @@ typedef struct ltg_pipe {
     float* rowpart_all; /* [n_ranks][n_rows][5]  exchange 2: all-gather IN PLACE (this rank writes block `rank`, n_rows = the call's batch) */
     float* dh2;         /* [n_rows][H]  exchange 3: local dh2, all-reduced in place */
     int32_t flags;      /* LTG_PIPE_* measurement switches, 0 = the shipped schedule */
-    int32_t reserved0;
+    uint32_t seq;       /* ordinal of this call on this pipe: the caller adds 1 before every ltg_g_step_sharded call (starting at 1) */
+    uint32_t* sync;     /* [16] device words, zeroed once by the caller: the two gates of the device-side hand-over (ABI v11).  NULL: the
+                         * hand-overs are events (ev_fork / ev_dec1), as with LTG_PIPE_EVENTS */
 } ltg_pipe;
 #define LTG_PIPE_NO_DEC1_FORK 1  /* everything on the caller's stream, in program order */
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
 #define LTG_PIPE_SLICE_ON_SIDE 4 /* the slice step t - 1 owes on the side stream in front of the weight update (joined by ev_slice) instead of
                                     in the catch-up launch of call t */
+#define LTG_PIPE_EVENTS 16       /* fork and join of the weight update as hipEventRecord / hipStreamWaitEvent pairs instead of device words */
 #define LTG_PIPE_WIDE_GRAD 8     /* the sparse W_q0 gradient in its column-blocked shape (three times the waves) although it runs beside the update */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
@@ -429,6 +439,10 @@ int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32
 int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,
                        const ltg_pairs* fake, const ltg_g_opts* opts, const ltg_gen_acts* acts, const ltg_comm* comm,
                        const ltg_pipe* pipe, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream);
+/* 1: `stream` and pipe->side_stream run concurrently (a waiter on one does not hold up the other), as the device-word hand-over needs;
+ * 0: they share a hardware queue (HIP maps streams onto a few of them) -- use another side stream, or LTG_PIPE_EVENTS; < 0: error.
+ * Synchronises both streams; uses sync[3..4].  Call it once per (stream, side stream) pair before the first step. */
+int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream);
 /* `stream` waits for the forked pieces of the last ltg_g_step_sharded call (dec1_stream, q0_stream). */
 int ltg_g_pipe_join(const ltg_pipe* pipe, ltg_stream stream);
 /* (re)build gen->wp1t_bf16 from gen->p[3] (after initialisation or after loading weights). */

@@ -90,7 +90,7 @@ class ltg_sample_inputs(C.Structure):
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
 LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
-LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_SLICE_ON_SIDE, LTG_PIPE_WIDE_GRAD = 1, 2, 4, 8
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_SLICE_ON_SIDE, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS = 1, 2, 4, 8, 16
 
 
 class ltg_comm(C.Structure):
@@ -99,7 +99,7 @@ class ltg_comm(C.Structure):
 
 class ltg_pipe(C.Structure):
     _fields_ = [("side_stream", vp), ("ev_fork", vp), ("ev_dec1", vp), ("ev_slice", vp),
-                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("reserved0", C.c_int32)]
+                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("seq", C.c_uint32), ("sync", vp)]
 
 
 # every symbol include/ltg.h declares: name -> (restype, argtypes)
@@ -109,6 +109,7 @@ SYMBOLS = {
                                      C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), C.POINTER(ltg_comm),
                                      C.POINTER(ltg_pipe), vp, vp, C.c_size_t, vp]),
     "ltg_g_pipe_join": (C.c_int, [C.POINTER(ltg_pipe), vp]),
+    "ltg_g_pipe_probe": (C.c_int, [C.POINTER(ltg_pipe), vp]),
     "ltg_abi_version": (C.c_int32, []),
     "ltg_workspace_bytes": (C.c_size_t, [C.POINTER(ltg_config), C.c_int32, C.c_int32]),
     "ltg_vae_forward": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch),

@@ -99,8 +99,11 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
 // (MultiVAE.py:161) from mulv.
 __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* __restrict__ z, const float* __restrict__ mulv,
                                               const float* __restrict__ Wp0, const float* __restrict__ bp0, float* __restrict__ kl_rows,
-                                              float* __restrict__ h2) {
+                                              float* __restrict__ h2, LtgGate gate = LTG_NO_GATE) {
+    // gate (one-call step): h2 may only be overwritten once the previous step's weight update, which runs on the side stream and reads
+    // it, has finished
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    ltg_gate_wait(gate);
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
     float kl = 0.f;
     if (blockIdx.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns

@@ -1553,8 +1553,51 @@ __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kch
 }
 
 // da2 = (sum_z part) * (1 - h2^2)
+// ---- device-side hand-over between the two streams of the one-call step (include/ltg.h: ltg_pipe.sync).  A cross-stream event costs
+// ~12 us per direction on this pool (scripts/micro/sync_cost.hip: hipEventRecord + hipStreamWaitEvent between two 10-us kernels) and
+// ~6 us of bubble on the recording stream; a word in device memory costs the consumer one poll.  A gate is a 32-bit sequence number:
+// the producer stores the call's ordinal, the consumer waits until the word has reached it (wrap-safe compare).  Every wait is bounded
+// (seconds, counted in ltg_pipe.sync[2]): a call that failed half-way leaves a waiter behind, not a hung GPU.
+// The two streams must be CONCURRENT: HIP maps streams onto a few hardware queues, and a waiter in front of its producer in one queue
+// waits for ever -- ltg_g_pipe_probe tests a pair of streams for that.
+struct LtgGate {
+    unsigned* word;   // NULL: no gate
+    unsigned seq;
+    unsigned* expired;   // counts the waits that gave up (ltg_pipe.sync[2]: the host checks it when it joins the pipe)
+    int limit;           // polls before a wait gives up (0: ~4 M polls, seconds)
+};
+#define LTG_NO_GATE LtgGate{nullptr, 0u, nullptr, 0}
+__device__ __forceinline__ void ltg_gate_wait(LtgGate g) {   // first statement of a consumer kernel; every thread calls
+    if (!g.word) return;
+    if (threadIdx.x == 0) {
+        bool open = false;
+        const int limit = g.limit > 0 ? g.limit : (1 << 22);
+        for (int it = 0; it < limit && !open; ++it) {
+            open = (int)(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq) >= 0;
+            if (!open) __builtin_amdgcn_s_sleep(8);
+        }
+        if (!open && g.expired) atomicAdd(g.expired, 1u);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void ltg_gate_set(LtgGate g) {   // by ONE thread, after everything the consumer may rely on has completed
+    if (!g.word) return;                                     // (a kernel boundary in front of the caller: the producers here are whole kernels)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(g.word, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave in front of the side stream's work: returns when the gate opens (the kernels behind it start in stream order)
+__global__ __launch_bounds__(64) void k_gate_wait(LtgGate g) { ltg_gate_wait(g); }
+// one wave behind the side stream's work: opens the gate
+__global__ __launch_bounds__(64) void k_gate_set(LtgGate g) {
+    if (threadIdx.x == 0) ltg_gate_set(g);
+}
+
 __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __restrict__ part, const float* __restrict__ h2,
-                                            float* __restrict__ da2) {
+                                            float* __restrict__ da2, LtgGate started = LTG_NO_GATE) {
+    // started: opened by the first workgroup as soon as this kernel runs -- whatever preceded it on its stream (the dh2 product) is
+    // complete, which is what the forked weight update waits for
+    if (blockIdx.x == 0 && threadIdx.x == 0) ltg_gate_set(started);
     // one output per thread (B H = 60 000 outputs -> 235 workgroups instead of 59 with float4), 16 slabs in flight; the slabs
     // are added in ascending order whatever the unroll: bitwise the same sum as a serial walk
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
@@ -3416,9 +3459,29 @@ int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32
             q0_lazy(cfg, gen)) ? 1 : 0;
 }
 
+int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream) {
+    clear_errors();
+    if (!pipe || !pipe->sync || !pipe->side_stream) return LTG_EINVAL;
+    hipStream_t st = (hipStream_t)stream, sd = (hipStream_t)pipe->side_stream;
+    unsigned zero[2] = {0u, 0u}, got[2] = {0u, 0u};
+    if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
+    if (hipMemcpy(pipe->sync + 3, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return LTG_ELAUNCH;
+    // a waiter on the side stream FIRST, then its producer on `stream`: with one hardware queue under both, the producer cannot start
+    // before the waiter has given up (a few ms)
+    hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pipe->sync + 3, 1u, pipe->sync + 4, 1 << 12});
+    hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, st, LtgGate{pipe->sync + 3, 1u, nullptr, 0});
+    if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
+    if (hipMemcpy(got, pipe->sync + 3, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) return LTG_ELAUNCH;
+    if (check_launch() != LTG_OK) return LTG_ELAUNCH;
+    return (got[0] == 1u && got[1] == 0u) ? 1 : 0;
+}
+
 int ltg_g_pipe_join(const ltg_pipe* pipe, ltg_stream stream) {
     clear_errors();
-    if (!pipe || !pipe->ev_dec1 || !pipe->ev_slice) return LTG_EINVAL;
+    if (!pipe || !pipe->ev_dec1 || !pipe->ev_slice || !pipe->side_stream) return LTG_EINVAL;
+    if (pipe->sync && (pipe->flags & LTG_PIPE_EVENTS) == 0) {   // gates: nothing was recorded per call -- everything on the side stream so far
+        if (hipEventRecord((hipEvent_t)pipe->ev_dec1, (hipStream_t)pipe->side_stream) != hipSuccess) return LTG_ELAUNCH;
+    }
     if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_dec1, 0) != hipSuccess) return LTG_ELAUNCH;
     if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_slice, 0) != hipSuccess) return LTG_ELAUNCH;
     return LTG_OK;
@@ -3442,7 +3505,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     const bool fork_dec1 = (pp->flags & LTG_PIPE_NO_DEC1_FORK) == 0;
     // the lazy clock's slice of the previous step: in this call's catch-up launch (default), on the side stream, or at the end of its own step
     const bool defer_slice = fork_dec1 && (pp->flags & LTG_PIPE_NO_SLICE_FORK) == 0;
-    const bool fork_slice = defer_slice && (pp->flags & LTG_PIPE_SLICE_ON_SIDE) != 0, merge_slice = defer_slice && !fork_slice;
+    // fork / join of the weight update: device words (ltg_pipe.sync) or event pairs
+    const bool gates = fork_dec1 && pp->sync && (pp->flags & LTG_PIPE_EVENTS) == 0;
+    const bool fork_slice = defer_slice && !gates && (pp->flags & LTG_PIPE_SLICE_ON_SIDE) != 0, merge_slice = defer_slice && !fork_slice;
     Workspace w = carve(cfg, B, nf, (char*)ws);
     if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
     const Probe pr{o->probe, st};
@@ -3468,10 +3533,11 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
     LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,
                                                   o->fwd.is_training, cfg->seed, o->fwd.rng_step, acts->mulv, acts->z, gen->p[4], acts->h1));
-    // (dec-0 overwrites h2, which the previous step's weight update is still reading)
-    if (fork_dec1) LTG_HIP(hipStreamWaitEvent(st, ev_dec1, 0));
+    // (dec-0 overwrites h2, which the previous step's weight update is still reading: it waits for the word the update's stream sets
+    // behind it -- or, with events, the stream waits)
+    if (fork_dec1 && !gates) LTG_HIP(hipStreamWaitEvent(st, ev_dec1, 0));
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
-                                                  acts->h2));
+                                                  acts->h2, gates ? LtgGate{pp->sync + 1, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE));
     {
         int G = 0;
         LTG_PROBED(pr, LTG_K_DEC1_FWD, G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st));
@@ -3501,7 +3567,10 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         od.dec1_done = 0;
         const int dw_groups = (pp->flags >> 8) & 0x1FF;   // measurement: persistent workgroups of the weight update (0 = the library's choice)
         hipStream_t sdw = st;
-        if (fork_dec1) {
+        if (gates) {   // the side stream's work starts behind a one-wave kernel that polls the word the slab sum (below) sets when it starts
+            hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync, pp->seq, pp->sync + 2, 0});
+            sdw = sd;
+        } else if (fork_dec1) {
             LTG_HIP(hipEventRecord(ev_fork, st));
             LTG_HIP(hipStreamWaitEvent(sd, ev_fork, 0));
             sdw = sd;
@@ -3514,9 +3583,11 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         }
         const int rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups);
         if (rc != LTG_OK) return rc;
-        if (fork_dec1) LTG_HIP(hipEventRecord(ev_dec1, sd));
+        if (gates) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 1, pp->seq, nullptr, 0});
+        else if (fork_dec1) LTG_HIP(hipEventRecord(ev_dec1, sd));
         const int n = B * H;
-        hipLaunchKernelGGL(k_da2, dim3((n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048), dim3(NT), 0, st, n, nsplit, w.part, (const float*)nullptr, pp->dh2);
+        hipLaunchKernelGGL(k_da2, dim3((n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048), dim3(NT), 0, st, n, nsplit, w.part, (const float*)nullptr, pp->dh2,
+                           gates ? LtgGate{pp->sync, pp->seq, nullptr, 0} : LTG_NO_GATE);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_DH2, LTG_COMM(comm->all_reduce(pp->dh2, pp->dh2, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
     // ---- the replicated rest: dz (tanh derivative in its loader) -> dh1 -> sparse W_q0 gradient + its Adam step -> the other updates

@@ -128,11 +128,22 @@ class Pipe:
         self.h1pre = torch.zeros(rows, engine.H, **f)
         self.rowpart_all = torch.zeros(n_ranks * rows * 5, **f)
         self.dh2 = torch.zeros(rows, engine.H, **f)
+        self.sync = torch.zeros(16, dtype=torch.int32, device=dev)        # gates of the device-side fork / join + the count of expired waits
         self.c = cabi.ltg_pipe(self.side_stream.cuda_stream, self._ev[0].start, self._ev[0].stop, self._ev[1].start, _ptr(self.h1pre),
-                               _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0)
+                               _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0, _ptr(self.sync))
+        self.probed_for = None      # the caller's stream the side stream was last tested against (Engine._pipe_ready)
+        self.handover = None        # "device-words" | "events"
+
+    def new_side_stream(self):
+        self.side_stream = torch.cuda.Stream(self.sync.device)
+        self.c.side_stream = self.side_stream.cuda_stream
 
     def buffers(self):
         return [self.h1pre, self.rowpart_all, self.dh2]
+
+    def expired_waits(self):
+        """device-side waits of the fork / join that gave up (must be 0; synchronises)"""
+        return int(self.sync[2].item())
 
 
 class Engine:
@@ -446,6 +457,8 @@ class Engine:
         """every launch of the step and its exchanges from one call (comm: _rccl.RcclComm / HostComm; None = one rank)"""
         loss_out = self.loss_buf if loss_out is None else loss_out
         ws = self.workspace(batch.n_rows, fake.n)
+        self._pipe_ready(pipe)
+        pipe.c.seq = (pipe.c.seq + 1) & 0xFFFFFFFF                     # the call's ordinal on this pipe (what its gates count in)
         rc = self.lib.ltg_g_step_sharded(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
                                          C.byref(gopts), C.byref(acts.c), C.byref(comm.c) if comm is not None else None, C.byref(pipe.c),
                                          _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
@@ -454,6 +467,31 @@ class Engine:
             self.pipe_join(pipe)       # a standalone step: nothing stays in flight behind the call (a trainer joins once per phase)
         self._q0_stepped()
         return loss_out
+
+    def _pipe_ready(self, pipe):
+        """The device-word hand-over of ltg_g_step_sharded needs two CONCURRENT streams; HIP maps streams onto a few hardware queues, so
+        the pair is tested once (ltg_g_pipe_probe; a few other side streams are tried, then the pipe falls back to event pairs)."""
+        st = self.stream()
+        if pipe.probed_for == st:
+            return
+        if pipe.probed_for is not None:
+            self.pipe_join(pipe)                     # the mode may change: nothing in flight across the change
+            torch.cuda.synchronize(self.device)
+        if pipe.c.flags & (cabi.LTG_PIPE_EVENTS | cabi.LTG_PIPE_NO_DEC1_FORK):
+            pipe.handover = "events"
+        else:
+            pipe.handover = "events"
+            for _ in range(6):
+                ok = self.lib.ltg_g_pipe_probe(C.byref(pipe.c), st)
+                if ok < 0:
+                    cabi.check(ok, "ltg_g_pipe_probe")
+                if ok == 1:
+                    pipe.handover = "device-words"
+                    break
+                pipe.new_side_stream()
+            if pipe.handover == "events":
+                pipe.c.flags |= cabi.LTG_PIPE_EVENTS
+        pipe.probed_for = st
 
     def pipe_join(self, pipe):
         cabi.check(self.lib.ltg_g_pipe_join(C.byref(pipe.c), self.stream()), "ltg_g_pipe_join")

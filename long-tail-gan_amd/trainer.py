@@ -155,6 +155,9 @@ class Trainer:
             eng.q0_defer = False
             if ok:
                 eng.g_flush()
+                if self.pipe is not None and self.pipe.expired_waits():
+                    raise RuntimeError("a device-side wait of the G step's fork / join gave up (ltg_pipe.sync[2] = %d): the phase's results "
+                                       "are not trustworthy" % self.pipe.expired_waits())
         finally:
             eng.q0_defer = False
             eng.pin_stream(False)

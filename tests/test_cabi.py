@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8 + 8
     assert C.sizeof(cabi.ltg_probe) == 8 + 16
     assert C.sizeof(cabi.ltg_comm) == 8 + 8 + 2 * 8 and cabi.ltg_comm.all_reduce.offset == 16
-    assert C.sizeof(cabi.ltg_pipe) == 7 * 8 + 8 and cabi.ltg_pipe.h1pre.offset == 32 and cabi.ltg_pipe.flags.offset == 56
+    assert C.sizeof(cabi.ltg_pipe) == 7 * 8 + 8 + 8 and cabi.ltg_pipe.h1pre.offset == 32 and cabi.ltg_pipe.flags.offset == 56 and cabi.ltg_pipe.seq.offset == 60 and cabi.ltg_pipe.sync.offset == 64
 
 
 def test_argument_validation_returns_codes_without_gpu():

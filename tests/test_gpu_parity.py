@@ -827,12 +827,13 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
     outs = []
     # "one-call": the lazy clock inside ltg_g_step_sharded -- the slice of step t rides in the catch-up launch of step t + 1 (a row in
     # both sets goes to whichever workgroup claims it), the decoder weight update runs beside the next step's encoder half (bf16 decoder
-    # path only); "-side-slice": the slice on the side stream instead (round 3's first
-    # schedule)
+    # path only)
     # "-no-uitem": the batch without its list of distinct items (ltg_batch.uitem, ABI v11): the kernels that walk the distinct items then
     # find an item through uptr -> csr_pos -> indices, as before
     # "-wide-grad": the sparse gradient in its column-blocked shape (the default of the one-call step is one wave per row over all columns)
-    pipe_flags = {"one-call": 0, "one-call-side-slice": cabi_flags("LTG_PIPE_SLICE_ON_SIDE"), "one-call-no-uitem": 0,
+    # "-events": fork / join of the weight update as event pairs instead of device words; "-events-side-slice" = round 3's first schedule
+    pipe_flags = {"one-call": 0, "one-call-events": cabi_flags("LTG_PIPE_EVENTS"),
+                  "one-call-events-side-slice": cabi_flags("LTG_PIPE_EVENTS", "LTG_PIPE_SLICE_ON_SIDE"), "one-call-no-uitem": 0,
                   "one-call-wide-grad": cabi_flags("LTG_PIPE_WIDE_GRAD")}
     for variant in ("dense", "lazy", "lazy-no-uitem") + (tuple(pipe_flags) if precision == "bf16" else ()):
         lazy = variant != "dense"
@@ -873,6 +874,7 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
                 mids.append(fa.h1[:40].clone())
         if pipe is not None:
             eng.pipe_join(pipe)
+            assert pipe.expired_waits() == 0
         if lazy:
             torch.cuda.synchronize()
             assert eng.gen_c.q0_ord == 2 * n_batches
