@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     // gate (one-call step): h2 may only be overwritten once the previous step's weight update, which runs on the side stream and reads
     // it, has finished
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    ltg_gate_wait(gate);
+    ltg_gate_wait(gate, false);
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
     float kl = 0.f;
     if (blockIdx.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns
