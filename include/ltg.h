@@ -397,7 +397,11 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  * recording stream (scripts/micro/sync_cost.hip), so fork and join go through two words of device memory (ltg_pipe.sync) instead: the
  * slab sum behind the dh2 product stores the call's ordinal into word 0 when it starts (stream order: the dh2 product is complete), a
  * one-wave kernel in front of the weight update on the side stream polls for it; a one-wave kernel behind the update stores the ordinal
- * into word 1, and dec-0 of the next call polls for it before it touches h2.  No packet waits on the caller's stream at all.  Every poll
+ * into word 1, and dec-0 of the next call polls for it before it touches h2.  No packet waits on the caller's stream at all.  In this
+ * mode the clock slice runs on the side stream as well, between the catch-up of call t (enc-0 opens word 5 when it starts; a one-wave
+ * kernel in front of the sweep polls for it) and the catch-up of call t + 1 (which polls word 6, opened by the waiter in front of the
+ * weight update when it starts): beside enc-1 / dec-0 instead of on the critical stream (LTG_PIPE_SLICE_IN_TOUCH: in the catch-up launch,
+ * as with events).  Every poll
  * is bounded (~1 s; a poll that gives up adds 1 to word 2, which the caller checks when it joins the pipe).  LTG_PIPE_EVENTS (or sync == NULL) selects event pairs: stream waits on events recorded by the PREVIOUS call (a
  * never-recorded event does not block).  A pipe is used in ONE mode between two joins, seq increases by 1 per call; the two streams of
  * the device-word mode must be concurrent (ltg_g_pipe_probe).  Before anything
@@ -431,6 +435,8 @@ typedef struct ltg_pipe {
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
 #define LTG_PIPE_SLICE_ON_SIDE 4 /* the slice step t - 1 owes on the side stream in front of the weight update (joined by ev_slice) instead of
                                     in the catch-up launch of call t */
+#define LTG_PIPE_SLICE_IN_TOUCH 32 /* with device words: the slice step t - 1 owes in the catch-up launch of call t (as with events) instead of on the
+                                      side stream between the catch-up of call t and that of call t + 1 */
 #define LTG_PIPE_EVENTS 16       /* fork and join of the weight update as hipEventRecord / hipStreamWaitEvent pairs instead of device words */
 #define LTG_PIPE_WIDE_GRAD 8     /* the sparse W_q0 gradient in its column-blocked shape (three times the waves) although it runs beside the update */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */

@@ -90,7 +90,7 @@ class ltg_sample_inputs(C.Structure):
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
 LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
-LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_SLICE_ON_SIDE, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS = 1, 2, 4, 8, 16
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_SLICE_ON_SIDE, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH = 1, 2, 4, 8, 16, 32
 
 
 class ltg_comm(C.Structure):

@@ -209,7 +209,10 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
                                                       uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
                                                       const float* __restrict__ bq0, float* __restrict__ h1, float* __restrict__ row_scale,
                                                       const float* __restrict__ row_norm2, int item_lo, int Ig, int pre_only,
-                                                      float* __restrict__ xd, int rps) {
+                                                      float* __restrict__ xd, int rps, LtgGate started = LTG_NO_GATE) {
+    // started (one-call step, slice on the side stream): opened as soon as this kernel runs -- the catch-up of the batch's rows in front
+    // of it is complete
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_set(started);
     // xd (optional, small item slabs): the dense row  xd[b][i] = keep_bi * x_bi / (keep * ||x_b||)  of the operand this
     // layer multiplies -- the backward forms dW_q0 = xd^T . da1 as a dense MFMA product with the very same dropout draw
     extern __shared__ __attribute__((aligned(16))) float s_row[];   // [I] when xd, else nothing

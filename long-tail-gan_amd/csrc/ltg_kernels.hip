@@ -1589,7 +1589,11 @@ __device__ __forceinline__ void ltg_gate_set(LtgGate g) {   // by ONE thread, af
     __hip_atomic_store(g.word, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one wave in front of the side stream's work: returns when the gate opens (the kernels behind it start in stream order)
-__global__ __launch_bounds__(64) void k_gate_wait(LtgGate g) { ltg_gate_wait(g); }
+// (set_first: a gate this kernel opens when it starts -- whatever preceded it on its stream is complete)
+__global__ __launch_bounds__(64) void k_gate_wait(LtgGate g, LtgGate set_first = LTG_NO_GATE) {
+    if (threadIdx.x == 0) ltg_gate_set(set_first);
+    ltg_gate_wait(g);
+}
 // one wave behind the side stream's work: opens the gate
 __global__ __launch_bounds__(64) void k_gate_set(LtgGate g) {
     if (threadIdx.x == 0) ltg_gate_set(g);
@@ -1925,7 +1929,10 @@ __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* 
 // rows of the batch's distinct items (G-step batches carry the list): up to `target`, before enc-0 reads them
 __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
                                                            const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target,
-                                                           ltg_gen_state st, AdamC ad) {
+                                                           ltg_gen_state st, AdamC ad, LtgGate wait = LTG_NO_GATE) {
+    // wait (one-call step, slice on the side stream): the slice of the previous call is done with every row.  Ordering only: the slice
+    // ended -- a kernel boundary, its rows written back -- before the gate opened, and this kernel's own start invalidated what it had cached
+    ltg_gate_wait(wait, false);
     const int u = blockIdx.x;
     if (u >= nu) return;
     const int H4 = H >> 2;
@@ -2499,13 +2506,13 @@ inline bool q0_lazy(const ltg_config* cfg, const ltg_gen_state* gen) {
            cfg->n_items >= 8192;   // smaller slabs update W_q0 as a dense product: nothing to defer
 }
 // the item rows this batch reads, up to the caller's clock (no-ops for rows that are current)
-void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st) {
+void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st, LtgGate wait = LTG_NO_GATE) {
     if (!q0_lazy(cfg, gen) || bt->n_rows <= 0) return;
     const AdamC ad = make_adam(cfg, 1);   // b1, b2, eps; the learning rates come from the history ring
     if (bt->uptr && bt->csr_pos) {
         if (bt->n_unique > 0)
             hipLaunchKernelGGL(k_q0_touch_unique, dim3(bt->n_unique), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
-                               gen->q0_ord, *gen, ad);
+                               gen->q0_ord, *gen, ad, wait);
     } else {
         hipLaunchKernelGGL(k_q0_touch_rows, dim3(bt->n_rows), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_rows, bt->indptr, bt->indices, gen->q0_ord, *gen, ad);
     }
@@ -2513,7 +2520,8 @@ void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* 
 
 // stage 1: enc-0 over this rank's item slab.  pre_only: leave the partial pre-activation in acts->h1.
 void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
-                   const ltg_gen_acts* acts, int pre_only, hipStream_t st, float* xd = nullptr, bool touched = false) {
+                   const ltg_gen_acts* acts, int pre_only, hipStream_t st, float* xd = nullptr, bool touched = false,
+                   LtgGate started = LTG_NO_GATE) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc;
     const Probe pr{o->probe, st};
     if (!touched) q0_touch(cfg, gen, bt, st);
@@ -2521,7 +2529,7 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
         LTG_PROBED(pr, LTG_K_ENC0_FWD,
                    hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), xd ? (size_t)I * sizeof(float) : 0, st, H, I, bt->indptr,
                                       bt->indices, bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
-                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd, o->rows_per_step));
+                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd, o->rows_per_step, started));
         return;
     }
     LTG_PROBED(pr, LTG_K_ENC0_FWD,
@@ -3509,7 +3517,10 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     const bool defer_slice = fork_dec1 && (pp->flags & LTG_PIPE_NO_SLICE_FORK) == 0;
     // fork / join of the weight update: device words (ltg_pipe.sync) or event pairs
     const bool gates = fork_dec1 && pp->sync && (pp->flags & LTG_PIPE_EVENTS) == 0;
-    const bool fork_slice = defer_slice && !gates && (pp->flags & LTG_PIPE_SLICE_ON_SIDE) != 0, merge_slice = defer_slice && !fork_slice;
+    // with device words the slice runs on the side stream between this call's catch-up and the next one's (two more words), beside
+    // enc-1 / dec-0 instead of inside the catch-up launch on the critical stream
+    const bool side_slice = gates && defer_slice && (pp->flags & LTG_PIPE_SLICE_IN_TOUCH) == 0;
+    const bool fork_slice = defer_slice && !gates && (pp->flags & LTG_PIPE_SLICE_ON_SIDE) != 0, merge_slice = defer_slice && !fork_slice && !side_slice;
     Workspace w = carve(cfg, B, nf, (char*)ws);
     if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
     const Probe pr{o->probe, st};
@@ -3524,13 +3535,26 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         const int start = gen->q0_ord % qP, ns = (I - start + qP - 1) / qP;
         hipLaunchKernelGGL(k_q0_touch_slice, dim3(bt->n_unique + ns), dim3(Q0_NT), 0, st, I, H, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
                            gen->q0_ord, start, qP, *gen, make_adam(cfg, 1));
+    } else if (side_slice) {
+        // the slice step t - 1 owes (rows i = ord (mod period) up to ord) on the SIDE stream, between this call's catch-up and the next call's:
+        // word 5 is opened by enc-0 when it starts (the catch-up in front of it is complete: the rows of this batch are at ord, the slice
+        // skips them whatever happens to them later), a one-wave kernel in front of the sweep polls for it; word 6 is opened by the side
+        // stream's next kernel (the waiter in front of the weight update) when it starts, and the NEXT call's catch-up polls for it
+        // (issued in the order the device needs them: the critical stream's kernels first)
+        q0_touch(cfg, gen, bt, st, LtgGate{pp->sync + 6, pp->seq - 1u, pp->sync + 2, 0});
     } else
         q0_touch(cfg, gen, bt, st);
     // ---- forward: enc-0 over the local slab -> exchange 1 -> enc-1 (bias + tanh in its loader), dec-0, local logits + statistics
     {
         ltg_gen_acts a1 = *acts;
         a1.h1 = pp->h1pre;
-        fwd_stage_enc(cfg, gen, bt, &o->fwd, &a1, 1, st, nullptr, true);
+        fwd_stage_enc(cfg, gen, bt, &o->fwd, &a1, 1, st, nullptr, true, side_slice ? LtgGate{pp->sync + 5, pp->seq, nullptr, 0} : LTG_NO_GATE);
+    }
+    if (side_slice) {
+        const int start = gen->q0_ord % qP;
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
+        if (gen->q0_ord > 0 && start < I)
+            hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1));
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
     LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,
@@ -3569,8 +3593,13 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         od.dec1_done = 0;
         const int dw_groups = (pp->flags >> 8) & 0x1FF;   // measurement: persistent workgroups of the weight update (0 = the library's choice)
         hipStream_t sdw = st;
+        const int n_da2 = B * H;
+        if (gates)   // the slab sum first: it is the next kernel of the critical stream, the side stream's launches take the host ~30 us
+            hipLaunchKernelGGL(k_da2, dim3((n_da2 + NT - 1) / NT < 2048 ? (n_da2 + NT - 1) / NT : 2048), dim3(NT), 0, st, n_da2, nsplit, w.part, (const float*)nullptr,
+                               pp->dh2, LtgGate{pp->sync, pp->seq, nullptr, 0});
         if (gates) {   // the side stream's work starts behind a one-wave kernel that polls the word the slab sum (below) sets when it starts
-            hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync, pp->seq, pp->sync + 2, 0});
+            hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync, pp->seq, pp->sync + 2, 0},
+                               side_slice ? LtgGate{pp->sync + 6, pp->seq, nullptr, 0} : LTG_NO_GATE);
             sdw = sd;
         } else if (fork_dec1) {
             LTG_HIP(hipEventRecord(ev_fork, st));
@@ -3587,9 +3616,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         if (rc != LTG_OK) return rc;
         if (gates) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 1, pp->seq, nullptr, 0});
         else if (fork_dec1) LTG_HIP(hipEventRecord(ev_dec1, sd));
-        const int n = B * H;
-        hipLaunchKernelGGL(k_da2, dim3((n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048), dim3(NT), 0, st, n, nsplit, w.part, (const float*)nullptr, pp->dh2,
-                           gates ? LtgGate{pp->sync, pp->seq, nullptr, 0} : LTG_NO_GATE);
+        if (!gates)
+            hipLaunchKernelGGL(k_da2, dim3((n_da2 + NT - 1) / NT < 2048 ? (n_da2 + NT - 1) / NT : 2048), dim3(NT), 0, st, n_da2, nsplit, w.part, (const float*)nullptr,
+                               pp->dh2);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_DH2, LTG_COMM(comm->all_reduce(pp->dh2, pp->dh2, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
     // ---- the replicated rest: dz (tanh derivative in its loader) -> dh1 -> sparse W_q0 gradient + its Adam step -> the other updates

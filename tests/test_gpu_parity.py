@@ -825,14 +825,15 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
     Xf = Hh.random_history(rng, 40, I, mean_nnz=30)                       # forward-only batch (no distinct-item list)
     fakes = [_fake_pairs(rng, X, I) for X in Xs]
     outs = []
-    # "one-call": the lazy clock inside ltg_g_step_sharded -- the slice of step t rides in the catch-up launch of step t + 1 (a row in
-    # both sets goes to whichever workgroup claims it), the decoder weight update runs beside the next step's encoder half (bf16 decoder
-    # path only)
+    # "one-call": the lazy clock inside ltg_g_step_sharded -- the decoder weight update runs beside the next step's encoder half, the slice
+    # of step t on the side stream between the catch-ups of steps t + 1 and t + 2, everything handed over through device words (bf16
+    # decoder path only); "-slice-in-touch": the slice rides in the catch-up launch of step t + 1 (a row in both sets goes to whichever
+    # workgroup claims it)
     # "-no-uitem": the batch without its list of distinct items (ltg_batch.uitem, ABI v11): the kernels that walk the distinct items then
     # find an item through uptr -> csr_pos -> indices, as before
     # "-wide-grad": the sparse gradient in its column-blocked shape (the default of the one-call step is one wave per row over all columns)
     # "-events": fork / join of the weight update as event pairs instead of device words; "-events-side-slice" = round 3's first schedule
-    pipe_flags = {"one-call": 0, "one-call-events": cabi_flags("LTG_PIPE_EVENTS"),
+    pipe_flags = {"one-call": 0, "one-call-events": cabi_flags("LTG_PIPE_EVENTS"), "one-call-slice-in-touch": cabi_flags("LTG_PIPE_SLICE_IN_TOUCH"),
                   "one-call-events-side-slice": cabi_flags("LTG_PIPE_EVENTS", "LTG_PIPE_SLICE_ON_SIDE"), "one-call-no-uitem": 0,
                   "one-call-wide-grad": cabi_flags("LTG_PIPE_WIDE_GRAD")}
     for variant in ("dense", "lazy", "lazy-no-uitem") + (tuple(pipe_flags) if precision == "bf16" else ()):
@@ -874,7 +875,7 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
                 mids.append(fa.h1[:40].clone())
         if pipe is not None:
             eng.pipe_join(pipe)
-            assert pipe.expired_waits() == 0
+            assert pipe.expired_waits() == 0, variant
         if lazy:
             torch.cuda.synchronize()
             assert eng.gen_c.q0_ord == 2 * n_batches
@@ -887,10 +888,11 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
         if lazy:
             assert eng.gen_c.q0_ord == 0 and int(eng.q0_last.max()) == 0    # every row current: the ordinals restart
         outs.append([x.cpu() for x in losses + mids + eng.g_p + eng.g_m + eng.g_v])
-    for o in outs[1:]:
+    names = ["dense", "lazy", "lazy-no-uitem"] + (list(pipe_flags) if precision == "bf16" else [])
+    for name, o in zip(names[1:], outs[1:]):
         assert len(o) == len(outs[0])
         for k, (a, b) in enumerate(zip(outs[0], o)):
-            assert torch.equal(a, b), k
+            assert torch.equal(a, b), (name, k)
 
 
 def test_sampler_ties_and_long_candidate_lists():
