@@ -180,6 +180,7 @@ def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BAT
             print("global-epoch:%s, discr-epoch:%s, d_loss:%.5f" % (i, j, dl[j, 0]))
         print("")
         gl = tr.g_phase().cpu().numpy()
+        tr.check_pipe(sync=False)       # (the copy above has synchronised: the phase's expired-wait count is on the host)
         for j in range(NUM_SUB_EPOCHS):
             print("global-epoch:%s, generator-epoch:%s, g_loss:%.5f (vae_loss: %.5f + gan_loss: %.5f, anneal: %.5f)" %
                   (i, j, gl[j, 0], gl[j, 1], gl[j, 2], tr.last_anneal[j]))
