@@ -21,7 +21,9 @@ from .engine import Engine, Pipe
 
 
 CREATE_LOGITS_BYTES = 1 << 30      # logits of one phase-C span (rows x I x 4)
-PIPE_MAX_ITEMS = 65536             # item slabs below this run the G step through ltg_g_step_sharded (one call, pipelined)
+PIPE_MAX_ITEMS = 1 << 30           # item slabs below this run the G step through ltg_g_step_sharded (one call, pipelined).  Was 65 536 while
+                                   # the step's fork / join were event pairs (at 200 000 items the gain was within the noise); with the
+                                   # device-word hand-over: phase G 279-281 -> 264 ms per epoch at 200 000 items, so every slab the call serves
 TOWER_PAIRS = 1 << 17              # fake pairs per launch of the batched fake tower (activations: pairs x (h1 + h2 + 2 h3) x 4 bytes)
 
 
@@ -60,8 +62,7 @@ class Trainer:
         self.order = np.arange(data.n_batches)
         # large item slabs: the whole G step as ONE call with the decoder weight update and the lazy clock's slice running beside
         # the next step (ltg_g_step_sharded; here without a communicator).  LTGAN_PIPE_STEP: 0 = off, 1 = whenever the library
-        # supports the configuration, default = slabs below PIPE_MAX_ITEMS (above, a step is two HBM sweeps and the chain already
-        # hides beside them inside ltg_g_step)
+        # supports the configuration, default = slabs below PIPE_MAX_ITEMS (= all of them since the device-word hand-over)
         self.pipe, self.comm = None, None
         mode = os.environ.get("LTGAN_PIPE_STEP", "auto") if pipe_step is None else ("1" if pipe_step else "0")
         if mode != "0" and engine.sharded_step_ok(data.max_rows) and (mode == "1" or engine.I < PIPE_MAX_ITEMS):

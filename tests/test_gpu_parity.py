@@ -116,7 +116,7 @@ def _fake_pairs(rng, X, I, per_user=5):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("I,B,path", [(1000, 100, "step"), (333, 17, "step"), (6000, 100, "step"), (6000, 100, "step-config-d"), (8200, 100, "step"),
                                       (8200, 150, "step"), (8200, 100, "one-call"), (20000, 100, "step"), (25024, 100, "step"),
-                                      (25024, 100, "one-call-config-d"), (200000, 100, "step")])
+                                      (25024, 100, "one-call-config-d"), (200000, 100, "step"), (200000, 100, "one-call")])
 def test_g_step_parity(precision, I, B, path):
     """path "step": ltg_g_step.  "one-call": ltg_g_step_sharded without a communicator (the G step of every large item slab:
     bias + tanh and the tanh derivative folded into operand loaders, weight update and clock slice forked) -- same oracle, same

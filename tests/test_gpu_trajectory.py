@@ -124,3 +124,23 @@ def test_pipelined_g_phase_equals_the_step_by_step_loop():
         assert torch.equal(x, y)
     for k, (x, y) in enumerate(zip(a[3], b[3])):
         assert torch.equal(x, y), k
+
+
+def test_an_expired_device_side_wait_is_reported_by_the_trainer():
+    """The hand-overs of the one-call G step poll words of device memory with a bound; a poll that gives up is counted in
+    ltg_pipe.sync[2] and must surface as an error at the end of the phase (Trainer.check_pipe), not as silently wrong weights."""
+    import torch
+    from ltgan.dataset import DeviceData
+    from ltgan.engine import Engine
+    from ltgan.synthetic import synthetic_index
+    from ltgan.trainer import Trainer
+    idx, _ = synthetic_index("custom:9000", users=230, seed=22)
+    eng = Engine(idx.n_items, h_sizes=(20, 24, 40, 36), lr=1e-3, precision="bf16", seed=5, d_seed=9)
+    data = DeviceData(idx, 100, eng.device)
+    tr = Trainer(eng, data, num_sub_epochs=2, shuffle_seed=4, pipe_step=True)
+    assert tr.pipe is not None
+    tr.epoch()                                   # a clean epoch passes the check
+    assert tr.pipe.handover in ("device-words", "events")
+    tr.pipe.sync[2] = 3                          # as if three polls had given up
+    with pytest.raises(RuntimeError, match="gave up"):
+        tr.epoch()
