@@ -402,7 +402,7 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  * kernel in front of the sweep polls for it) and the catch-up of call t + 1 (which polls word 6, opened by the waiter in front of the
  * weight update when it starts): beside enc-1 / dec-0 instead of on the critical stream (LTG_PIPE_SLICE_IN_TOUCH: in the catch-up launch,
  * as with events).  Every poll
- * is bounded (~1 s; a poll that gives up adds 1 to word 2, which the caller checks when it joins the pipe).  LTG_PIPE_EVENTS (or sync == NULL) selects event pairs: stream waits on events recorded by the PREVIOUS call (a
+ * is bounded (30 s; a poll that gives up adds 1 to word 2, which the caller checks when it joins the pipe).  LTG_PIPE_EVENTS (or sync == NULL) selects event pairs: stream waits on events recorded by the PREVIOUS call (a
  * never-recorded event does not block).  A pipe is used in ONE mode between two joins, seq increases by 1 per call; the two streams of
  * the device-word mode must be concurrent (ltg_g_pipe_probe).  Before anything
  * else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs ltg_g_pipe_join on the

@@ -60,6 +60,21 @@ class RcclComm:
         self.count = int(n.value)                       # world size as RCCL reports it
         self.c = cabi.ltg_comm(self.comm, self.n_ranks, self.rank, C.cast(self.lib.ncclAllReduce, C.c_void_p), C.cast(self.lib.ncclAllGather, C.c_void_p))
         self.kind = "rccl-direct"
+        self._warm_up()
+
+    def _warm_up(self):
+        """One all-reduce and one all-gather of the step's message sizes, then a stream sync: RCCL sets its channels up at the first
+        collective (that can take seconds on a node), and the first training step has kernels polling device words with a bound."""
+        vp, sz = C.c_void_p, C.c_size_t
+        self.lib.ncclAllReduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp]
+        self.lib.ncclAllGather.argtypes = [vp, vp, sz, C.c_int, vp, vp]
+        st = torch.cuda.current_stream().cuda_stream
+        a = torch.zeros(128 * 600, dtype=torch.float32, device="cuda")
+        g = torch.zeros(self.n_ranks * 640, dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            self._check(self.lib.ncclAllReduce(a.data_ptr(), a.data_ptr(), a.numel(), cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, self.comm, st), "ncclAllReduce")
+            self._check(self.lib.ncclAllGather(g.data_ptr() + 4 * 640 * self.rank, g.data_ptr(), 640, cabi.LTG_NCCL_FLOAT32, self.comm, st), "ncclAllGather")
+        torch.cuda.current_stream().synchronize()
 
     def _check(self, rc, what):
         if rc != 0:

@@ -1557,14 +1557,14 @@ __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kch
 // ~12 us per direction on this pool (scripts/micro/sync_cost.hip: hipEventRecord + hipStreamWaitEvent between two 10-us kernels) and
 // ~6 us of bubble on the recording stream; a word in device memory costs the consumer one poll.  A gate is a 32-bit sequence number:
 // the producer stores the call's ordinal, the consumer waits until the word has reached it (wrap-safe compare).  Every wait is bounded
-// (seconds, counted in ltg_pipe.sync[2]): a call that failed half-way leaves a waiter behind, not a hung GPU.
+// (30 s, counted in ltg_pipe.sync[2]): a call that failed half-way leaves a waiter behind, not a hung GPU.
 // The two streams must be CONCURRENT: HIP maps streams onto a few hardware queues, and a waiter in front of its producer in one queue
 // waits for ever -- ltg_g_pipe_probe tests a pair of streams for that.
 struct LtgGate {
     unsigned* word;   // NULL: no gate
     unsigned seq;
     unsigned* expired;   // counts the waits that gave up (ltg_pipe.sync[2]: the host checks it when it joins the pipe)
-    int limit;           // polls before a wait gives up (0: ~4 M polls, seconds)
+    int limit;           // milliseconds before a wait gives up (0: 30 s)
 };
 #define LTG_NO_GATE LtgGate{nullptr, 0u, nullptr, 0}
 // acquire = false: the consumer only needs to run AFTER the producer (a write-after-read hazard), it reads nothing the producer wrote --
@@ -1573,10 +1573,12 @@ __device__ __forceinline__ void ltg_gate_wait(LtgGate g, bool acquire = true) { 
     if (!g.word) return;
     if (threadIdx.x == 0) {
         bool open = false;
-        const int limit = g.limit > 0 ? g.limit : (1 << 22);
-        for (int it = 0; it < limit && !open; ++it) {
+        const unsigned long long ticks = (unsigned long long)(g.limit > 0 ? g.limit : 30000) * 100000ull;   // wall_clock64: 100 MHz
+        const unsigned long long t0 = wall_clock64();
+        while (!open) {
             open = (int)(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq) >= 0;
-            if (!open) __builtin_amdgcn_s_sleep(8);
+            if (open || wall_clock64() - t0 > ticks) break;
+            __builtin_amdgcn_s_sleep(8);
         }
         if (!open && g.expired) atomicAdd(g.expired, 1u);
     }
@@ -3477,8 +3479,8 @@ int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream) {
     if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
     if (hipMemcpy(pipe->sync + 3, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return LTG_ELAUNCH;
     // a waiter on the side stream FIRST, then its producer on `stream`: with one hardware queue under both, the producer cannot start
-    // before the waiter has given up (a few ms)
-    hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pipe->sync + 3, 1u, pipe->sync + 4, 1 << 12});
+    // before the waiter has given up (5 ms)
+    hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pipe->sync + 3, 1u, pipe->sync + 4, 5});
     hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, st, LtgGate{pipe->sync + 3, 1u, nullptr, 0});
     if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
     if (hipMemcpy(got, pipe->sync + 3, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) return LTG_ELAUNCH;
