@@ -477,7 +477,9 @@ class Engine:
         if pipe.probed_for is not None:
             self.pipe_join(pipe)                     # the mode may change: nothing in flight across the change
             torch.cuda.synchronize(self.device)
-        if pipe.c.flags & (cabi.LTG_PIPE_EVENTS | cabi.LTG_PIPE_NO_DEC1_FORK):
+        if pipe.c.flags & cabi.LTG_PIPE_NO_DEC1_FORK:
+            pipe.handover = "none (everything in program order)"
+        elif pipe.c.flags & cabi.LTG_PIPE_EVENTS:
             pipe.handover = "events"
         else:
             pipe.handover = "events"

@@ -116,7 +116,7 @@ def test_pipelined_g_phase_equals_the_step_by_step_loop():
         torch.cuda.synchronize()
         tr.check_pipe()                                                    # no device-side wait of the hand-overs gave up
         if pipe:
-            assert tr.pipe.handover in ("device-words", "events") and tr.pipe.expired_waits() == 0
+            assert tr.pipe.handover in ("device-words", "events") and tr.pipe.expired_waits() == 0, tr.pipe.handover
         runs.append((data.fake_gen.clone(), data.fake_pop.clone(), losses, [t.clone() for t in eng.g_p + eng.g_m + eng.g_v + eng.d_p]))
     a, b = runs
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
