@@ -302,6 +302,22 @@ __device__ __forceinline__ void st_fetch_w(const unsigned short* __restrict__ Wb
     r.d = row[c0 + 48];
     r.e = row[min(c0 + 64, ST_C16 - 1)];
 }
+// one HALF of the shadow rows (the dh2 product split over column halves): 38 chunks of 16 B per item row, stored compactly (LDS columns
+// 0 .. 303); lanes 6 .. 15 of a row's 16 threads have no third chunk (clamped duplicate load, no store)
+__device__ __forceinline__ void st_fetch_w_half(const unsigned short* __restrict__ Wb, int I, int i0, int half, StW& r) {
+    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    const ltg_u32x4* row = reinterpret_cast<const ltg_u32x4*>(Wb + (size_t)min(i0 + it, I - 1) * ST_KP) + half * (ST_C16 / 2);
+    r.a = row[c0];
+    r.b = row[c0 + 16];
+    r.c = row[min(c0 + 32, ST_C16 / 2 - 1)];
+}
+__device__ __forceinline__ void st_stash_w_half(unsigned short* __restrict__ Wl, const StW& r) {
+    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
+    ltg_u32x4* row = reinterpret_cast<ltg_u32x4*>(Wl + it * ST_LDW);
+    row[c0] = r.a;
+    row[c0 + 16] = r.b;
+    if (c0 + 32 < ST_C16 / 2) row[c0 + 32] = r.c;
+}
 __device__ __forceinline__ void st_stash_w(unsigned short* __restrict__ Wl, const StW& r) {
     const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
     ltg_u32x4* row = reinterpret_cast<ltg_u32x4*>(Wl + it * ST_LDW);
@@ -429,12 +445,24 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
 }
 
 // part[blockIdx.x][b][h]: this workgroup's share of dh2 (k_da2 sums the slabs)
-template <bool D16>
+// NH = 2: blockIdx.y = which HALF of the 608 columns this workgroup produces, over a chunk of twice the items -- the same number of
+// workgroups and the same W bytes per workgroup, but half the partial slabs (at 25 024 items 98 x 240 KB instead of 196: the slab sum
+// that follows on the critical stream reads 23.5 MB instead of 47) and half the accumulator registers (76 instead of 152)
+template <bool D16, int NH = 1>
 __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int chunk, const float* __restrict__ dlog,
                                                       const unsigned short* __restrict__ Wb, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    constexpr int NTL = ST_KP / 16;  // 38 column tiles of the accumulator
+    constexpr int NTL = ST_KP / 16 / NH;  // 38 (19) column tiles of the accumulator
+    const int half = NH == 2 ? (int)blockIdx.y : 0;
+    auto fetch_w = [&](int i0_, StW& r_) {
+        if constexpr (NH == 2) st_fetch_w_half(Wb, I, i0_, half, r_);
+        else st_fetch_w(Wb, I, i0_, r_);
+    };
+    auto stash_w = [&](unsigned short* Wl_, const StW& r_) {
+        if constexpr (NH == 2) st_stash_w_half(Wl_, r_);
+        else st_stash_w(Wl_, r_);
+    };
     ltg_f32x4 acc[NTL];
 #pragma unroll
     for (int n = 0; n < NTL; ++n) acc[n] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -458,10 +486,10 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     }
     StW r0, r1;
     float4 e0, e1, o0, o1;     // A fragments of the even / odd steps
-    st_fetch_w(Wb, I, ibeg, r0);
-    st_stash_w(st_lds, r0);
+    fetch_w(ibeg, r0);
+    stash_w(st_lds, r0);
     DH_LOAD_A(ibeg, e0, e1)
-    st_fetch_w(Wb, I, min(ibeg + ST_BN, ilast), r1);
+    fetch_w(min(ibeg + ST_BN, ilast), r1);
     DH_LOAD_A(ibeg + ST_BN, o0, o1)
     __syncthreads();
     int cur = 0;
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     // fragment two steps ahead into X again -- two steps of HBM loads are always outstanding.
 #define DH_STEP(RL, RS, X0, X1)                                                                                                 \
     {                                                                                                                           \
-        st_fetch_w(Wb, I, min(i0 + 2 * ST_BN, ilast), RL);                                                                      \
+        fetch_w(min(i0 + 2 * ST_BN, ilast), RL);                                                                                \
         const unsigned keep = (row < B && i0 + 8 * lq < iend) ? 0xFFFFFFFFu : 0u;                                               \
         ltg_u32x4 au;                                                                                                           \
         if constexpr (D16) {                                                                                                    \
@@ -496,7 +524,7 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
             bu[4] = b1[0]; bu[5] = b1[1]; bu[6] = b1[2]; bu[7] = b1[3];                                                         \
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(ltg_bf16x8, bu), acc[n], 0, 0, 0);          \
         }                                                                                                                       \
-        st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                    \
+        stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                       \
         __syncthreads();                                                                                                        \
         cur ^= 1;                                                                                                               \
         i0 += ST_BN;                                                                                                            \
@@ -510,7 +538,7 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     float* out = part + (size_t)blockIdx.x * B * H;
 #pragma unroll
     for (int n = 0; n < NTL; ++n) {
-        const int h = n * 16 + lr;
+        const int h = half * (ST_KP / 2) + n * 16 + lr;
         if (h < H) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -2336,7 +2364,10 @@ inline bool stream_ok(const ltg_config* cfg, const ltg_gen_state* gen, int rows)
 }
 // k_dec1_bwd_adam_stream walks the 4 H/4 float4 a wave owns per tile as exactly ten 64-lane accesses
 inline bool dw_stream_ok(int H) { return (H % 4) == 0 && H > 576 && H <= 640; }
-inline int dh2_stream_chunk(int I) {
+constexpr int DH2_NH = 2;   // column halves of the streaming dh2 product (k_dh2_stream<.., NH>)
+inline int dh2_stream_chunk1(int I);
+inline int dh2_stream_chunk(int I) { return DH2_NH * dh2_stream_chunk1(I); }
+inline int dh2_stream_chunk1(int I) {
     // items per workgroup of k_dh2_stream = one partial [B][H] slab each: up to 256 workgroups, but at least 4 tiles per
     // workgroup -- at 20 000 items 157 slabs instead of 209 (each slab is 240 KB written and read once more by k_da2)
     int c = (I + 255) / 256;
@@ -3002,8 +3033,8 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
     pr.before(LTG_K_DH2);
-    if (stream && d16) hipLaunchKernelGGL(k_dh2_stream<true>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
-    else if (stream) hipLaunchKernelGGL(k_dh2_stream<false>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
+    if (stream && d16) hipLaunchKernelGGL((k_dh2_stream<true, DH2_NH>), dim3(nsplit, DH2_NH), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
+    else if (stream) hipLaunchKernelGGL((k_dh2_stream<false, DH2_NH>), dim3(nsplit, DH2_NH), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
     else if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf && (I % 4) == 0 && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dh2_partial<true, false, true>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf) hipLaunchKernelGGL((k_dh2_partial<true, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
@@ -3583,8 +3614,8 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
                        w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo);
     {
         const int kchunk = dh2_stream_chunk(I), nsplit = (I + kchunk - 1) / kchunk;
-        LTG_PROBED(pr, LTG_K_DH2, hipLaunchKernelGGL(k_dh2_stream<true>, dim3(nsplit), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog,
-                                                     gen->wp1t_bf16, w.part));
+        LTG_PROBED(pr, LTG_K_DH2, hipLaunchKernelGGL((k_dh2_stream<true, DH2_NH>), dim3(nsplit, DH2_NH), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk,
+                                                     w.dlog, gen->wp1t_bf16, w.part));
         // ---- ONE fork, behind the dh2 product (the last reader of this step's W_p1t shadow), onto the side stream:
         //   (1) the clock slice of the PREVIOUS step -- rows i = q0_ord (mod period) up to q0_ord; every row of this batch is at q0_ord
         //       already (q0_touch), so the slice skips them whatever the rest of this step does to them; joined at the start of the next
