@@ -245,7 +245,10 @@ class KernelProfiler:
         else:
             return None
         bf = self.a.precision == "bf16" and name in ("dec1_fwd", "dh2", "dec1_bwd_adam")
-        peak_f = PEAK["mfma_bf16"] if bf else PEAK["mfma_fp32"]
+        # the discriminator's e4m3 GEMMs use the NON-scaled v_mfma_f32_16x16x32_fp8_fp8, which issues at the bf16 rate (MI355X_MICROARCH.md:
+        # the ~5 PF figure is the block-scaled form); its bf16 mode likewise
+        d_low = getattr(self.a, "d_precision", "fp32") in ("fp8", "bf16") and name.startswith("d_") and name != "d_adam"
+        peak_f = PEAK["mfma_bf16"] if (bf or d_low) else PEAK["mfma_fp32"]
         t_f, t_b = fl / peak_f, by / PEAK["hbm"]
         if t_b >= t_f:
             ach, peak, unit, bound = by / (avg * 1e-3) / 1e9, PEAK["hbm"] / 1e9, "GB/s", "hbm"
