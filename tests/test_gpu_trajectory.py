@@ -144,3 +144,18 @@ def test_an_expired_device_side_wait_is_reported_by_the_trainer():
     tr.pipe.sync[2] = 3                          # as if three polls had given up
     with pytest.raises(RuntimeError, match="gave up"):
         tr.epoch()
+
+
+@pytest.mark.parametrize("queues,expect", [("1", "events"), ("2", "device-words")])
+def test_one_call_step_falls_back_to_events_when_its_streams_share_a_hardware_queue(queues, expect):
+    """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues.  With ONE, a waiter on the side stream sits in front of its producer in
+    the same queue: ltg_g_pipe_probe must see that and the engine must fall back to event pairs -- with the same bits as the
+    step-by-step loop either way (scripts/soak_onecall.py compares every tensor).  A fresh process: the variable is read at HIP start-up."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_onecall.py"), "9000", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "hand-over: " + expect in r.stdout and "expired waits: 0" in r.stdout and "differing: []" in r.stdout, r.stdout
