@@ -41,6 +41,45 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_pipe) == 7 * 8 + 8 + 8 and cabi.ltg_pipe.h1pre.offset == 32 and cabi.ltg_pipe.flags.offset == 56 and cabi.ltg_pipe.seq.offset == 60 and cabi.ltg_pipe.sync.offset == 64
 
 
+def test_struct_layouts_match_the_header_as_gcc_lays_it_out(tmp_path):
+    """The numbers above are the binding's; this compiles include/ltg.h with gcc and compares size and EVERY field offset of every struct
+    the binding mirrors (a C host that includes the header and the ctypes binding must agree on the bytes)."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from ltgan import _cabi as cabi
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    names = ["ltg_config", "ltg_gen_state", "ltg_disc_state", "ltg_batch", "ltg_gen_acts", "ltg_probe", "ltg_fwd_opts", "ltg_pairs", "ltg_d_opts",
+             "ltg_g_opts", "ltg_sample_inputs", "ltg_comm", "ltg_pipe"]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "ltg.h"', "int main(void) {"]
+    for n in names:
+        st = getattr(cabi, n)
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (n, n))
+        for f in st._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (n, f[0], n, f[0]))
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for ln in out:
+        if not ln.strip():
+            continue
+        n, f, v = ln.split()
+        st = getattr(cabi, n)
+        if f == "size":
+            assert C.sizeof(st) == int(v), (n, C.sizeof(st), int(v))
+        else:
+            assert getattr(st, f).offset == int(v), (n, f, getattr(st, f).offset, int(v))
+        seen += 1
+    assert seen == sum(1 + len(getattr(cabi, n)._fields_) for n in names)
+
+
 def test_argument_validation_returns_codes_without_gpu():
     from ltgan import _cabi as cabi
     lib = cabi.load()
