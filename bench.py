@@ -47,8 +47,11 @@ def parse():
     ap.add_argument("--d-split", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: split the discriminator's pair rows over the ranks + gradient all-reduce (auto: when the discriminator has >= 1 M parameters)")
     ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
-    ap.add_argument("--warm-moments", action="store_true", help="give every row of W_q0 non-zero Adam moments before timing (a long-trained "
-                    "model: the lazy clock then has its full deferred arithmetic to do; rows no batch has touched cost nothing otherwise)")
+    ap.add_argument("--warm-moments", action="store_true", help="(the default for the synthetic workloads) give every row of W_q0 non-zero Adam moments "
+                    "before timing: the state of the 136 000- / 1 000 000-user configurations, where every item has been seen -- the lazy clock "
+                    "then has its full deferred arithmetic to do")
+    ap.add_argument("--cold-moments", action="store_true", help="leave the moments of W_q0 at zero (a bounded sample touches a fraction of the items: "
+                    "rows no batch has touched then cost the lazy clock nothing -- NOT the state of the named configurations)")
     ap.add_argument("--no-probe", action="store_true", help="skip the HIP-event kernel probes (use under rocprofv3 --pmc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the bounded C3 / C4-shaped 1-GPU measurements reported beside the headline")
@@ -295,6 +298,18 @@ def step_algorithmic_bytes(idx, data, eng, S, active=None, lazy=False):
     return tot
 
 
+def step_fracs(idx, data, eng, S, active, dt, n_gpus):
+    """whole-step HBM fraction: the bytes the step really has to move / measured time / (8 TB/s x GPUs).  With the lazy Adam clock of
+    W_q0 (item slabs >= 8192) that is the clock's byte model -- the batch's rows and one row in `period` per G step -- so the fraction
+    cannot exceed 1; SURVEY 8/d4's dense-Adam count (every row of W_q0 every step: what tf.train.AdamOptimizer itself would move)
+    is reported beside it under its own key and CAN exceed 1 -- the clock moves fewer bytes than that model."""
+    dense = step_algorithmic_bytes(idx, data, eng, S, active)
+    moved = step_algorithmic_bytes(idx, data, eng, S, active, lazy=True)
+    pk = PEAK["hbm"] * n_gpus
+    return {"step_algorithmic_bytes": moved, "step_frac": moved / dt / pk,
+            "step_algorithmic_bytes_dense_adam": dense, "step_frac_vs_dense_adam_bytes": dense / dt / pk}
+
+
 def copy_ceiling(device, nbytes=1 << 30, reps=5):
     """Device-to-device copy rate of THIS box (read + write bytes / time), the practical HBM ceiling next to the 8 TB/s
     spec the roofline fraction is quoted against: boxes of the pool differ by ~10 % in it, and so do the HBM-bound kernels."""
@@ -336,6 +351,19 @@ def visible_gpus():
     return n
 
 
+def choose_backend(world, n_devices, env=None):
+    """(backend, note) of a rank: LTGAN_DIST_BACKEND if set (the self-launching parent sets gloo when it SAW fewer GPUs than ranks);
+    otherwise nccl (= RCCL) when every rank can have its own GPU and gloo -- a test rig whose ranks share devices and whose exchanges are
+    host callbacks, a different system from the one the metric is about -- when not.  The note goes into the result line."""
+    env = os.environ if env is None else env
+    forced = env.get("LTGAN_DIST_BACKEND")
+    if forced:
+        return forced, ("LTGAN_DIST_BACKEND=%s" % forced) + (" (test rig: %d ranks share %d GPU(s))" % (world, n_devices) if forced != "nccl" else "")
+    if world > n_devices:
+        return "gloo", "fallback: %d ranks on %d visible GPU(s) -- ranks share devices, exchanges through host callbacks" % (world, n_devices)
+    return "nccl", "one GPU per rank"
+
+
 def self_launch(a):
     """`python bench.py --gpus N` (N > 1) outside a launcher: start N FRESH rank processes with torch.distributed.run as a
     CHILD of this process (which never loads the HIP runtime: it imports neither torch nor the library), relay their output and
@@ -344,10 +372,12 @@ def self_launch(a):
     import subprocess
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     n_dev = visible_gpus()      # from sysfs / the visibility variables: this parent never loads the HIP runtime
-    if n_dev < a.gpus and "LTGAN_DIST_BACKEND" not in env:
+    if 0 < n_dev < a.gpus and "LTGAN_DIST_BACKEND" not in env:
         # fewer GPUs than ranks (single-GPU test box): RCCL cannot put two ranks on one device -> gloo, ranks share GPUs
         env["LTGAN_DIST_BACKEND"] = "gloo"
         print("bench.py: %d rank(s) on %d visible GPU(s): using the gloo backend (ranks share devices)" % (a.gpus, n_dev), file=sys.stderr, flush=True)
+    # (n_dev == 0: sysfs unreadable or restricted by the container -- nothing is forced here; every rank decides from
+    # torch.cuda.device_count() once it runs, see choose_backend)
     # --rdzv-endpoint 127.0.0.1:0 lets the launcher's own store pick a free port (no bind-then-close race in this process)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--rdzv-backend", "c10d",
            "--rdzv-endpoint", "127.0.0.1:0", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
@@ -393,7 +423,8 @@ def other_workloads(a, device, users=6400):
         idx, data, desc = load_workload(name, a.batch_size, device, users)
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
         eng.cfg.reserved0 = a.variant
-        if a.warm_moments:
+        warm = not a.cold_moments      # configs 3 / 4 are 136 000 / 1 000 000 users: every row of W_q0 carries moments there
+        if warm:
             warm_moments(eng)
         tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
         tr.epoch()
@@ -411,14 +442,13 @@ def other_workloads(a, device, users=6400):
         dt = (time.perf_counter() - t0) / 2
         tr.probe_hook = None
         r = prof.roofline(kname, None) if not a.no_probe else None
-        sb = step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active)
         nb = max(1, len(tr.active))
         out[key] = {"workload": name, "users": data.N, "items": data.I, "batches": data.n_batches, "value": data.N / dt, "unit": "users/s",
                     "ms_per_step": dt * 1e3, "g_step_us": float(np.median([p["t_g"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
                     "d_step_us": float(np.median([p["t_d"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
-                    "step_frac": sb / dt / PEAK["hbm"],
+                    "warm_moments": bool(warm),
                     "lazy_q0": bool(eng.lazy_q0),
-                    "step_frac_bytes_moved": step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active, lazy=True) / dt / PEAK["hbm"],
+                    **step_fracs(idx, data, eng, a.sub_epochs, tr.active, dt, 1),
                     "dominant_kernel": None if r is None else {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}}
         del tr, prof, eng, data, idx
         torch.cuda.empty_cache()
@@ -441,10 +471,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    local %= max(1, torch.cuda.device_count())      # more ranks than GPUs only with LTGAN_DIST_BACKEND=gloo (test rigs)
+    backend, backend_note = choose_backend(world, torch.cuda.device_count())      # "nccl" is RCCL on ROCm
+    local %= max(1, torch.cuda.device_count())      # more ranks than GPUs only on the gloo test rig
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
-    backend = os.environ.get("LTGAN_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -452,6 +482,9 @@ def main():
     from ltgan.trainer import Trainer
     workload = a.workload or ("askubuntu" if world == 1 else "c4")
     a.workload = workload
+    # every synthetic workload stands for a configuration whose users cover the whole item table (136 000 / 1 000 000 users): W_q0
+    # carries Adam moments in every row there, so that is what is timed unless --cold-moments asks for the bounded sample's own state
+    a.warm = (a.warm_moments or workload != "askubuntu") and not a.cold_moments
     mode = a.parallelism or ("item-shard" if world > 1 else "single")
     if mode == "item-shard" and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -465,6 +498,8 @@ def main():
         if world > 1 and rank == 0:
             # same workload on ONE GPU, measured in this very job (the other ranks wait): the strong-scaling reference
             e1 = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
+            if a.warm:
+                warm_moments(e1)
             t1 = Trainer(e1, data, num_sub_epochs=a.sub_epochs)
             t1.epoch()
             torch.cuda.synchronize()
@@ -478,13 +513,13 @@ def main():
         data = DeviceData(idx, a.batch_size, device, item_lo=lo, item_hi=hi)
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device, item_lo=lo, item_hi=hi)
         eng.cfg.reserved0 = a.variant
-        if a.warm_moments:
+        if a.warm:
             warm_moments(eng)
         tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs, d_split={"auto": None, "on": True, "off": False}[a.d_split])
     else:
         eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
         eng.cfg.reserved0 = a.variant
-        if a.warm_moments:
+        if a.warm:
             warm_moments(eng)
         tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
 
@@ -540,8 +575,9 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
         "dtype": a.precision, "data": desc,
         "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
-                   "sub_epochs": a.sub_epochs, "batch_size": a.batch_size,
+                   "sub_epochs": a.sub_epochs, "batch_size": a.batch_size, "warm_moments": bool(a.warm),
                    "backend": ("%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "test rig: ranks share GPUs")) if dist.is_initialized() else "none",
+                   "backend_choice": backend_note if dist.is_initialized() else None,
                    "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step %s)" %
                                    (world, "pair rows split + gradient all-reduce" if getattr(tr, "d_split", False) else "replicated"))
                    if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
@@ -558,6 +594,8 @@ def main():
             "distinct_gpus": len({r["gpu_uuid"] or r["pci_bus_id"] or r["local_rank"] for r in ranks_info}) if ranks_info else 1,
         }
     if dist.is_initialized():
+        if hasattr(tr, "close"):
+            tr.close()                  # the step's own RCCL communicator (ncclCommDestroy) before the group it was created over goes
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -572,13 +610,10 @@ def main():
         res["roofline"] = prof.roofline(dominant, calib) if dominant else None
         if res["roofline"] is None:
             res["roofline"] = {"kernel": None, "note": "kernel probes disabled (--no-probe)" if a.no_probe else "no probed launch fell into the timed region"}
-        # whole-step fraction: SURVEY 8/d4 algorithmic bytes of one step / measured step time / (8 TB/s x GPUs)
-        sb = step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active)
-        res["roofline"]["step_algorithmic_bytes"] = sb
-        res["roofline"]["step_frac"] = sb / (dt / a.steps) / (PEAK["hbm"] * (1 if replicas else world))
-        if eng.lazy_q0:   # the lazy Adam clock of W_q0 moves fewer bytes than SURVEY's dense-Adam count: the fraction on its own byte model
-            res["roofline"]["lazy_q0"] = {"period": eng.q0_period, "step_frac_bytes_moved": step_algorithmic_bytes(idx, data, eng, a.sub_epochs, tr.active, lazy=True) /
-                                          (dt / a.steps) / (PEAK["hbm"] * (1 if replicas else world))}
+        # whole-step fraction: algorithmic bytes of one step / measured step time / (8 TB/s x GPUs) (step_fracs: never above 1)
+        res["roofline"].update(step_fracs(idx, data, eng, a.sub_epochs, tr.active, dt / a.steps, 1 if replicas else world))
+        if eng.lazy_q0:
+            res["roofline"]["lazy_q0"] = {"period": eng.q0_period, "warm_moments": bool(a.warm)}
         res["roofline"]["copy_ceiling_this_box"] = copy_ceiling(device)
         if calib:
             res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}

@@ -170,8 +170,11 @@ def load():
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or make -C long-tail-gan_amd/csrc).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    ab = bool(os.environ.get("LTG_HIP_LIB"))   # A/B timing against an OLDER build of the same library (scripts/ab.sh): entry points
-    for name, (res, args) in SYMBOLS.items():  # it lacks stay unbound (Engine.sharded_step_ok is then False); struct layouts only ever grew
+    # LTG_HIP_LIB alone points at another build of THIS library: same strict checks.  LTG_AB_COMPAT=1 (scripts/ab_libs.sh, A/B timing
+    # against an OLDER build): entry points it lacks stay unbound (Engine.sharded_step_ok is then False) and ABI 9 / 10 are accepted --
+    # struct layouts only ever grew.
+    ab = bool(os.environ.get("LTG_HIP_LIB")) and os.environ.get("LTG_AB_COMPAT", "0") == "1"
+    for name, (res, args) in SYMBOLS.items():
         if ab and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)  # AttributeError if the export is missing

@@ -40,27 +40,50 @@ def _librccl():
 class RcclComm:
     """A communicator of this process group's ranks created directly on RCCL (one rank per GPU)."""
 
-    def __init__(self, group=None, device=None):
-        self.lib = _librccl()
+    def __init__(self, group=None, device=None, warm_counts=(128 * 600, 640)):
+        """warm_counts: floats of the step's all-reduce message and of one rank's all-gather block (ltg_pipe.h1pre, rowpart_all / R).
+        ncclCommInitRank is a COLLECTIVE: every step before it that can fail on one rank alone (loading librccl, the unique id, its
+        broadcast) is followed by an agreement over the existing group, so a rank that failed never leaves the others blocked inside it."""
         self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.comm = C.c_void_p()
+        self.group = group
+        err = None
+        try:
+            self.lib = _librccl()
+        except Exception as e:
+            err = "librccl: %r" % (e,)
+        self._agree(err, device)
         uid = _UniqueId()
-        if self.rank == 0:
-            self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]    # (the raw 128 bytes: a c_char array reads as a C string)
+        box = [None]
+        try:
+            if self.rank == 0:
+                self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+                box = [C.string_at(C.byref(uid), 128)]    # (the raw 128 bytes: a c_char array reads as a C string)
+        except Exception as e:
+            err = "ncclGetUniqueId: %r" % (e,)
+        self._agree(err, device)
         if self.n_ranks > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        assert len(box[0]) == 128
+        self._agree(None if (box[0] is not None and len(box[0]) == 128) else "unique id not received", device)
         C.memmove(C.byref(uid), box[0], 128)
         if device is not None:
             torch.cuda.set_device(device)
-        self.comm = C.c_void_p()
         self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.n_ranks, uid, self.rank), "ncclCommInitRank")
+        self._warm_counts = (int(warm_counts[0]), int(warm_counts[1]))
         n = C.c_int()
         self._check(self.lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
         self.count = int(n.value)                       # world size as RCCL reports it
         self.c = cabi.ltg_comm(self.comm, self.n_ranks, self.rank, C.cast(self.lib.ncclAllReduce, C.c_void_p), C.cast(self.lib.ncclAllGather, C.c_void_p))
         self.kind = "rccl-direct"
         self._warm_up()
+
+    def _agree(self, err, device):
+        """every rank reports whether it got this far; all raise together if one did not"""
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device if (device is not None and dist.get_backend(self.group) == "nccl") else "cpu")
+        if self.n_ranks > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            raise cabi.LtgError("RCCL communicator not created: %s" % (err or "another rank failed before ncclCommInitRank"))
 
     def _warm_up(self):
         """One all-reduce and one all-gather of the step's message sizes, then a stream sync: RCCL sets its channels up at the first
@@ -69,11 +92,12 @@ class RcclComm:
         self.lib.ncclAllReduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp]
         self.lib.ncclAllGather.argtypes = [vp, vp, sz, C.c_int, vp, vp]
         st = torch.cuda.current_stream().cuda_stream
-        a = torch.zeros(128 * 600, dtype=torch.float32, device="cuda")
-        g = torch.zeros(self.n_ranks * 640, dtype=torch.float32, device="cuda")
+        n_ar, n_ag = self._warm_counts
+        a = torch.zeros(n_ar, dtype=torch.float32, device="cuda")
+        g = torch.zeros(self.n_ranks * n_ag, dtype=torch.float32, device="cuda")
         for _ in range(2):
             self._check(self.lib.ncclAllReduce(a.data_ptr(), a.data_ptr(), a.numel(), cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, self.comm, st), "ncclAllReduce")
-            self._check(self.lib.ncclAllGather(g.data_ptr() + 4 * 640 * self.rank, g.data_ptr(), 640, cabi.LTG_NCCL_FLOAT32, self.comm, st), "ncclAllGather")
+            self._check(self.lib.ncclAllGather(g.data_ptr() + 4 * n_ag * self.rank, g.data_ptr(), n_ag, cabi.LTG_NCCL_FLOAT32, self.comm, st), "ncclAllGather")
         torch.cuda.current_stream().synchronize()
 
     def _check(self, rc, what):

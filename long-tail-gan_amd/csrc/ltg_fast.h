@@ -51,7 +51,10 @@ template <bool PRE>
 __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* __restrict__ h1, const float* __restrict__ Wq1,
                                               const float* __restrict__ bq1, const float* __restrict__ eps_in, float is_training,
                                               uint64_t seed, uint64_t step, float* __restrict__ mulv, float* __restrict__ z,
-                                              const float* __restrict__ bq0 = nullptr, float* __restrict__ h1_out = nullptr) {
+                                              const float* __restrict__ bq0 = nullptr, float* __restrict__ h1_out = nullptr,
+                                              LtgGate end_wait = LTG_NO_GATE) {
+    // end_wait (one-call step): the kernel behind this one, dec-0, overwrites h2, which the previous step's weight update reads in its
+    // prologue on the side stream -- ONE thread of this launch polls for the update's word as the last thing it does
     __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, Z2 = 2 * Z;
     auto col = [=] __device__(int c) { return min(n0 + (c & 15), Z - 1) + (c >> 4) * Z; };   // logical tile column -> column of mulv
@@ -93,17 +96,19 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
     };
     // the block sees logical columns [0, 32) of this tile (all "in range"; the real bounds are the functors' business)
     ltg_rgemm<1, 2, 1, 1, 4, 10>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
 }
 
 // dec-0 (MultiVAE.py:168-172): h2 = tanh(z . W_p0 + b_p0); the column-tile-0 workgroups also add up the per-row KL
 // (MultiVAE.py:161) from mulv.
 __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* __restrict__ z, const float* __restrict__ mulv,
                                               const float* __restrict__ Wp0, const float* __restrict__ bp0, float* __restrict__ kl_rows,
-                                              float* __restrict__ h2, LtgGate gate = LTG_NO_GATE) {
-    // gate (one-call step): h2 may only be overwritten once the previous step's weight update, which runs on the side stream and reads
-    // it, has finished
+                                              float* __restrict__ h2, LtgGate end_wait = LTG_NO_GATE, const unsigned* __restrict__ poison = nullptr) {
+    // one-call step: h2 may only be overwritten once the previous step's weight update (side stream) has read it -- the kernel in front
+    // of this one waited for that (fk_enc1's end_wait; poison: the wait gave up).  end_wait: the kernel BEHIND this one streams the bf16
+    // shadow of W_p1t, which that update rewrites until it ends: one thread of this launch polls for its end as the last thing it does.
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    ltg_gate_wait(gate, false);
+    if (ltg_poisoned(poison)) return;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
     float kl = 0.f;
     if (blockIdx.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
         for (int o = 8; o > 0; o >>= 1) kl += __shfl_xor(kl, o);    // the 16 lanes of a row are consecutive
         if ((threadIdx.x & 15) == 0 && m0 + (threadIdx.x >> 4) < B) kl_rows[m0 + (threadIdx.x >> 4)] = kl;
     }
+    if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);   // (block column 1: not one that adds up the KL)
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)          [B][2Z]
@@ -478,7 +484,8 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad_rows(int B, int I, int H, 
                                                            const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
                                                            const float* __restrict__ row_scale, const float* __restrict__ da1,
                                                            float* __restrict__ G, int item_lo, int Ig, ltg_gen_state st, AdamC ad, int lazy_ord,
-                                                           const int32_t* __restrict__ uitem) {
+                                                           const int32_t* __restrict__ uitem, const unsigned* __restrict__ poison = nullptr) {
+    if (ltg_poisoned(poison)) return;   // (one-call step: a device-side wait of the pipe gave up -- the model is not touched)
     constexpr int U = NCB == 1 ? 8 : (NCB == 2 ? 4 : 3);   // entries in flight per wave (x NCB float4 each)
     __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][NCB * 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -587,6 +594,9 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
                                               const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                               const float* __restrict__ b2, DropView dA, DropView dB, float keep, uint64_t seed,
                                               uint64_t step, float* __restrict__ A1) {
+#ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
+    if (pv.nr >= 0) return;
+#endif
     __shared__ __attribute__((aligned(16))) float lds[Rg32::LDS_FLOATS];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const bool br = blockIdx.z != 0;
@@ -620,6 +630,9 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
                                               const float* __restrict__ b3, const float* __restrict__ w4, DropView dC, float keep,
                                               uint64_t seed, uint64_t step, float* __restrict__ A3, float* __restrict__ G3,
                                               float* __restrict__ spart) {
+#ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
+    if (n >= 0) return;
+#endif
     __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
     const int tn = (h3 + 31) / 32;
     const int tid_ = xcd_chunk(blockIdx.x, gridDim.x);
@@ -681,11 +694,18 @@ __global__ __launch_bounds__(NT) void fk_d_y(PairView pv, int ntile, const float
 //   job B  slab[z] = A1^T . (ds G3) (+ ones row -> db3), split over row chunks [h12+1][h3]  32 x 32 tiles
 //   job C  slab[z]: dw4 = A3^T . ds, db4 = sum ds, and the chunk's share of d_loss (slot P of the slab)
 // Every job first rebuilds ds (and the loss terms) of the pair rows it touches from the tile partials of fk_d_l2.
+__device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int h3, int bid, int nB, int ntile, const DLayout& L, int SP,
+                                               const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
+                                               const float* __restrict__ spart, float b4v, float* __restrict__ slab, float* __restrict__ lds,
+                                               float* __restrict__ s_ds, float* __restrict__ s_lr);
 __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, int nA, int nB, int ntile, DLayout L, int SP,
                                                 const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
                                                 const float* __restrict__ spart, const float* __restrict__ b4p,
                                                 const float* __restrict__ w3, float keep, float* __restrict__ dpre1,
                                                 float* __restrict__ slab) {
+#ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
+    if (pv.nr >= 0) return;
+#endif
     __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
     __shared__ float s_ds[D_KCHUNK], s_lr[D_KCHUNK];
     const int n = pv.nr + pv.nf, tid = threadIdx.x;
@@ -729,7 +749,16 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
         ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
         return;
     }
-    bid -= nA;
+    d_bwd1_jobs_bc(pv, h12, h3, bid - nA, nB, ntile, L, SP, A1, A3, G3, spart, b4v, slab, lds, s_ds, s_lr);
+}
+
+// jobs B and C of backward stage 1 (see fk_d_bwd1) for block `bid` of nB + nC: they need the forward's outputs only, not dpre1 --
+// either kernel of the backward may carry them (d_step_impl: beside job A, or beside the embedding products of stage 2)
+__device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int h3, int bid, int nB, int ntile, const DLayout& L, int SP,
+                                               const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
+                                               const float* __restrict__ spart, float b4v, float* __restrict__ slab, float* __restrict__ lds,
+                                               float* __restrict__ s_ds, float* __restrict__ s_lr) {
+    const int n = pv.nr + pv.nf, tid = threadIdx.x;
     if (bid < nB) bid = xcd_chunk(bid, nB);            // a chunk of job B = the tiles of one or two row chunks z
     const int tmB = (h12 + 1 + 31) / 32, tnB = (h3 + 31) / 32;
     const int z = bid < nB ? bid / (tmB * tnB) : (bid - nB) / ((h3 + 2 + 31) / 32);
@@ -812,9 +841,24 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
 }
 
 // Backward stage 2: dw1 / db1 and dw2 / db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), 16 x 32 tiles.
+struct DBwdBC {   // jobs B and C of stage 1 riding in stage 2's launch (n2 = first of their blocks; nB = 0: not in this launch)
+    int n2, nB, h3, ntile;
+    const float *A1, *A3, *G3, *spart, *b4p;
+};
+template <bool WITH_BC>
 __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
-                                                const float* __restrict__ dpre1, float* __restrict__ slab) {
-    __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
+                                                const float* __restrict__ dpre1, float* __restrict__ slab, DBwdBC bc) {
+#ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
+    if (pv.nr >= 0) return;
+#endif
+    __shared__ __attribute__((aligned(16))) float lds[WITH_BC ? (Rg32k::LDS_FLOATS > Rg16x32::LDS_FLOATS ? Rg32k::LDS_FLOATS : Rg16x32::LDS_FLOATS) : Rg16x32::LDS_FLOATS];
+    if constexpr (WITH_BC) {
+        __shared__ float s_ds[D_KCHUNK], s_lr[D_KCHUNK];
+        if ((int)blockIdx.x >= bc.n2) {
+            d_bwd1_jobs_bc(pv, h1 + h2, bc.h3, (int)blockIdx.x - bc.n2, bc.nB, bc.ntile, L, SP, bc.A1, bc.A3, bc.G3, bc.spart, bc.b4p[0], slab, lds, s_ds, s_lr);
+            return;
+        }
+    }
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const int tm = (h0 + 1 + 15) / 16;
     const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
@@ -876,6 +920,9 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
 // slabs; 16 bytes per lane.  Block 0 also adds up d_loss (train.py:142) from slot P of the slabs.
 __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const float* __restrict__ slab, float* __restrict__ p,
                                                 float* __restrict__ m, float* __restrict__ v, AdamC ad, float* __restrict__ loss_out) {
+#ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
+    if (ks >= 0) return;
+#endif
     const int P4 = P >> 2;
     for (int e = blockIdx.x * NT + threadIdx.x; e < P4; e += gridDim.x * NT) {
         ltg_f32x4 g = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1176,11 +1223,21 @@ struct TailArgs {
     const int32_t* cnt;
     float anneal, lam;
     float *loss_out, *loss_out2;
+    // one-call step: `poison` != 0 -> nothing is updated; n_wait = 1: one more block at the end of the grid whose first thread polls for
+    // `end_wait` (the clock slice on the side stream is done with every row: the next call's catch-up is the kernel behind this one)
+    const unsigned* poison;
+    int n_wait;
+    LtgGate end_wait;
 };
 template <bool BF>
 __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, AdamC ad) {
     __shared__ __attribute__((aligned(16))) float lds[LtgRg<2, LTG_TAIL_BN / 16, 1, 1, 4>::LDS_FLOATS];
     int bid = blockIdx.x;
+    if (a.n_wait && bid == (int)gridDim.x - 1) {
+        if (threadIdx.x == 0) ltg_gate_wait_tail(a.end_wait);
+        return;
+    }
+    if (ltg_poisoned(a.poison)) return;
     const int B = a.B, I = a.I, H = a.H, Z = a.Z;
     // (The dz / dh1 tiles once rode in front of the jobs -- three launches of this kernel per step, measured +23 us; the variant
     // is gone: its 80 operand registers set the register count of the whole kernel and with it the tiles' occupancy.)

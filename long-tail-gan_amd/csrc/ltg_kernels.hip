@@ -71,6 +71,78 @@ __device__ __forceinline__ float block_max(float x, float* red) {
     return s;
 }
 
+// ---- device-side hand-over between the two streams of the one-call step (include/ltg.h: ltg_pipe.sync).  A cross-stream event costs
+// ~12 us per direction on this pool (scripts/micro/sync_cost.hip: hipEventRecord + hipStreamWaitEvent between two 10-us kernels) and
+// ~6 us of bubble on the recording stream; a word in device memory costs the consumer one poll.  A gate is a 32-bit sequence number:
+// the producer stores the call's ordinal, the consumer waits until the word has reached it (wrap-safe compare).  Every wait is bounded
+// (30 s, counted in ltg_pipe.sync[2]): a call that failed half-way leaves a waiter behind, not a hung GPU.
+// The two streams must be CONCURRENT: HIP maps streams onto a few hardware queues, and a waiter in front of its producer in one queue
+// waits for ever -- ltg_g_pipe_probe tests a pair of streams for that.
+struct LtgGate {
+    unsigned* word;   // NULL: no gate
+    unsigned seq;
+    unsigned* expired;   // counts the waits that gave up (ltg_pipe.sync[2]: the host checks it when it joins the pipe)
+    int limit;           // milliseconds before a wait gives up (0: 30 s)
+};
+#define LTG_NO_GATE LtgGate{nullptr, 0u, nullptr, 0}
+// acquire = false: the consumer only needs to run AFTER the producer (a write-after-read hazard), it reads nothing the producer wrote --
+// no cache invalidation (dec-0: 14.7 -> ~8 us; whoever reads the producer's data later does so behind a kernel boundary)
+__device__ __forceinline__ void ltg_gate_wait(LtgGate g, bool acquire = true) {   // first statement of a consumer kernel; every thread calls
+    if (!g.word) return;
+    if (threadIdx.x == 0) {
+        bool open = false;
+        const unsigned long long ticks = (unsigned long long)(g.limit > 0 ? g.limit : 30000) * 100000ull;   // wall_clock64: 100 MHz
+        const unsigned long long t0 = wall_clock64();
+        while (!open) {
+            open = (int)(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq) >= 0;
+            if (open || wall_clock64() - t0 > ticks) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!open && g.expired) atomicAdd(g.expired, 1u);
+    }
+    __syncthreads();
+    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// The same wait as the LAST thing ONE thread of a kernel does: the kernel behind it on the stream starts in stream order, i.e. after this
+// one has ended, so that kernel is gated whatever its size while a single wave of the whole device spins (no workgroup of a large
+// launch ever occupies a CU polling for a producer that still needs one: forward progress by construction).  A wait that gives up
+// POISONS the pipe (word 2 != 0): the kernels behind it skip their work (ltg_poisoned) and the host raises when it next looks.
+__device__ __forceinline__ void ltg_gate_wait_tail(LtgGate g) {
+    if (!g.word) return;
+    const unsigned long long ticks = (unsigned long long)(g.limit > 0 ? g.limit : 30000) * 100000ull;   // wall_clock64: 100 MHz
+    const unsigned long long t0 = wall_clock64();
+    bool open = false;
+    while (!open) {
+        open = (int)(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq) >= 0;
+        if (open || wall_clock64() - t0 > ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (!open && g.expired) atomicAdd(g.expired, 1u);
+}
+// word 2 of ltg_pipe.sync: a device-side wait of this pipe has given up -- nothing that follows may touch the model
+__device__ __forceinline__ bool ltg_poisoned(const unsigned* __restrict__ p) {
+    return p && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+__device__ __forceinline__ void ltg_gate_set(LtgGate g) {   // by ONE thread, after everything the consumer may rely on has completed
+    if (!g.word) return;                                     // (a kernel boundary in front of the caller: the producers here are whole kernels)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(g.word, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave in front of the side stream's work: returns when the gate opens (the kernels behind it start in stream order)
+// (set_first: a gate this kernel opens when it starts -- whatever preceded it on its stream is complete)
+__global__ __launch_bounds__(64) void k_gate_wait(LtgGate g, LtgGate set_first = LTG_NO_GATE) {
+    if (threadIdx.x == 0) ltg_gate_set(set_first);
+    ltg_gate_wait(g);
+}
+// one wave behind the side stream's work: opens the gate
+__global__ __launch_bounds__(64) void k_gate_set(LtgGate g, LtgGate g2 = LTG_NO_GATE) {
+    if (threadIdx.x == 0) {
+        ltg_gate_set(g);
+        ltg_gate_set(g2);
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Generator forward
 // ---------------------------------------------------------------------------------------------
@@ -555,12 +627,23 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
 // (row-major bf16 LDS image, consumed transposed by ds_read_b64_tr_b16), theta/m/v touched exactly once.
 constexpr int DW_LDD = 40;  // LDS row stride of the dlog tile in bf16 (80 B: 16-B aligned)
 constexpr int DW_LDC = 84;  // row stride of a wave's fp32 gradient block (80 columns + 4)
+// read_h2: the one-call step's hand-over of h2 (ltg_pipe.sync words 8 / 1).  h2 is read in the prologue only; a workgroup that has its
+// fragments counts itself in word 8, and the one that completes the grid stores the call's ordinal into word 1 -- from then on the next
+// step's dec-0 may overwrite h2 although this kernel still runs (a write-after-read hazard: the reads have returned, nothing is published).
+struct LtgH2Done {
+    unsigned* count;   // NULL: no hand-over
+    unsigned* word;
+    unsigned seq;
+    const unsigned* poison;
+};
 template <bool D16>
 __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, int H, const float* __restrict__ dlog,
-                                                                const float* __restrict__ h2, ltg_gen_state st, AdamC ad) {
+                                                                const float* __restrict__ h2, ltg_gen_state st, AdamC ad,
+                                                                LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr}) {
     __shared__ __attribute__((aligned(16))) unsigned short Dl[2][128 * DW_LDD];
     __shared__ __attribute__((aligned(16))) float Cs[8 * 32 * DW_LDC];   // per-wave [32][80] gradient blocks
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    if (ltg_poisoned(hd.poison)) return;
     float4 *W4 = reinterpret_cast<float4*>(st.p[3]), *M4 = reinterpret_cast<float4*>(st.m[3]), *V4 = reinterpret_cast<float4*>(st.v[3]);
 #if defined(LTG_X_SPIN)
     // MEASUREMENT BUILD ONLY (results wrong): the kernel's footprint (registers, LDS, one workgroup per CU) for LTG_X_SPIN us, no memory traffic
@@ -608,6 +691,12 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
                 bf[nt][ks] = __builtin_bit_cast(ltg_bf16x8, t);
             }
             __syncthreads();
+        }
+    }
+    if (hd.count && tid == 0) {   // (behind the prologue's last barrier: every h2 value this workgroup needs sits in registers)
+        if (atomicAdd(hd.count, 1u) + 1u == gridDim.x) {
+            __hip_atomic_store(hd.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next call's kernel starts behind this one on its stream)
+            __hip_atomic_store(hd.word, hd.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     const int ntiles = I / 32, G = gridDim.x;   // full tiles only: the host sends the ragged tail (I % 32 rows) to k_dec1_bwd_adam
@@ -1581,54 +1670,6 @@ __global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kch
 }
 
 // da2 = (sum_z part) * (1 - h2^2)
-// ---- device-side hand-over between the two streams of the one-call step (include/ltg.h: ltg_pipe.sync).  A cross-stream event costs
-// ~12 us per direction on this pool (scripts/micro/sync_cost.hip: hipEventRecord + hipStreamWaitEvent between two 10-us kernels) and
-// ~6 us of bubble on the recording stream; a word in device memory costs the consumer one poll.  A gate is a 32-bit sequence number:
-// the producer stores the call's ordinal, the consumer waits until the word has reached it (wrap-safe compare).  Every wait is bounded
-// (30 s, counted in ltg_pipe.sync[2]): a call that failed half-way leaves a waiter behind, not a hung GPU.
-// The two streams must be CONCURRENT: HIP maps streams onto a few hardware queues, and a waiter in front of its producer in one queue
-// waits for ever -- ltg_g_pipe_probe tests a pair of streams for that.
-struct LtgGate {
-    unsigned* word;   // NULL: no gate
-    unsigned seq;
-    unsigned* expired;   // counts the waits that gave up (ltg_pipe.sync[2]: the host checks it when it joins the pipe)
-    int limit;           // milliseconds before a wait gives up (0: 30 s)
-};
-#define LTG_NO_GATE LtgGate{nullptr, 0u, nullptr, 0}
-// acquire = false: the consumer only needs to run AFTER the producer (a write-after-read hazard), it reads nothing the producer wrote --
-// no cache invalidation (dec-0: 14.7 -> ~8 us; whoever reads the producer's data later does so behind a kernel boundary)
-__device__ __forceinline__ void ltg_gate_wait(LtgGate g, bool acquire = true) {   // first statement of a consumer kernel; every thread calls
-    if (!g.word) return;
-    if (threadIdx.x == 0) {
-        bool open = false;
-        const unsigned long long ticks = (unsigned long long)(g.limit > 0 ? g.limit : 30000) * 100000ull;   // wall_clock64: 100 MHz
-        const unsigned long long t0 = wall_clock64();
-        while (!open) {
-            open = (int)(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq) >= 0;
-            if (open || wall_clock64() - t0 > ticks) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!open && g.expired) atomicAdd(g.expired, 1u);
-    }
-    __syncthreads();
-    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__device__ __forceinline__ void ltg_gate_set(LtgGate g) {   // by ONE thread, after everything the consumer may rely on has completed
-    if (!g.word) return;                                     // (a kernel boundary in front of the caller: the producers here are whole kernels)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(g.word, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one wave in front of the side stream's work: returns when the gate opens (the kernels behind it start in stream order)
-// (set_first: a gate this kernel opens when it starts -- whatever preceded it on its stream is complete)
-__global__ __launch_bounds__(64) void k_gate_wait(LtgGate g, LtgGate set_first = LTG_NO_GATE) {
-    if (threadIdx.x == 0) ltg_gate_set(set_first);
-    ltg_gate_wait(g);
-}
-// one wave behind the side stream's work: opens the gate
-__global__ __launch_bounds__(64) void k_gate_set(LtgGate g) {
-    if (threadIdx.x == 0) ltg_gate_set(g);
-}
-
 __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __restrict__ part, const float* __restrict__ h2,
                                             float* __restrict__ da2, LtgGate started = LTG_NO_GATE) {
     // started: opened by the first workgroup as soon as this kernel runs -- whatever preceded it on its stream (the dh2 product) is
@@ -1959,10 +2000,10 @@ __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* 
 // rows of the batch's distinct items (G-step batches carry the list): up to `target`, before enc-0 reads them
 __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
                                                            const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target,
-                                                           ltg_gen_state st, AdamC ad, LtgGate wait = LTG_NO_GATE) {
-    // wait (one-call step, slice on the side stream): the slice of the previous call is done with every row.  Ordering only: the slice
-    // ended -- a kernel boundary, its rows written back -- before the gate opened, and this kernel's own start invalidated what it had cached
-    ltg_gate_wait(wait, false);
+                                                           ltg_gen_state st, AdamC ad, const unsigned* __restrict__ poison = nullptr) {
+    // (one-call step, slice on the side stream: the slice of the previous call is done with every row before this kernel starts -- the
+    // previous call's last kernel on this stream waited for word 6, ltg_gate_wait_tail; poison: that wait gave up)
+    if (ltg_poisoned(poison)) return;
     const int u = blockIdx.x;
     if (u >= nu) return;
     const int H4 = H >> 2;
@@ -2096,7 +2137,9 @@ __global__ __launch_bounds__(Q0_NT) void k_q0_step_touched(int I, int H, int nu,
 }
 
 // rows start, start + stride, ...: zero-gradient steps up to `target` (the rotating slice of a G step; the flush: 0, 1)
-__global__ __launch_bounds__(Q0_NT) void k_q0_sweep(int I, int H, int start, int stride, int target, ltg_gen_state st, AdamC ad) {
+__global__ __launch_bounds__(Q0_NT) void k_q0_sweep(int I, int H, int start, int stride, int target, ltg_gen_state st, AdamC ad,
+                                                    const unsigned* __restrict__ poison = nullptr) {
+    if (ltg_poisoned(poison)) return;
     const int H4 = H >> 2;
     for (size_t i = (size_t)start + (size_t)blockIdx.x * stride; i < (size_t)I; i += (size_t)gridDim.x * stride) {
         const int from = st.q0_last[i];
@@ -2539,13 +2582,13 @@ inline bool q0_lazy(const ltg_config* cfg, const ltg_gen_state* gen) {
            cfg->n_items >= 8192;   // smaller slabs update W_q0 as a dense product: nothing to defer
 }
 // the item rows this batch reads, up to the caller's clock (no-ops for rows that are current)
-void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st, LtgGate wait = LTG_NO_GATE) {
+void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st, const unsigned* poison = nullptr) {
     if (!q0_lazy(cfg, gen) || bt->n_rows <= 0) return;
     const AdamC ad = make_adam(cfg, 1);   // b1, b2, eps; the learning rates come from the history ring
     if (bt->uptr && bt->csr_pos) {
         if (bt->n_unique > 0)
             hipLaunchKernelGGL(k_q0_touch_unique, dim3(bt->n_unique), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
-                               gen->q0_ord, *gen, ad, wait);
+                               gen->q0_ord, *gen, ad, poison);
     } else {
         hipLaunchKernelGGL(k_q0_touch_rows, dim3(bt->n_rows), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_rows, bt->indptr, bt->indices, gen->q0_ord, *gen, ad);
     }
@@ -2869,10 +2912,15 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         const int nA = (((n + 31) / 32) * ((h12 + 31) / 32) + 7) & ~7;      // padded: job B starts on a multiple of 8 (XCD chunk map)
         const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
         const int nC = ks * ((h3 + 2 + 31) / 32);
-        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
-                                                        w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab));
         const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab));
+        // jobs B / C (dw3, db3, dw4, db4, d_loss: they need the forward only) ride either beside job A (dpre1) or beside stage 2's
+        // embedding products (tuning-knob bit 5): stage 1 is then the critical product alone
+        const bool bc2 = (cfg->reserved0 & 32) != 0;
+        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(bc2 ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
+                                                        w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab));
+        const DBwdBC bc{n2, nB, h3, ntile, w.A1, w.A3, w.G3, w.spart, disc->p[7]};
+        if (bc2) LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2<true>, dim3(n2 + nB + nC), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab, bc));
+        else LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2<false>, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab, bc));
         if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
         else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st);
         return check_launch();
@@ -3061,7 +3109,8 @@ static const int32_t* g_slot_map(const ltg_config* cfg, const ltg_batch* bt, con
 
 // sparse gradient rows of W_q0 (+ partial bias rows) into w.gq0
 static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts, const Workspace& w,
-                        hipStream_t st, const ltg_gen_state* gen = nullptr, const AdamC* ad = nullptr, bool row_waves = true) {   // gen + ad: fused lazy Adam step
+                        hipStream_t st, const ltg_gen_state* gen = nullptr, const AdamC* ad = nullptr, bool row_waves = true,
+                        const unsigned* poison = nullptr) {   // gen + ad: fused lazy Adam step
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique;
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_GRAD);
@@ -3071,7 +3120,7 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
 #define LTG_G0_ROWS(N)                                                                                                                                   \
     hipLaunchKernelGGL(fk_enc0_grad_rows<N>, g, dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, \
                        o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{},     \
-                       ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem)
+                       ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem, poison)
         if (ncb == 1) LTG_G0_ROWS(1);
         else if (ncb == 2) LTG_G0_ROWS(2);
         else LTG_G0_ROWS(3);
@@ -3092,7 +3141,7 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
 //   stage 1: dh1 tiles + W_p0        stage 2: W_q1, W_q0 (dense product when slot == NULL, else sweep + sparse rows), scalars
 static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st,
-                   bool no_q0 = false, bool q0_bias = false) {
+                   bool no_q0 = false, bool q0_bias = false, const unsigned* poison = nullptr, LtgGate end_wait = LTG_NO_GATE) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     TailArgs a;
     a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
@@ -3124,10 +3173,11 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
     a.da1 = w.da1;
     a.slot = slot; a.rowout = w.rowout; a.cnt = o->cnt; a.anneal = o->anneal; a.lam = o->gan_lambda;
     a.loss_out = w.scal; a.loss_out2 = loss_out;
+    a.poison = poison; a.n_wait = end_wait.word ? 1 : 0; a.end_wait = end_wait;
     const Probe pr{o->probe, st};
     const int kid = stage == 0 ? LTG_K_DZ : (stage == 1 ? LTG_K_DH1 : LTG_K_G_TAIL);
     pr.before(kid);
-    const dim3 g(a.nz + a.nh + a.n1 + a.n2 + a.n3 + a.n4 + a.n5);
+    const dim3 g(a.nz + a.nh + a.n1 + a.n2 + a.n3 + a.n4 + a.n5 + a.n_wait);
     if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_g_tail<true>, g, dim3(NT), 0, st, a, *gen, ad);
     else hipLaunchKernelGGL(fk_g_tail<false>, g, dim3(NT), 0, st, a, *gen, ad);
     pr.after(kid);
@@ -3177,7 +3227,7 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
                             const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false,
-                            bool only_dec1 = false, int dw_groups = 0) {
+                            bool only_dec1 = false, int dw_groups = 0, LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr}) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
@@ -3207,7 +3257,11 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
     }
     if (have_aux) release_aux();  // dlog, h2, da2 and the dh2 products with the old W_p1t are all enqueued
-    int dw_gmax = 224;   // persistent workgroups of the streaming decoder weight update (see launch_dw)
+    // persistent workgroups of the streaming decoder weight update (see launch_dw).  Slabs below 65 536 items: 160 -- the rest of the
+    // step runs beside the update, and what a kernel of that chain costs there is mostly how many CUs the update leaves it (round 4,
+    // same box, per-rank proxy at 25 024 items: 196 workgroups 173.3-174.1 us per step, 160: 170.1-170.5, 128: 184, 96: 205;
+    // 20 000 items: 166.3 / 161.6 / 161.3-162.4 / 179; the update alone takes 89 / 92 / 110 / 122 us with 196 / 160 / 128 / 98)
+    int dw_gmax = I / 32 < 2048 ? 160 : 224;
     auto launch_dw = [&]() {
         const Probe prs{o->probe, s_dw};
         prs.before(LTG_K_DEC1_BWD_ADAM);
@@ -3223,7 +3277,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
                 // 224 or with 196 workgroups -- 60 CUs left to the chain and the collective running beside it)
                 if (!gk && ntl > gmax) gmax = (ntl + (ntl + gmax - 1) / gmax - 1) / ((ntl + gmax - 1) / gmax);
                 if (dw_groups > 0) gmax = dw_groups;
-                hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
+                hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, hd);
                 if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
                     hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
             } else {
@@ -3559,6 +3613,19 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     const Probe pr{o->probe, st};
     const AdamC ad = make_adam(cfg, o->adam_t);
     float* rowpart = pp->rowpart_all + (size_t)rank * B * RP;   // this rank's block of the all-gather buffer: the exchange is in place
+    // Device words of the pipe (ltg_pipe.sync; `seq` = this call's ordinal):
+    //   0  the dh2 product of call seq is complete (set by the slab sum when it starts; polled by one wave in front of the weight update)
+    //   1  the weight update of call seq has READ h2 (its workgroups count themselves in word 8 behind their prologue; ragged slabs: set
+    //      when the update ends) -- polled by the last thread of the next call's enc-1, in front of dec-0, which overwrites h2
+    //   7  the weight update of call seq has ENDED (one wave behind it) -- polled by the last thread of the next call's dec-0, in front of
+    //      the streaming forward, which reads the shadow rows and the bias the update writes
+    //   5  enc-0 of call seq has started = the catch-up of the batch's rows is complete (polled by one wave in front of the clock slice)
+    //   6  the clock slice of call seq has ended (set by the next kernel of the side stream when it starts) -- polled by the last thread
+    //      of call seq's OWN last kernel (the tail), in front of the next call's catch-up
+    //   2  waits that gave up = the pipe's POISON: every kernel of the step that writes h2 or the model returns at once when it is set
+    // Every poll is made by ONE thread, either a one-wave kernel of the side stream or the last thread of the kernel in front of the
+    // one that needs the gate: no workgroup of a large launch ever holds a CU while it waits for a producer that still needs one.
+    const unsigned* poison = (fork_dec1 && pp->sync && (pp->flags & LTG_PIPE_EVENTS) == 0) ? pp->sync + 2 : nullptr;
 #define LTG_HIP(x) do { if ((x) != hipSuccess) return LTG_ELAUNCH; } while (0)
 #define LTG_COMM(x) do { if ((x) != 0) return LTG_ELAUNCH; } while (0)
     // ---- the clock slice forked by the PREVIOUS call is done (it must not meet the catch-up below on a row); the rows this batch reads
@@ -3574,9 +3641,10 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         // skips them whatever happens to them later), a one-wave kernel in front of the sweep polls for it; word 6 is opened by the side
         // stream's next kernel (the waiter in front of the weight update) when it starts, and the NEXT call's catch-up polls for it
         // (issued in the order the device needs them: the critical stream's kernels first)
-        q0_touch(cfg, gen, bt, st, LtgGate{pp->sync + 6, pp->seq - 1u, pp->sync + 2, 0});
+        // (the previous call's last kernel waited for word 6 before it ended: ltg_gate_wait_tail in fk_g_tail)
+        q0_touch(cfg, gen, bt, st, poison);
     } else
-        q0_touch(cfg, gen, bt, st);
+        q0_touch(cfg, gen, bt, st, poison);
     // ---- forward: enc-0 over the local slab -> exchange 1 -> enc-1 (bias + tanh in its loader), dec-0, local logits + statistics
     {
         ltg_gen_acts a1 = *acts;
@@ -3587,16 +3655,17 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         const int start = gen->q0_ord % qP;
         hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
         if (gen->q0_ord > 0 && start < I)
-            hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1));
+            hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1), poison);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
     LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,
-                                                  o->fwd.is_training, cfg->seed, o->fwd.rng_step, acts->mulv, acts->z, gen->p[4], acts->h1));
-    // (dec-0 overwrites h2, which the previous step's weight update is still reading: it waits for the word the update's stream sets
-    // behind it -- or, with events, the stream waits)
+                                                  o->fwd.is_training, cfg->seed, o->fwd.rng_step, acts->mulv, acts->z, gen->p[4], acts->h1,
+                                                  gates ? LtgGate{pp->sync + 1, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE));
+    // (dec-0 overwrites h2, which the previous step's weight update reads in its prologue: enc-1's last thread polled for word 1 -- or,
+    // with events, the stream waits for the whole update; the streaming forward behind dec-0 needs the update's END: word 7)
     if (fork_dec1 && !gates) LTG_HIP(hipStreamWaitEvent(st, ev_dec1, 0));
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
-                                                  acts->h2, gates ? LtgGate{pp->sync + 1, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE));
+                                                  acts->h2, gates ? LtgGate{pp->sync + 7, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE, poison));
     {
         int G = 0;
         LTG_PROBED(pr, LTG_K_DEC1_FWD, G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st));
@@ -3645,9 +3714,14 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
                 LTG_HIP(hipEventRecord(ev_slice, sd));
             }
         }
-        const int rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups);
+        // (a ragged slab's last I % 32 rows go through the generic tile kernel behind the streaming one, and that reads h2 throughout:
+        // word 1 then opens with word 7)
+        const bool h2_early = gates && (I % 32) == 0;
+        const int rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups,
+                                        h2_early ? LtgH2Done{pp->sync + 8, pp->sync + 1, pp->seq, poison} : LtgH2Done{nullptr, nullptr, 0u, poison});
         if (rc != LTG_OK) return rc;
-        if (gates) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 1, pp->seq, nullptr, 0});
+        if (gates) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 7, pp->seq, nullptr, 0},
+                                      h2_early ? LTG_NO_GATE : LtgGate{pp->sync + 1, pp->seq, nullptr, 0});
         else if (fork_dec1) LTG_HIP(hipEventRecord(ev_dec1, sd));
         if (!gates)
             hipLaunchKernelGGL(k_da2, dim3((n_da2 + NT - 1) / NT < 2048 ? (n_da2 + NT - 1) / NT : 2048), dim3(NT), 0, st, n_da2, nsplit, w.part, (const float*)nullptr,
@@ -3658,8 +3732,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz_dh2, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, pp->dh2, acts->h2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv, w.da2));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-    g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, (pp->flags & LTG_PIPE_WIDE_GRAD) == 0);
-    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true);
+    g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, (pp->flags & LTG_PIPE_WIDE_GRAD) == 0, poison);
+    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true, poison,
+           side_slice ? LtgGate{pp->sync + 6, pp->seq, pp->sync + 2, 0} : LTG_NO_GATE);
     if (!defer_slice) {   // the slice of THIS step at its end, in program order (the cut-point schedule)
         const int ord = gen->q0_ord + 1, start = ord % qP;
         if (start < I) hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, st, I, H, start, qP, ord, *gen, make_adam(cfg, 1));

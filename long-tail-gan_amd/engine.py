@@ -128,11 +128,12 @@ class Pipe:
         self.h1pre = torch.zeros(rows, engine.H, **f)
         self.rowpart_all = torch.zeros(n_ranks * rows * 5, **f)
         self.dh2 = torch.zeros(rows, engine.H, **f)
-        self.sync = torch.zeros(16, dtype=torch.int32, device=dev)        # gates of the device-side fork / join + the count of expired waits
+        self.sync = torch.zeros(16, dtype=torch.int32, device=dev)        # words of the device-side hand-overs; [2] = waits that gave up = the pipe's poison
         self.c = cabi.ltg_pipe(self.side_stream.cuda_stream, self._ev[0].start, self._ev[0].stop, self._ev[1].start, _ptr(self.h1pre),
                                _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0, _ptr(self.sync))
         self.probed_for = None      # the caller's stream the side stream was last tested against (Engine._pipe_ready)
         self.handover = None        # "device-words" | "events"
+        engine._pipes.add(self)     # Engine.check_pipes(): nothing reads the model out behind a wait that gave up
 
     def new_side_stream(self):
         self.side_stream = torch.cuda.Stream(self.sync.device)
@@ -142,8 +143,17 @@ class Pipe:
         return [self.h1pre, self.rowpart_all, self.dh2]
 
     def expired_waits(self):
-        """device-side waits of the fork / join that gave up (must be 0; synchronises)"""
+        """device-side waits of the hand-overs that gave up (must be 0; synchronises).  Non-zero = the pipe is POISONED: every kernel of the
+        one-call step that writes h2 or the model returns at once (csrc: ltg_poisoned), so the model stays what it was when the wait expired."""
         return int(self.sync[2].item())
+
+    def reset(self):
+        """after a failed call: nothing in flight, every word zero, ordinals restart (a call that stopped between its gate launches would
+        otherwise leave the next one waiting for words nobody sets)"""
+        torch.cuda.synchronize(self.sync.device)
+        self.sync.zero_()
+        self.c.seq = 0
+        torch.cuda.synchronize(self.sync.device)
 
 
 class Engine:
@@ -157,6 +167,8 @@ class Engine:
         for item slabs of 8192 items or more.  Rows are brought up to date by every forward that reads them; `g_flush()`
         does it for all rows and runs after every G step unless a trainer holds `q0_defer` for the length of its phase."""
         self.lib = cabi.load()
+        import weakref
+        self._pipes = weakref.WeakSet()                              # the Pipe objects created for this engine (check_pipes)
         self._pinned = None                                          # pin_stream()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
@@ -430,10 +442,20 @@ class Engine:
         if self.lazy_q0 and self._q0_dirty:
             cabi.check(self.lib.ltg_g_flush(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_g_flush")
             self._q0_dirty = False
+            self.check_pipes()                                       # (end of a G phase / before the model is read out: one host sync)
             # every row is current: restart the ordinals (the int32 clock never grows without bound; stream order keeps the
             # memset behind the flush kernel)
             self.q0_last.zero_()
             self.gen_c.q0_ord = 0
+
+    def check_pipes(self):
+        """raises if a device-side wait of a one-call G step gave up (ltg_pipe.sync[2]).  The kernels behind such a wait have skipped
+        their work, so the model is the one from before that step -- but the run is not the run that was asked for.  Synchronises."""
+        for pipe in list(self._pipes):
+            n = pipe.expired_waits()
+            if n:
+                raise cabi.LtgError("%d device-side wait(s) of the G step's hand-overs gave up: the steps behind them were skipped, "
+                                    "the results of that phase are not trustworthy" % n)
 
     # ------------------------------------------------------------------ the G step cut at its exchange points
     def fwd_opts(self, keep_prob=0.75, is_training=0.0, rng_step=0, drop_keep=None, eps=None, probe=None):
@@ -462,10 +484,12 @@ class Engine:
         rc = self.lib.ltg_g_step_sharded(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
                                          C.byref(gopts), C.byref(acts.c), C.byref(comm.c) if comm is not None else None, C.byref(pipe.c),
                                          _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
+        if rc != 0:
+            pipe.reset()               # (the call may have stopped between its gate launches: words of this ordinal that nobody will set)
         cabi.check(rc, "ltg_g_step_sharded")
         if not self.q0_defer:
             self.pipe_join(pipe)       # a standalone step: nothing stays in flight behind the call (a trainer joins once per phase)
-        self._q0_stepped()
+        self._q0_stepped()             # (standalone: flushes the clock and checks the pipe's poison -- g_flush)
         return loss_out
 
     def _pipe_ready(self, pipe):
@@ -484,7 +508,7 @@ class Engine:
         else:
             pipe.handover = "events"
             for _ in range(6):
-                ok = self.lib.ltg_g_pipe_probe(C.byref(pipe.c), st)
+                ok = self.lib.ltg_g_pipe_probe(C.byref(pipe.c), st) if hasattr(self.lib, "ltg_g_pipe_probe") else 0   # (an older build under LTG_AB_COMPAT)
                 if ok < 0:
                     cabi.check(ok, "ltg_g_pipe_probe")
                 if ok == 1:

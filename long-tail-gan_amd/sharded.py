@@ -88,7 +88,7 @@ class ShardedTrainer(Trainer):
         if dist.get_backend(self.group) == "nccl" and os.environ.get("LTGAN_COMM", "rccl") == "rccl":
             comm, err = None, ""
             try:
-                comm = RcclComm(self.group, engine.device)
+                comm = RcclComm(self.group, engine.device, warm_counts=(self.pipe.h1pre.numel(), self.pipe.rowpart_all.numel() // self.R))
             except Exception as e:                # (every rank must take the same branch: agree below)
                 err = repr(e)
             ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=engine.device)
@@ -101,6 +101,22 @@ class ShardedTrainer(Trainer):
             if self.rank == 0:
                 print("ltgan.sharded: direct RCCL communicator unavailable (%s); exchanges go through torch.distributed" % err, flush=True)
         self.comm = HostComm(self.group, self.pipe.buffers())
+
+    def close(self):
+        """destroys the step's own RCCL communicator (ncclCommDestroy); call before torch.distributed.destroy_process_group()"""
+        if self.pipe is not None:
+            self.eng.pipe_join(self.pipe)
+            torch.cuda.synchronize(self.eng.device)
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "comm", None) is not None:
+                self.comm.close()
+        except Exception:
+            pass
 
     # -- collectives -------------------------------------------------------------------------------
     def _allreduce(self, t):

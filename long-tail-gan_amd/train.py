@@ -90,6 +90,7 @@ def save_checkpoint(path, eng, tr, epoch, rank=0, world=1):
     st = {"format": CKPT_FORMAT, "epoch": epoch, "adam_t": eng.adam_t, "update_count": tr.update_count, "rng_step": tr.rng_step,
           "shuffle_rng_state": _rng_state_plain(tr.np_rng.get_state()), "d_w1": eng.d_emb.cpu()}
     eng.g_flush()                                      # lazy Adam clock of W_q0: every row up to date before it is read
+    eng.check_pipes()                                  # nothing is written out behind a device-side wait that gave up
     gp, gm, gv = _full(eng.g_p, eng, world), _full(eng.g_m, eng, world), _full(eng.g_v, eng, world)     # collective: every rank
     for i, n in enumerate(G_NAMES):
         tf = (lambda t: t.t().contiguous()) if i == 3 else (lambda t: t)
@@ -180,7 +181,6 @@ def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BAT
             print("global-epoch:%s, discr-epoch:%s, d_loss:%.5f" % (i, j, dl[j, 0]))
         print("")
         gl = tr.g_phase().cpu().numpy()
-        tr.check_pipe(sync=False)       # (the copy above has synchronised: the phase's expired-wait count is on the host)
         for j in range(NUM_SUB_EPOCHS):
             print("global-epoch:%s, generator-epoch:%s, g_loss:%.5f (vae_loss: %.5f + gan_loss: %.5f, anneal: %.5f)" %
                   (i, j, gl[j, 0], gl[j, 1], gl[j, 2], tr.last_anneal[j]))
@@ -194,6 +194,8 @@ def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BAT
         last = m
     if world > 1:
         import torch.distributed as dist
+        if hasattr(tr, "close"):
+            tr.close()                  # the step's own RCCL communicator
         dist.barrier()
         dist.destroy_process_group()
     return last

@@ -143,17 +143,11 @@ class Trainer:
                                             seg_off=t["seg_off"], y_off=j * self.data.n_slots + t["s0"])
 
     def check_pipe(self, sync=True):
-        """raises if a device-side wait of the one-call G step's hand-overs gave up in a finished phase (ltg_pipe.sync[2])"""
-        if self.pipe is None or getattr(self, "_expired_host", None) is None:
-            return
-        if sync:
-            torch.cuda.synchronize(self.eng.device)
-        n = int(self._expired_host[0])
-        if n:
-            raise RuntimeError("%d device-side wait(s) of the G step's fork / join gave up: the results of that phase are not trustworthy" % n)
+        """raises if a device-side wait of the one-call G step's hand-overs gave up (Engine.check_pipes; every G phase ends with it)"""
+        if self.pipe is not None:
+            self.eng.check_pipes()
 
     def _g_begin(self):
-        self.check_pipe(sync=False)     # the previous G phase (its copy was queued a whole C + D phase ago)
         self.last_anneal = []
         self.eng.q0_defer = True        # lazy Adam clock of W_q0: one flush at the end of the phase
         self.eng.pin_stream()
@@ -166,11 +160,8 @@ class Trainer:
                 eng.pipe_join(self.pipe)    # the forked weight update and clock slice of the last step
             eng.q0_defer = False
             if ok:
-                eng.g_flush()
-                if self.pipe is not None:     # (checked when the next phase begins / by check_pipe(): no host sync inside the phase)
-                    if getattr(self, "_expired_host", None) is None:
-                        self._expired_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                    self._expired_host.copy_(self.pipe.sync[2:3], non_blocking=True)
+                eng.g_flush()               # (+ Engine.check_pipes: one host sync per phase; raises if a hand-over wait gave up)
+                self.check_pipe()           # (a phase without a dirty clock still checks)
         finally:
             eng.q0_defer = False
             eng.pin_stream(False)
@@ -225,7 +216,6 @@ class Trainer:
         self.g_phase()
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        self.check_pipe(sync=False)
         return dict(user_err_cnt=err, t_create=t1 - t0, t_d=t2 - t1, t_g=t3 - t2, t_total=t3 - t0)
 
 

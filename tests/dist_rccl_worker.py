@@ -41,6 +41,9 @@ def main():
             losses.append(tr.g_phase().clone())
         torch.cuda.synchronize()
         runs.append((data.fake_gen.clone(), losses, [t.clone() for t in eng.g_p + eng.g_m + eng.g_v]))
+        if kind == "rccl":
+            tr.close()
+            assert tr.comm is None
     a, b = runs
     assert torch.equal(a[0], b[0]), "fake pairs differ"
     for x, y in zip(a[1], b[1]):

@@ -24,9 +24,13 @@ def main():
     wide = mode in ("wide_fp8", "wide_fp8_full")                 # BASELINE config 5 inside the sharded loop: wide discriminator, fp8 GEMM operands
     if mode == "cutpoints":                                      # the G step cut at its exchange points (torch.distributed collectives)
         os.environ["LTGAN_SHARDED_STEP"] = "0"                   # instead of the one-call step with in-stream exchanges
-    dist.init_process_group("gloo")
+    # LTGAN_TEST_BACKEND=nccl (tests/test_gpu_sharded.py::test_two_ranks_on_two_gpus_over_rccl, boxes with >= 2 GPUs): one GPU per
+    # rank, the exchanges issued in-stream by RCCL itself -- the transport of a real node
+    backend = os.environ.get("LTGAN_TEST_BACKEND", "gloo")
+    dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = "cuda:0"
+    dev = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
     idx, _ = synthetic_index(workload, users=users, seed=5)
     I = idx.n_items
     hs = (2048, 1024, 512, 256) if mode == "wide_fp8_full" else ((512, 256, 256, 128) if wide else (16, 24, 40, 32))
@@ -43,6 +47,8 @@ def main():
     assert tr.d_split == d_split
     one_call = precision == "bf16" and hi - lo >= 8192 and mode != "cutpoints"
     assert (tr.pipe is not None) == one_call and (tr.comm is not None) == one_call, (tr.pipe, tr.comm)
+    if backend == "nccl" and one_call:
+        assert tr.comm.kind == "rccl-direct" and tr.comm.count == world, (tr.comm.kind, tr.comm.count)     # ncclCommCount of the step's own communicator
     p0 = [t.clone() for t in ref.g_p]                            # initial variables: the runs are compared by how far they MOVE
     # ---- ranking metrics over the shards (before training: parameters are identical, only the all-reduce order differs)
     import scipy.sparse as sp
@@ -116,9 +122,14 @@ def main():
         else:
             assert dd.max().item() < (2e-5 if d_split else 1e-6), ("disc tensor", i)
     assert eng.adam_t == ref.adam_t
+    if tr.pipe is not None:
+        assert tr.pipe.expired_waits() == 0 and (ref_tr.pipe is None or ref_tr.pipe.expired_waits() == 0)
+    transport = getattr(tr.comm, "kind", "torch.distributed")
+    tr.close()
     dist.barrier()
     if rank == 0:
-        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s d_precision=%s" % (world, workload, precision, d_split, dq))
+        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s d_precision=%s backend=%s transport=%s handover=%s" % (
+            world, workload, precision, d_split, dq, backend, transport, getattr(tr.pipe, "handover", None)))
     dist.destroy_process_group()
 
 

@@ -185,6 +185,47 @@ def test_bench_parent_counts_gpus_without_the_hip_runtime(monkeypatch):
     assert was_loaded or "torch" not in sys.modules      # importing bench.py and counting devices pulls in no torch
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_ranks_choose_their_backend_when_the_parent_could_not_count_gpus():
+    """sysfs may be unreadable inside a container: the parent then forces nothing, the ranks decide from torch.cuda.device_count(),
+    and a gloo fallback is recorded in the result line (config.backend_choice)."""
+    bench = _bench_module()
+    assert bench.choose_backend(8, 8, env={}) == ("nccl", "one GPU per rank")
+    b, note = bench.choose_backend(2, 1, env={})
+    assert b == "gloo" and "fallback" in note and "2 ranks on 1" in note
+    b, note = bench.choose_backend(2, 1, env={"LTGAN_DIST_BACKEND": "gloo"})
+    assert b == "gloo" and "LTGAN_DIST_BACKEND" in note
+    assert bench.choose_backend(4, 8, env={"LTGAN_DIST_BACKEND": "nccl"})[0] == "nccl"
+
+
+def test_bench_step_fraction_is_priced_on_the_bytes_the_step_moves():
+    """roofline.step_frac uses the lazy clock's byte model when the clock is on (it cannot exceed 1 by construction: the model counts
+    only what the step has to move); SURVEY 8/d4's dense-Adam count sits beside it under its own key and is never smaller."""
+    import types
+    import numpy as np
+    bench = _bench_module()
+    nb, B, I = 4, 100, 200000
+    indptr = np.arange(0, nb * B + 1, dtype=np.int64) * 30
+    idx = types.SimpleNamespace(train=types.SimpleNamespace(indptr=indptr))
+    views = [dict(lo=b * B, hi=(b + 1) * B, n_real=900, n_slots=950) for b in range(nb)]
+    data = types.SimpleNamespace(n_batches=nb, view=lambda b: views[b])
+    for lazy in (True, False):
+        eng = types.SimpleNamespace(I_global=I, H=600, Z=200, h0=100, h1=150, h2=250, h3=300, lazy_q0=lazy, q0_period=32)
+        f = bench.step_fracs(idx, data, eng, 10, None, 1e-3, 1)
+        assert f["step_algorithmic_bytes"] <= f["step_algorithmic_bytes_dense_adam"] and f["step_frac"] <= f["step_frac_vs_dense_adam_bytes"]
+        assert (f["step_algorithmic_bytes"] < f["step_algorithmic_bytes_dense_adam"]) == lazy
+        # a step that took exactly the time its bytes need at 8 TB/s sits at 1.0 on its own model
+        t = f["step_algorithmic_bytes"] / bench.PEAK["hbm"]
+        assert abs(bench.step_fracs(idx, data, eng, 10, None, t, 1)["step_frac"] - 1.0) < 1e-12
+
+
 def test_default_initialisers_match_the_reference_distributions():
     """a3: MultiVAE.py:199-207,219-225 (Xavier-uniform weights, truncated-normal sigma = 1e-3 biases) and
     discriminator.py:14-41 (truncated-normal sigma = 0.1 matrices, zero biases): shapes, hard bounds and moments."""

@@ -113,10 +113,155 @@ def _fake_pairs(rng, X, I, per_user=5):
     return np.array(rows, np.int32), np.array(gen, np.int32), np.array(pop, np.int32)
 
 
+def _warm_moments(shapes_like, grads, seed):
+    """Adam moments as after many updates: m ~ N(0, rms(g)), v ~ U(0.25, 4) rms(g)^2 per tensor (fp32-representable), so that the
+    step's quotient m / (sqrt(v) + eps) is a smooth function of every input -- what a first step from zero moments (a sign
+    function of g) cannot test."""
+    r = np.random.default_rng(seed)
+    m0, v0 = {}, {}
+    for k, ref in shapes_like.items():
+        g = np.asarray(grads[k], np.float64)
+        nz = g[g != 0]
+        s = float(np.sqrt(np.mean(nz * nz))) if nz.size else 1e-3
+        m0[k] = (r.normal(0.0, s, ref.shape)).astype(np.float32)
+        v0[k] = (r.uniform(0.25, 4.0, ref.shape) * s * s).astype(np.float32)
+    return m0, v0
+
+
+def _check_warm_adam(p_got, p0, p_want, m_got, m_want, v_got, v_want, tol, tag, t, lr=1e-3, eps=1e-8, max_norm=False):
+    """theta-move, m and v ELEMENT-WISE against TF-Adam in fp64 (train.py:160-164) from injected non-zero moments: pins the hardware
+    sqrt / reciprocal form of the library's adam_move to m / (sqrt(v) + eps).
+    (a) the quotient alone: every element's move against lr_t m / (sqrt(v) + eps) evaluated in fp64 from the moments the DEVICE
+        wrote -- no gradient error in it, so the bound is a few fp32 ulp (v_sqrt_f32 and v_rcp_f32 are 1 ulp each);
+    (b) end to end against the oracle's update: element-wise (1e-4) where the move is not negligible on the fp32 path; in the max norm
+        (1e-3, north_star's bound) with bf16 decoder operands."""
+    p0 = np.asarray(p0, np.float64)
+    mv_got, mv_want = np.asarray(p_got, np.float64) - p0, np.asarray(p_want, np.float64) - p0
+    ulp = np.spacing(np.maximum(np.abs(p0), np.abs(np.asarray(p_got, np.float64))).astype(np.float32)).astype(np.float64)   # theta is rounded to fp32 once
+    mg, vg = np.asarray(m_got, np.float64), np.asarray(v_got, np.float64)
+    # lr_t as the library forms it (csrc make_adam): lr, beta1, beta2 are the fp32 values of ltg_config, the powers are taken in fp64
+    # (TF keeps beta^t as an fp32 variable multiplied up step by step: either differs from the exact 0.999^t by ~1e-5 at t = 138,
+    # 6e-6 on lr_t -- far inside (b)'s bound, but 3x this check's)
+    lr32, b1, b2 = (float(np.float32(x)) for x in (lr, 0.9, 0.999))
+    lr_t = np.float64(np.float32(lr32 * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)))
+    q = -lr_t * mg / (np.sqrt(vg) + np.float64(np.float32(eps)))
+    qerr = (np.abs(mv_got - q) - ulp) / np.maximum(np.abs(q), 1e-30)
+    w = np.unravel_index(int(np.argmax(qerr)), qerr.shape)
+    assert float(qerr[w]) < 2e-6, (tag, "quotient", float(qerr[w]), "at", w, "p0 %.9g p_got %.9g m %.9g v %.9g move %.9g want %.9g ulp %.3g" % (
+        p0[w], np.asarray(p_got, np.float64)[w], mg[w], vg[w], mv_got[w], q[w], ulp[w]))
+    err = np.abs(mv_got - mv_want)
+    if max_norm:
+        # bf16 decoder operands: dlogits are ROUNDED to bf16 before the two products that consume them, so an element of the gradient
+        # differs from the (equally quantised) oracle's by whatever a value near a rounding boundary moves it -- a bound relative to
+        # the tensor's largest element, like every bf16 comparison of this file; (a) above stays element-wise
+        worst = float((err - ulp).max() / np.abs(mv_want).max())
+        assert worst < tol, (tag, "theta move (max norm)", worst)
+        assert Hh.rel_err(m_got, m_want) < tol and Hh.rel_err(v_got, v_want) < 2 * tol, (tag, "m / v")
+        return worst
+    sel = np.abs(mv_want) > 0.01 * np.abs(mv_want).max()
+    worst = float(((err - ulp)[sel] / np.abs(mv_want)[sel]).max())
+    assert worst < tol, (tag, "theta move", worst)
+    selm = np.abs(m_want) > 0.01 * np.abs(m_want).max()
+    assert float((np.abs(m_got - m_want)[selm] / np.abs(m_want)[selm]).max()) < tol, (tag, "m")
+    assert float((np.abs(v_got - v_want) / v_want).max()) < tol, (tag, "v")
+    return worst
+
+
+G_CASES = [(1000, 100, "step"), (333, 17, "step"), (6000, 100, "step"), (6000, 100, "step-config-d"), (8200, 100, "step"),
+           (8200, 150, "step"), (8200, 100, "one-call"), (20000, 100, "step"), (25024, 100, "step"),
+           (25024, 100, "one-call-config-d"), (200000, 100, "step"), (200000, 100, "one-call"),
+           # ragged slabs (I % 32 != 0): the last I % 32 item rows go through the streaming kernels' tail path
+           (25032, 100, "one-call"), (200008, 100, "step")]
+
+
+def _g_step_case(precision, I, B, path, warm):
+    import torch
+    from ltgan.engine import Pairs, Pipe
+    rng, X, P = _problem(I, B, seed=11 * I + B)
+    hs = (100, 150, 250, 300) if path.endswith("config-d") else (20, 24, 40, 36)
+    D = O.init_discriminator(I, *hs, seed=5)
+    rows, gen, pop = _fake_pairs(rng, X, I)
+    valid = (gen >= 0) & (pop >= 0)
+    cnt = int(valid.sum())
+    step, dstep, keep, dkeep, anneal, lam = 3, 9, 0.75, 0.7, 0.13, 1.0
+    t0 = 137 if warm else 4                 # the shared counter before this update (t = t0 + 1)
+    # ---- oracle
+    q = precision == "bf16"
+    mask = Hh.dropout_mask_dense(SEED, step, B, I, keep)
+    eps = Hh.eps_dense(SEED, step, B, 200)
+    n = len(rows)
+    dm = Hh.d_masks(SEED, dstep, n, hs[1:], dkeep)
+    gid = np.where(valid, gen, 0)
+    pid = np.where(valid, pop, 0)
+    T = O.d_tower(D, pid, gid, dm, dkeep)
+    sum_y = float((T["y"] * valid).sum())
+    losses, g, F = O.g_loss_and_grads(P, X.toarray(), mask, keep, eps, anneal, lam, rows[valid], gen[valid], cnt, sum_y,
+                                      1.0, np.float64, quant=q)
+    ad = O.SharedAdam(1e-3)
+    ad.t = t0
+    m0 = v0 = None
+    if warm:
+        m0, v0 = _warm_moments({k: P[k] for k in O.G_KEYS}, g, seed=I + 7)
+        for k in O.G_KEYS:
+            ad.m[k], ad.v[k] = m0[k].astype(np.float64), v0[k].astype(np.float64)
+    P64 = {k: np.asarray(v, np.float64) for k, v in P.items()}
+    ad.apply(P64, g, O.G_KEYS)
+    # ---- device
+    eng = _engine(I, precision, hs=hs, lr=1e-3)
+    assert eng.Z == 200
+    if warm:
+        eng.set_generator(Hh.gen_to_engine(P), m=Hh.gen_to_engine(m0), v=Hh.gen_to_engine(v0))
+    else:
+        eng.set_generator(Hh.gen_to_engine(P))
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    dev = eng.device
+    fake = Pairs(torch.from_numpy(pop).to(dev), torch.from_numpy(gen).to(dev), torch.from_numpy(rows).to(dev))
+    cnt_t = torch.tensor([cnt], dtype=torch.int32, device=dev)
+    batch = _upload_batch(eng, X, with_csc=True)
+    acts = eng.new_acts(B)
+    eng.adam_t = t0  # exercise the shared counter
+    if path.startswith("one-call"):
+        assert eng.sharded_step_ok(B)
+        pipe = Pipe(eng, B)
+        go = eng.g_opts(cnt_t, anneal, lam, keep, 1.0, dkeep, step, dstep)
+        loss = eng.g_step_sharded(batch, fake, acts, go, pipe)
+        assert pipe.expired_waits() == 0
+    else:
+        loss = eng.g_step(batch, fake, acts, cnt_t, anneal, lam, keep, 1.0, dkeep, rng_step=step, d_rng_step=dstep)
+    eng.g_flush()
+    torch.cuda.synchronize()
+    loss = loss.cpu().numpy()
+    assert abs(loss[4] - sum_y) < 1e-4 * max(1.0, abs(sum_y))
+    assert abs(loss[3] - losses["sum_p"]) < 2e-3 * abs(losses["sum_p"]) + 1e-7
+    for i, k in enumerate(("g_loss", "vae_loss", "gan_loss")):
+        assert abs(loss[i] - losses[k]) < 1e-3 * abs(losses[k]) + 1e-6, k
+    # one TF-Adam update at the shared step t0 + 1
+    want = Hh.gen_to_engine(P64)
+    want_m = Hh.gen_to_engine({k: ad.m[k] for k in O.G_KEYS})
+    want_v = Hh.gen_to_engine({k: ad.v[k] for k in O.G_KEYS})
+    gtol = 2e-3 if q else 5e-4
+    worst = 0.0
+    for i in range(8):
+        m_got = eng.g_m[i].cpu().numpy()
+        v_got = eng.g_v[i].cpu().numpy()
+        p_got = eng.g_p[i].cpu().numpy()
+        if warm:
+            worst = max(worst, _check_warm_adam(p_got, Hh.gen_to_engine(P)[i], want[i], m_got, want_m[i], v_got, want_v[i], 1e-3 if q else 1e-4, ("tensor", i), t0 + 1,
+                                                max_norm=q))
+            continue
+        assert Hh.rel_err(m_got, want_m[i]) < gtol, ("m", i)
+        assert Hh.rel_err(v_got, want_v[i]) < 2 * gtol, ("v", i)
+        # theta moves by at most lr_t per element; compare the MOVE
+        move_got = p_got - Hh.gen_to_engine(P)[i]
+        move_want = want[i] - np.asarray(Hh.gen_to_engine(P)[i], np.float64)
+        _check_adam_move(move_got, move_want, want_m[i], ad.lr_t(t0 + 1), ("theta", i))
+    if warm:
+        print("I=%d %s %s: worst relative error of a theta move from warm moments %.2e" % (I, precision, path, worst))
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("I,B,path", [(1000, 100, "step"), (333, 17, "step"), (6000, 100, "step"), (6000, 100, "step-config-d"), (8200, 100, "step"),
-                                      (8200, 150, "step"), (8200, 100, "one-call"), (20000, 100, "step"), (25024, 100, "step"),
-                                      (25024, 100, "one-call-config-d"), (200000, 100, "step"), (200000, 100, "one-call")])
+@pytest.mark.parametrize("I,B,path", G_CASES)
 def test_g_step_parity(precision, I, B, path):
     """path "step": ltg_g_step.  "one-call": ltg_g_step_sharded without a communicator (the G step of every large item slab:
     bias + tanh and the tanh derivative folded into operand loaders, weight update and clock slice forked) -- same oracle, same
@@ -126,73 +271,32 @@ def test_g_step_parity(precision, I, B, path):
         pytest.skip("BASELINE configs 3 / 4 run the bf16 decoder path")
     if path.startswith("one-call") and precision != "bf16":
         pytest.skip("ltg_g_step_sharded serves the bf16 decoder path")
-    import torch
-    from ltgan.engine import Pairs, Pipe
-    rng, X, P = _problem(I, B, seed=11 * I + B)
-    hs = (100, 150, 250, 300) if path.endswith("config-d") else (20, 24, 40, 36)
-    D = O.init_discriminator(I, *hs, seed=5)
-    eng = _engine(I, precision, hs=hs, lr=1e-3)
-    eng.set_generator(Hh.gen_to_engine(P))
-    emb, darr = Hh.disc_to_engine(D)
-    eng.set_discriminator(emb, darr)
-    rows, gen, pop = _fake_pairs(rng, X, I)
-    valid = (gen >= 0) & (pop >= 0)
-    cnt = int(valid.sum())
-    dev = eng.device
-    fake = Pairs(torch.from_numpy(pop).to(dev), torch.from_numpy(gen).to(dev), torch.from_numpy(rows).to(dev))
-    cnt_t = torch.tensor([cnt], dtype=torch.int32, device=dev)
-    batch = _upload_batch(eng, X, with_csc=True)
-    acts = eng.new_acts(B)
-    step, dstep, keep, dkeep, anneal, lam = 3, 9, 0.75, 0.7, 0.13, 1.0
-    eng.adam_t = 4  # exercise the shared counter: this update is t = 5
-    if path.startswith("one-call"):
-        assert eng.sharded_step_ok(B)
-        pipe = Pipe(eng, B)
-        go = eng.g_opts(cnt_t, anneal, lam, keep, 1.0, dkeep, step, dstep)
-        loss = eng.g_step_sharded(batch, fake, acts, go, pipe)
-    else:
-        loss = eng.g_step(batch, fake, acts, cnt_t, anneal, lam, keep, 1.0, dkeep, rng_step=step, d_rng_step=dstep)
-    torch.cuda.synchronize()
-    loss = loss.cpu().numpy()
-    # ---- oracle
-    q = precision == "bf16"
-    mask = Hh.dropout_mask_dense(SEED, step, B, I, keep)
-    eps = Hh.eps_dense(SEED, step, B, eng.Z)
-    n = len(rows)
-    dm = Hh.d_masks(SEED, dstep, n, hs[1:], dkeep)
-    gid = np.where(valid, gen, 0)
-    pid = np.where(valid, pop, 0)
-    T = O.d_tower(D, pid, gid, dm, dkeep)
-    sum_y = float((T["y"] * valid).sum())
-    losses, g, F = O.g_loss_and_grads(P, X.toarray(), mask, keep, eps, anneal, lam, rows[valid], gen[valid], cnt, sum_y,
-                                      1.0, np.float64, quant=q)
-    assert abs(loss[4] - sum_y) < 1e-4 * max(1.0, abs(sum_y))
-    assert abs(loss[3] - losses["sum_p"]) < 2e-3 * abs(losses["sum_p"]) + 1e-7
-    for i, k in enumerate(("g_loss", "vae_loss", "gan_loss")):
-        assert abs(loss[i] - losses[k]) < 1e-3 * abs(losses[k]) + 1e-6, k
-    # one TF-Adam update at shared step t=5
-    ad = O.SharedAdam(1e-3)
-    ad.t = 4
-    P64 = {k: np.asarray(v, np.float64) for k, v in P.items()}
-    ad.apply(P64, g, O.G_KEYS)
-    want = Hh.gen_to_engine(P64)
-    want_m = Hh.gen_to_engine({k: ad.m[k] for k in O.G_KEYS})
-    want_v = Hh.gen_to_engine({k: ad.v[k] for k in O.G_KEYS})
-    gtol = 2e-3 if q else 5e-4
-    for i in range(8):
-        m_got = eng.g_m[i].cpu().numpy()
-        v_got = eng.g_v[i].cpu().numpy()
-        p_got = eng.g_p[i].cpu().numpy()
-        assert Hh.rel_err(m_got, want_m[i]) < gtol, ("m", i)
-        assert Hh.rel_err(v_got, want_v[i]) < 2 * gtol, ("v", i)
-        # theta moves by at most lr_t per element; compare the MOVE
-        move_got = p_got - Hh.gen_to_engine(P)[i]
-        move_want = want[i] - np.asarray(Hh.gen_to_engine(P)[i], np.float64)
-        _check_adam_move(move_got, move_want, want_m[i], ad.lr_t(5), ("theta", i))
+    _g_step_case(precision, I, B, path, warm=False)
+
+
+@pytest.mark.parametrize("precision,I,B,path", [("fp32", 1000, 100, "step"), ("bf16", 1000, 100, "step"), ("fp32", 6000, 100, "step"),
+                                                ("bf16", 8200, 100, "step"), ("bf16", 20000, 100, "step"), ("bf16", 25024, 100, "one-call"),
+                                                ("bf16", 25032, 100, "one-call")])
+def test_g_step_adam_quotient_from_warm_moments(precision, I, B, path):
+    """The G step from injected NON-ZERO Adam moments at shared step t = 138 against oracle.SharedAdam (train.py:160-164): every
+    theta move, m and v element-wise -- dense tile epilogues, the streaming weight update, the lazy clock's kernels (rows of W_q0
+    the batch does not touch take a zero-gradient step) all go through the library's one adam_move."""
+    _g_step_case(precision, I, B, path, warm=True)
 
 
 @pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (1, 0), (0, 5), (260, 250)])
 def test_d_step_parity(nr, nf):
+    _d_step_case(nr, nf, warm=False)
+
+
+@pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (260, 250)])
+def test_d_step_adam_quotient_from_warm_moments(nr, nf):
+    """The D step from injected non-zero Adam moments at shared step t = 212 (train.py:160-163): the flat Adam sweep's theta move,
+    m and v element-wise against oracle.SharedAdam."""
+    _d_step_case(nr, nf, warm=True)
+
+
+def _d_step_case(nr, nf, warm):
     import torch
     from ltgan.engine import Pairs
     I = 500
@@ -204,10 +308,6 @@ def test_d_step_parity(nr, nf):
     D["b1"] = rng.normal(0, 0.05, D["b1"].shape).astype(np.float32)
     D["b3"] = rng.normal(0, 0.05, D["b3"].shape).astype(np.float32)
     D["b4"] = rng.normal(0, 0.05, D["b4"].shape).astype(np.float32)
-    eng = _engine(I, "fp32", hs=hs, lr=1e-3)
-    emb, darr = Hh.disc_to_engine(D)
-    eng.set_discriminator(emb, darr)
-    dev = eng.device
 
     def mk(n):
         pop = rng.integers(0, I, n).astype(np.int32)
@@ -219,13 +319,8 @@ def test_d_step_parity(nr, nf):
 
     rp, rn = mk(nr)
     fp, fn = mk(nf)
-    real = Pairs(torch.from_numpy(rp).to(dev), torch.from_numpy(rn).to(dev)) if nr else Pairs(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), n=0)
-    fake = Pairs(torch.from_numpy(fp).to(dev), torch.from_numpy(fn).to(dev)) if nf else Pairs(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), n=0)
     step, keep = 21, 0.7
-    eng.adam_t = 2
-    loss = eng.d_step(real, fake, keep, rng_step=step)
-    torch.cuda.synchronize()
-    loss = float(loss.cpu().numpy()[0])
+    t0 = 211 if warm else 2
     # oracle: masks are indexed by the logical row (real rows first, then fake rows)
     n = nr + nf
     dm = Hh.d_masks(SEED, step, n, hs[1:], keep)
@@ -237,11 +332,38 @@ def test_d_step_parity(nr, nf):
     gr = O.d_tower_backward(D, Tr, [m[:nr] for m in dm], keep, -(1 - Tr["y"]) * vr)
     gf = O.d_tower_backward(D, Tf, [m[nr:] for m in dm], keep, Tf["y"] * vf)
     g = {k: gr[k] + gf[k] for k in gr}
-    assert abs(loss - want_loss) < 1e-4 * max(1.0, abs(want_loss))
     ad = O.SharedAdam(1e-3)
-    ad.t = 2
+    ad.t = t0
+    m0 = v0 = None
+    if warm:
+        m0, v0 = _warm_moments({k: np.asarray(D[k]) for k in O.D_KEYS}, {k: np.asarray(g[k]).reshape(np.asarray(D[k]).shape) for k in O.D_KEYS}, seed=nr + 3)
+        for k in O.D_KEYS:
+            ad.m[k], ad.v[k] = m0[k].astype(np.float64), v0[k].astype(np.float64)
     D64 = {k: np.asarray(v, np.float64) for k, v in D.items()}
     ad.apply(D64, g, O.D_KEYS)
+    # device
+    eng = _engine(I, "fp32", hs=hs, lr=1e-3)
+    emb, darr = Hh.disc_to_engine(D)
+    if warm:
+        eng.set_discriminator(emb, darr, m=[m0[k] for k in O.D_KEYS], v=[v0[k] for k in O.D_KEYS])
+    else:
+        eng.set_discriminator(emb, darr)
+    dev = eng.device
+    real = Pairs(torch.from_numpy(rp).to(dev), torch.from_numpy(rn).to(dev)) if nr else Pairs(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), n=0)
+    fake = Pairs(torch.from_numpy(fp).to(dev), torch.from_numpy(fn).to(dev)) if nf else Pairs(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), n=0)
+    eng.adam_t = t0
+    loss = eng.d_step(real, fake, keep, rng_step=step)
+    torch.cuda.synchronize()
+    loss = float(loss.cpu().numpy()[0])
+    assert abs(loss - want_loss) < 1e-4 * max(1.0, abs(want_loss))
+    if warm:
+        worst = 0.0
+        for i, k in enumerate(O.D_KEYS):
+            sh = np.asarray(D[k]).shape
+            worst = max(worst, _check_warm_adam(eng.d_p[i].cpu().numpy().reshape(sh), np.asarray(D[k]), D64[k], eng.d_m[i].cpu().numpy().reshape(sh), ad.m[k],
+                                                eng.d_v[i].cpu().numpy().reshape(sh), ad.v[k], 1e-4, ("d tensor", k), t0 + 1))
+        print("D step (%d, %d): worst relative error of a theta move from warm moments %.2e" % (nr, nf, worst))
+        return
     for i, k in enumerate(O.D_KEYS):
         m_got = eng.d_m[i].cpu().numpy().reshape(-1)
         assert Hh.rel_err(m_got, ad.m[k].reshape(-1)) < 5e-4, ("m", k)
@@ -323,14 +445,30 @@ def _sampler_problem(rng, B, I, with_zero_probs):
 
 @pytest.mark.parametrize("with_zero_probs", [False, True])
 def test_sampler_matches_oracle(with_zero_probs):
+    I, B = 1000, 100
+    rng = np.random.default_rng(5 + with_zero_probs)
+    _sampler_case(rng, I, B, _sampler_problem(rng, B, I, with_zero_probs), with_zero_probs)
+
+
+def test_sampler_matches_oracle_at_200000_items():
+    """BASELINE config 4's item count with the candidate statistics of the C4-shaped synthetic (ltgan.synthetic: a user's n niche
+    items + max(2n, 10 - n) others drawn by popularity, up to ~2 500 candidates for the heaviest users)."""
+    from ltgan.synthetic import synthetic_index
+    idx, _ = synthetic_index("c4", users=100, seed=31)
+    rng = np.random.default_rng(41)
+    prob = (idx.cand_ptr.astype(np.int32), idx.cand_idx.astype(np.int32), idx.pop_ptr.astype(np.int32), idx.pop_idx.astype(np.int32),
+            idx.n_sample.astype(np.int32), idx.valid_item.astype(np.uint8))
+    assert int(np.diff(prob[0]).max()) > 20
+    _sampler_case(rng, idx.n_items, 100, prob, False)
+
+
+def _sampler_case(rng, I, B, prob, with_zero_probs):
     import ctypes as C
     import torch
     from ltgan import _cabi as cabi
     from ltgan.engine import _ptr
-    I, B = 1000, 100
-    rng = np.random.default_rng(5 + with_zero_probs)
     eng = _engine(I, "fp32")
-    cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, valid = _sampler_problem(rng, B, I, with_zero_probs)
+    cand_ptr, cand_idx, pop_ptr, pop_idx, n_sample, valid = prob
     slot_ptr = np.concatenate([[0], np.cumsum(n_sample)]).astype(np.int32)
     acts = eng.new_acts(B)
     logits = rng.normal(0, 2.0, (B, I)).astype(np.float32)
@@ -389,7 +527,7 @@ def test_sampler_matches_oracle(with_zero_probs):
         assert cnt == total_ok
 
 
-@pytest.mark.parametrize("n,I", [(64, 1000), (33, 257), (5, 4097)])
+@pytest.mark.parametrize("n,I", [(64, 1000), (33, 257), (5, 4097), (8, 20000), (4, 200000)])     # the last two: BASELINE configs 3 / 4
 def test_rank_metrics_match_oracle(n, I):
     import torch
     from ltgan.engine import CsrRows

@@ -34,3 +34,19 @@ def test_direct_rccl_transport_of_the_one_call_step_at_world_size_one():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_worker.py")], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "RCCL_DIRECT_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
+
+
+@pytest.mark.parametrize("workload,users,mode", [("custom:50048", 200, ""), ("c4", 200, ""), ("custom:50048", 200, "wide_fp8")])
+def test_two_ranks_on_two_gpus_over_rccl(workload, users, mode):
+    """The same comparison on a box with at least two GPUs: backend nccl (= RCCL), one GPU per rank, the three exchanges of every
+    G step issued in-stream by RCCL's own entry points (ltgan._rccl.RcclComm; the worker asserts ncclCommCount == 2 and that no
+    device-side wait of the hand-overs gave up).  custom:50048 = two slabs of 25 024 items (what one of eight ranks owns at 200 000);
+    c4 = 100 000 items per rank.  Skipped on single-GPU boxes: RCCL refuses two ranks on one device."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LTGAN_TEST_BACKEND="nccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), "bf16"] + ([mode] if mode else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)      # fresh children: this process never hands its GPU state on
+    assert out.returncode == 0 and "SHARDED_OK" in out.stdout and "transport=rccl-direct" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]

@@ -141,9 +141,29 @@ def test_an_expired_device_side_wait_is_reported_by_the_trainer():
     assert tr.pipe is not None
     tr.epoch()                                   # a clean epoch passes the check
     assert tr.pipe.handover in ("device-words", "events")
-    tr.pipe.sync[2] = 3                          # as if three polls had given up
+    if tr.pipe.handover != "device-words":
+        tr.pipe.sync[2] = 3
+        with pytest.raises(RuntimeError, match="gave up"):
+            tr.epoch()
+        return
+    torch.cuda.synchronize()
+    before = [t.clone() for t in eng.g_p + eng.g_m + eng.g_v]
+    tr.pipe.sync[2] = 3                          # as if three polls had given up: the pipe is poisoned
     with pytest.raises(RuntimeError, match="gave up"):
         tr.epoch()
+    torch.cuda.synchronize()
+    # ... and every kernel of the poisoned phase that writes the generator returned at once: the model is the one from before
+    for k, (x, y) in enumerate(zip(before, eng.g_p + eng.g_m + eng.g_v)):
+        assert torch.equal(x, y), ("generator tensor moved behind a wait that gave up", k)
+    # nothing is read out either: the checkpoint writer and the parameter accessor check the pipes first
+    from ltgan.train import save_checkpoint
+    with pytest.raises(RuntimeError, match="gave up"):
+        save_checkpoint("/tmp/ltgan_never_written.pt", eng, tr, 0)
+    assert not os.path.exists("/tmp/ltgan_never_written.pt")
+    # a failed call leaves no word behind for the next one to wait on
+    tr.pipe.reset()
+    assert tr.pipe.expired_waits() == 0 and tr.pipe.c.seq == 0
+    tr.epoch()
 
 
 @pytest.mark.parametrize("queues,expect", [("1", "events"), ("2", "device-words")])
