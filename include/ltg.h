@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 11
+#define LTG_ABI_VERSION 12
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -58,7 +58,11 @@ typedef struct ltg_config {
      *   bits 0-3   decoder weight-gradient kernel: 1..4 = tile variant 0..3 of the generic kernel, 9 = no streaming kernels
      *   bits 10-12 discriminator tiles: 1 = scalar loaders, 2 = all 64 x 64, 3 = all 128 x 128
      *   bit 13 / 15 / 16  scalar instead of 16-byte loaders: middle layers / embedding gathers / small-item decoder kernels
-     *   bit 9  no fake-tower fork onto the aux stream; bit 17  weight-gradient kernels of the G backward on the aux stream */
+     *   bit 9  no fake-tower fork onto the aux stream;
+     *   bit 14 column-blocked sparse W_q0 gradient; bit 18 the round-1 kernels instead of csrc/ltg_fast.h; bit 19 / 24 fp8 discriminator:
+     *   backward converts on the fly / register-resident forward tiles; bits 21 / 22 softmax statistics from a second pass / fp32 dlogits;
+     *   bit 23 register-resident forward-only towers; bit 25 sparse gradient and Adam as two launches; bits 27-30 = k: the streaming
+     *   weight update with 256 - 8 k workgroups */
     int32_t reserved0;
     /* item shard of this rank: it owns global items [item_lo, item_lo + n_items); n_items_global = 0 means
      * unsharded (n_items_global = n_items, item_lo = 0).  W_q0 / W_p1t / b_p1 and their Adam moments hold
@@ -384,30 +388,40 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  * the stream and reduce through another backend.  comm == NULL: no exchange (one GPU); a communicator of ONE rank still gets its
  * three calls (the single-GPU proxy of a rank's step measures them).
  *
- * Pipeline (ltg_pipe: ONE caller-created side stream, three events and the exchange buffers; the library allocates nothing).
- * One fork per step, behind the dh2 product of step t (the last reader of the W_p1t shadow), puts onto the side stream
- * the Adam update of the local W_p1t / b_p1 rows of step t (HBM-bound, the largest kernel; needs only dlogits and h2): joined
- * (ev_dec1) before dec-0 of step t + 1 overwrites h2 -- it runs beside the rest of step t's backward and the encoder half of
- * step t + 1's forward.  The rotating slice of the lazy Adam clock that step t - 1 owes (rows i = ord (mod q0_period) up to ordinal
- * ord = t - 1) rides in the catch-up launch of call t (one launch over the batch's rows and the slice's rows, both up to ord; a row in
- * both sets goes to whichever workgroup's atomic max on its clock comes first).  LTG_PIPE_SLICE_ON_SIDE: the slice on the side stream in
- * front of the weight update instead (every row of batch t is already at ord, so the slice skips them whatever the rest of step t does
- * to them), joined (ev_slice) at the start of call t + 1, before that batch's catch-up.
+ * Pipeline (ltg_pipe: ONE caller-created side stream, two events and the exchange buffers; the library allocates nothing).
+ * One fork per step, behind the dh2 product of step t (the last reader of the W_p1t shadow), puts onto the side stream the Adam update
+ * of the local W_p1t / b_p1 rows of step t (HBM-bound, the largest kernel; needs only dlogits and h2): it runs beside the rest of
+ * step t's backward and the encoder half of step t + 1's forward.  The rotating slice of the lazy Adam clock that step t - 1 owes (rows
+ * i = ord (mod q0_period) up to ordinal ord = t - 1) runs on the side stream too, between the catch-up of call t and that of call t + 1.
+ *
  * Hand-over between the two streams: a cross-stream event pair costs ~12 us per direction on this hardware and ~6 us of bubble on the
- * recording stream (scripts/micro/sync_cost.hip), so fork and join go through two words of device memory (ltg_pipe.sync) instead: the
- * slab sum behind the dh2 product stores the call's ordinal into word 0 when it starts (stream order: the dh2 product is complete), a
- * one-wave kernel in front of the weight update on the side stream polls for it; a one-wave kernel behind the update stores the ordinal
- * into word 1, and dec-0 of the next call polls for it before it touches h2.  No packet waits on the caller's stream at all.  In this
- * mode the clock slice runs on the side stream as well, between the catch-up of call t (enc-0 opens word 5 when it starts; a one-wave
- * kernel in front of the sweep polls for it) and the catch-up of call t + 1 (which polls word 6, opened by the waiter in front of the
- * weight update when it starts): beside enc-1 / dec-0 instead of on the critical stream (LTG_PIPE_SLICE_IN_TOUCH: in the catch-up launch,
- * as with events).  Every poll
- * is bounded (30 s; a poll that gives up adds 1 to word 2, which the caller checks when it joins the pipe).  LTG_PIPE_EVENTS (or sync == NULL) selects event pairs: stream waits on events recorded by the PREVIOUS call (a
- * never-recorded event does not block).  A pipe is used in ONE mode between two joins, seq increases by 1 per call; the two streams of
- * the device-word mode must be concurrent (ltg_g_pipe_probe).  Before anything
- * else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs ltg_g_pipe_join on the
- * stream that will read them.  Results equal ltg_g_step's / the cut-point sequence's bit for bit (same kernels, same order of
- * additions; the slice only runs later). */
+ * recording stream (scripts/micro/sync_cost.hip), so the streams meet through words of device memory (ltg_pipe.sync; `seq` = the
+ * call's ordinal) -- no packet waits on the caller's stream at all:
+ *   word 0  the dh2 product of call seq is complete (stored by the slab sum when it starts; a one-wave kernel in front of the weight
+ *           update polls for it)
+ *   word 1  the weight update of call seq has READ h2 -- it reads h2 in its prologue only: its workgroups count themselves in word 8
+ *           behind it and the last one stores the ordinal (ragged slabs: stored when the update ends).  dec-0 of call seq + 1 overwrites h2.
+ *   word 7  the weight update of call seq has ENDED (one wave behind it): the streaming forward of call seq + 1 reads the shadow rows
+ *           and the bias it writes
+ *   word 5  enc-0 of call seq has started = the catch-up of the batch's rows is complete (a one-wave kernel in front of the slice polls)
+ *   word 6  the clock slice of call seq has ended (stored by the next kernel of the side stream when it starts): the catch-up of
+ *           call seq + 1 must not meet it on a row
+ *   word 9  dh1 of call seq is complete (stored by the sparse gradient kernel when it starts; a one-wave kernel in front of the Adam
+ *           tail on ltg_pipe.tail_stream polls);  word 10  that tail has ended (one wave behind it): enc-1 of call seq + 1 reads what it updates
+ *   word 2  polls that gave up (each is bounded: 30 s) = the pipe's POISON
+ * Every poll is made by ONE thread: a one-wave kernel of the side stream, or -- on the caller's stream -- the last thread of the kernel
+ * IN FRONT of the one that needs the word (enc-1 for word 1, dec-0 for word 7, enc-0 for word 10, the step's last kernel for word 6): stream order then
+ * gates the consumer whatever its size, and no workgroup of a large launch holds a CU while it waits for a producer that may still
+ * need one.  Once word 2 is non-zero every kernel of the step that writes h2 or the model returns at once, so the model stays what it
+ * was when the wait expired; the caller checks word 2 before it reads the model out (end of a phase, checkpoint) and treats it as fatal.
+ * LTG_PIPE_SLICE_IN_TOUCH keeps the slice in the catch-up launch of call t (one launch over the batch's rows and the slice's rows; a
+ * row in both sets goes to whichever workgroup's atomic max on its clock comes first).  LTG_PIPE_EVENTS (or sync == NULL) selects event
+ * pairs instead of words: stream waits on events recorded by the PREVIOUS call (a never-recorded event does not block), the slice in
+ * the catch-up launch.  A pipe is used in ONE mode between two joins, seq increases by 1 per call; the two streams of the device-word
+ * mode must be concurrent (ltg_g_pipe_probe).  After a call that FAILED the caller synchronises, zeroes the words and restarts seq at 0.
+ * Before anything else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs
+ * ltg_g_pipe_join on the stream that will read them.  Results equal ltg_g_step's / the cut-point sequence's bit for bit (same
+ * kernels, same order of additions; the slice only runs later). */
 #define LTG_NCCL_FLOAT32 7
 #define LTG_NCCL_SUM 0
 typedef struct ltg_comm {
@@ -420,25 +434,27 @@ typedef struct ltg_comm {
 
 typedef struct ltg_pipe {
     ltg_stream side_stream;
-    void* ev_fork; /* hipEvent_t x 3, timing disabled */
+    void* ev_fork; /* hipEvent_t x 2, timing disabled (LTG_PIPE_EVENTS and ltg_g_pipe_join) */
     void* ev_dec1;
-    void* ev_slice;
+    void* ev_tail; /* hipEvent_t, timing disabled: ltg_g_pipe_join's join of tail_stream (NULL: no tail stream) */
     float* h1pre;       /* [n_rows][H]  exchange 1: partial encoder pre-activation, all-reduced in place */
     float* rowpart_all; /* [n_ranks][n_rows][5]  exchange 2: all-gather IN PLACE (this rank writes block `rank`, n_rows = the call's batch) */
     float* dh2;         /* [n_rows][H]  exchange 3: local dh2, all-reduced in place */
     int32_t flags;      /* LTG_PIPE_* measurement switches, 0 = the shipped schedule */
     uint32_t seq;       /* ordinal of this call on this pipe: the caller adds 1 before every ltg_g_step_sharded call (starting at 1) */
-    uint32_t* sync;     /* [16] device words, zeroed once by the caller: the two gates of the device-side hand-over (ABI v11).  NULL: the
-                         * hand-overs are events (ev_fork / ev_dec1), as with LTG_PIPE_EVENTS */
+    uint32_t* sync;     /* [16] device words, zeroed once by the caller: the hand-overs listed above (words 0-2, 5-8; 3-4: ltg_g_pipe_probe).
+                         * NULL: the hand-overs are events (ev_fork / ev_dec1), as with LTG_PIPE_EVENTS */
+    ltg_stream tail_stream; /* optional THIRD stream (ABI v12; device-word mode only): the step's Adam tail -- W_p0, W_q1 and the biases; it needs
+                             * the backward's dh1 only -- runs there beside the sparse W_q0 gradient, the next call's catch-up and enc-0
+                             * (words 9 / 10).  NULL: the tail stays the step's last kernel on the caller's stream */
 } ltg_pipe;
 #define LTG_PIPE_NO_DEC1_FORK 1  /* everything on the caller's stream, in program order */
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
-#define LTG_PIPE_SLICE_ON_SIDE 4 /* the slice step t - 1 owes on the side stream in front of the weight update (joined by ev_slice) instead of
-                                    in the catch-up launch of call t */
 #define LTG_PIPE_SLICE_IN_TOUCH 32 /* with device words: the slice step t - 1 owes in the catch-up launch of call t (as with events) instead of on the
                                       side stream between the catch-up of call t and that of call t + 1 */
 #define LTG_PIPE_EVENTS 16       /* fork and join of the weight update as hipEventRecord / hipStreamWaitEvent pairs instead of device words */
 #define LTG_PIPE_WIDE_GRAD 8     /* the sparse W_q0 gradient in its column-blocked shape (three times the waves) although it runs beside the update */
+#define LTG_PIPE_TAIL_INLINE 64  /* the Adam tail on the caller's stream although the pipe has a tail stream */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
 int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);

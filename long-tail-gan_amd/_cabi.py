@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 11
+LTG_ABI_VERSION = 12
 LTG_Q0_HIST = 1024
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
@@ -90,7 +90,7 @@ class ltg_sample_inputs(C.Structure):
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
 LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
-LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_SLICE_ON_SIDE, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH = 1, 2, 4, 8, 16, 32
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH, LTG_PIPE_TAIL_INLINE = 1, 2, 8, 16, 32, 64
 
 
 class ltg_comm(C.Structure):
@@ -98,8 +98,8 @@ class ltg_comm(C.Structure):
 
 
 class ltg_pipe(C.Structure):
-    _fields_ = [("side_stream", vp), ("ev_fork", vp), ("ev_dec1", vp), ("ev_slice", vp),
-                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("seq", C.c_uint32), ("sync", vp)]
+    _fields_ = [("side_stream", vp), ("ev_fork", vp), ("ev_dec1", vp), ("ev_tail", vp),
+                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("seq", C.c_uint32), ("sync", vp), ("tail_stream", vp)]
 
 
 # every symbol include/ltg.h declares: name -> (restype, argtypes)

@@ -215,9 +215,14 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
                                                       uint64_t seed, uint64_t step, const float* __restrict__ Wq0,
                                                       const float* __restrict__ bq0, float* __restrict__ h1, float* __restrict__ row_scale,
                                                       const float* __restrict__ row_norm2, int item_lo, int Ig, int pre_only,
-                                                      float* __restrict__ xd, int rps, LtgGate started = LTG_NO_GATE) {
+                                                      float* __restrict__ xd, int rps, LtgGate started = LTG_NO_GATE, LtgGate end_wait = LTG_NO_GATE) {
     // started (one-call step, slice on the side stream): opened as soon as this kernel runs -- the catch-up of the batch's rows in front
-    // of it is complete
+    // of it is complete.  end_wait (the Adam tail of the PREVIOUS call on its own stream): enc-1, behind this kernel, reads W_q1 and the
+    // biases that tail updates and overwrites activations it reads -- one more block row (blockIdx.y == gridDim.y - 1) polls for its word
+    if (end_wait.word && blockIdx.y == gridDim.y - 1) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
+        return;
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_set(started);
     // xd (optional, small item slabs): the dense row  xd[b][i] = keep_bi * x_bi / (keep * ||x_b||)  of the operand this
     // layer multiplies -- the backward forms dW_q0 = xd^T . da1 as a dense MFMA product with the very same dropout draw
@@ -484,8 +489,22 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad_rows(int B, int I, int H, 
                                                            const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
                                                            const float* __restrict__ row_scale, const float* __restrict__ da1,
                                                            float* __restrict__ G, int item_lo, int Ig, ltg_gen_state st, AdamC ad, int lazy_ord,
-                                                           const int32_t* __restrict__ uitem, const unsigned* __restrict__ poison = nullptr) {
+                                                           const int32_t* __restrict__ uitem, const unsigned* __restrict__ poison = nullptr,
+                                                           LtgGate started = LTG_NO_GATE, LtgGate end_wait = LTG_NO_GATE, float* __restrict__ lr_slot = nullptr) {
+    // one-call step with the Adam tail on its own stream (ltg_pipe.tail_stream): `started` opens when this kernel runs -- dh1, the kernel
+    // in front of it, is complete, which is all the tail waits for; lr_slot: this step's learning rate goes into the clock's ring HERE (the
+    // next call's catch-up reads it, and the tail that used to write it now runs beside that catch-up); end_wait: this is then the last
+    // kernel of the step on the caller's stream -- one more block at the end of the grid polls for the clock slice's word (see fk_g_tail)
+    const int NG = (int)gridDim.x - (end_wait.word ? 1 : 0);     // groups of gradient rows
+    if (end_wait.word && (int)blockIdx.x == NG) {
+        if (threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
+        return;
+    }
     if (ltg_poisoned(poison)) return;   // (one-call step: a device-side wait of the pipe gave up -- the model is not touched)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (lr_slot) *lr_slot = ad.lr_t;
+        ltg_gate_set(started);
+    }
     constexpr int U = NCB == 1 ? 8 : (NCB == 2 ? 4 : 3);   // entries in flight per wave (x NCB float4 each)
     __shared__ __attribute__((aligned(16))) float4 s_g[G0_NW][NCB * 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -525,17 +544,17 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad_rows(int B, int I, int H, 
     int q0[G0_NW], q1[G0_NW], uit[G0_NW];
 #pragma unroll
     for (int j = 0; j < G0_NW; ++j) {
-        const int u = min(j * (int)gridDim.x + (int)blockIdx.x, nrows - 1);
+        const int u = min(j * NG + (int)blockIdx.x, nrows - 1);
         const int bp = u - nu;
         q0[j] = u < nu ? uptr[u] : min(B, bp * per);
         q1[j] = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
         uit[j] = (uitem && u < nu) ? uitem[u] : -1;
-        if (j * (int)gridDim.x + (int)blockIdx.x >= nrows) q1[j] = q0[j];     // beyond the last row: empty
+        if (j * NG + (int)blockIdx.x >= nrows) q1[j] = q0[j];     // beyond the last row: empty
     }
     // light rows: wave j alone, its W / m / v rows requested before the gather
 #pragma unroll
     for (int j = 0; j < G0_NW; ++j) {
-        const int u = j * (int)gridDim.x + (int)blockIdx.x;
+        const int u = j * NG + (int)blockIdx.x;
         if (j == w && u < nrows && q1[j] - q0[j] <= G0_LIGHT) {
             const bool pre = lazy_ord > 0 && u < nu && uit[j] >= 0;   // wave-uniform
             float4 rp[NCB], rm[NCB], rv[NCB];
@@ -560,7 +579,7 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad_rows(int B, int I, int H, 
     // heavy rows: all eight waves (chain w = entries w, w + 8, ...), one row after the other; chunk k is finished by wave k
 #pragma unroll
     for (int j = 0; j < G0_NW; ++j) {
-        const int u = j * (int)gridDim.x + (int)blockIdx.x;
+        const int u = j * NG + (int)blockIdx.x;
         if (u < nrows && q1[j] - q0[j] > G0_LIGHT) {     // uniform over the workgroup
             float4 acc[NCB];
             enc0_grad_entries<U, NCB>(acc, q0[j] + w, q1[j], G0_NW, u < nu, c4, H4, rowidx, csr_pos, indices, values, drop_keep, keep, seed, step, row_scale,
@@ -841,24 +860,12 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
 }
 
 // Backward stage 2: dw1 / db1 and dw2 / db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), 16 x 32 tiles.
-struct DBwdBC {   // jobs B and C of stage 1 riding in stage 2's launch (n2 = first of their blocks; nB = 0: not in this launch)
-    int n2, nB, h3, ntile;
-    const float *A1, *A3, *G3, *spart, *b4p;
-};
-template <bool WITH_BC>
 __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
-                                                const float* __restrict__ dpre1, float* __restrict__ slab, DBwdBC bc) {
+                                                const float* __restrict__ dpre1, float* __restrict__ slab) {
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (pv.nr >= 0) return;
 #endif
-    __shared__ __attribute__((aligned(16))) float lds[WITH_BC ? (Rg32k::LDS_FLOATS > Rg16x32::LDS_FLOATS ? Rg32k::LDS_FLOATS : Rg16x32::LDS_FLOATS) : Rg16x32::LDS_FLOATS];
-    if constexpr (WITH_BC) {
-        __shared__ float s_ds[D_KCHUNK], s_lr[D_KCHUNK];
-        if ((int)blockIdx.x >= bc.n2) {
-            d_bwd1_jobs_bc(pv, h1 + h2, bc.h3, (int)blockIdx.x - bc.n2, bc.nB, bc.ntile, L, SP, bc.A1, bc.A3, bc.G3, bc.spart, bc.b4p[0], slab, lds, s_ds, s_lr);
-            return;
-        }
-    }
+    __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const int tm = (h0 + 1 + 15) / 16;
     const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
@@ -1218,7 +1225,8 @@ struct TailArgs {
     const float *dlog, *h2, *z, *da2, *h1, *dmlv, *G;
     const float *xd, *da1;        // xd != NULL: job 4 = the dense product xd^T . da1 + Adam (no sparse rows, no slot map)
     const int32_t* slot;
-    int q0_bias;                  // job 4 = only the bias row of the first encoder layer (lazy Adam clock: the item rows were updated by fk_enc0_grad)
+    int q0_bias;                  // job 4 = only the bias row of the first encoder layer (lazy Adam clock: the item rows were updated by fk_enc0_grad);
+                                  // 2: its gradient is summed from da1 here, not read from fk_enc0_grad's partial rows (the tail on its own stream)
     const float* rowout;
     const int32_t* cnt;
     float anneal, lam;
@@ -1270,17 +1278,44 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     }
     if (bid < a.n4 && a.q0_bias) {   // b_q0 from the partial bias rows of fk_enc0_grad + this step's learning rate into the clock's ring
         const int H4 = H >> 2;
-        if (threadIdx.x == 0) st.q0_lr_hist[(st.q0_ord + 1) & (LTG_Q0_HIST - 1)] = ad.lr_t;
+        if (threadIdx.x == 0 && a.q0_bias == 1) st.q0_lr_hist[(st.q0_ord + 1) & (LTG_Q0_HIST - 1)] = ad.lr_t;
         float4* b4 = reinterpret_cast<float4*>(st.p[4]);
         float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
         float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
         const float4* G4 = reinterpret_cast<const float4*>(a.G);
+        const float4* D4 = reinterpret_cast<const float4*>(a.da1);
         for (int c = threadIdx.x; c < H4; c += NT) {
-            float4 g = G4[(size_t)a.nu * H4 + c];
+            float4 g;
+            if (a.q0_bias == 2) {
+                // the tail runs BESIDE the sparse gradient kernel (own stream): the partial bias rows are summed here, in that kernel's
+                // order -- ENC0_BIAS_PARTS parts of `per` batch rows, each a serial sum from zero (its light-row path: per <= G0_LIGHT,
+                // checked by the caller), the parts added in ascending order -- so b_q0 gets the same bits either way
+                const int per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+                g = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int pj = 0; pj < ENC0_BIAS_PARTS; ++pj) {
+                    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int r0 = min(B, pj * per), r1 = min(B, (pj + 1) * per);
+                    // the part's rows all in flight at once (clamped addresses, a row past the end counts with weight 0 -- as in the
+                    // gradient kernel), then the serial sum: a loop of load -> add would be `per` dependent round trips per part
+                    float4 d[G0_LIGHT];
+#pragma unroll
+                    for (int t = 0; t < G0_LIGHT; ++t) d[t] = D4[(size_t)min(r0 + t, B - 1) * H4 + c];
+#pragma unroll
+                    for (int t = 0; t < G0_LIGHT; ++t) {
+                        const float sc = r0 + t < r1 ? 1.f : 0.f;
+                        sp.x = __builtin_fmaf(sc, d[t].x, sp.x); sp.y = __builtin_fmaf(sc, d[t].y, sp.y);
+                        sp.z = __builtin_fmaf(sc, d[t].z, sp.z); sp.w = __builtin_fmaf(sc, d[t].w, sp.w);
+                    }
+                    if (pj == 0) g = sp;
+                    else { g.x += sp.x; g.y += sp.y; g.z += sp.z; g.w += sp.w; }
+                }
+            } else {
+            g = G4[(size_t)a.nu * H4 + c];
 #pragma unroll
             for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
                 const float4 t = G4[(size_t)(a.nu + j) * H4 + c];
                 g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            }
             }
             float4 p = b4[c], mm = mb4[c], vv = vb4[c];
             adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
@@ -1664,8 +1699,13 @@ __global__ __launch_bounds__(NT) void fks_d_l2(int n, int h12, int h3, const flo
 // (BM / 2) x (BN / 2) quarter from there: 64 x 64 tiles move 178 MB for the same product (each operand byte once per workgroup),
 // and three or four 37-KB workgroups per CU hide each other's load latency.  K % 128 == 0.
 //   a_row(r) / b_row(c): start of operand row r / column c of the tile (k-contiguous e4m3), nullptr = all zero.
-template <int BM, int BN, class ARow, class BRow, class EF>
-__device__ __forceinline__ void ltg_sgemm8(int K, ARow a_row, BRow b_row, float scale, EF epi, uint8_t* __restrict__ lds) {
+// The product loop, accumulators left in acc[BM / 32][BN / 32] (C layout of v_mfma_f32_16x16x32_fp8_fp8 per 16 x 16 block).
+// Round 4: TWO K blocks of global loads in flight per workgroup (two register sets of 16-byte pieces; LDS stays double-buffered): a
+// workgroup's stage used to last one L2 / HBM round trip (~1.2 us against 0.1 us of MFMA), 16 of them per 2048-deep tile.  The loop is
+// unrolled by two with static set names, fetches are clamped instead of guarded and a block past the end is stashed as zeros (adds
+// nothing), so the loop has no branch and every s_waitcnt is an exact count.  -DLTG_SG8_SHALLOW builds the one-block-ahead loop.
+template <int BM, int BN, class ARow, class BRow>
+__device__ __forceinline__ void ltg_sgemm8_core(int K, ARow a_row, BRow b_row, ltg_f32x4 (&acc)[BM / 32][BN / 32], uint8_t* __restrict__ lds) {
     constexpr int BK = 128, LDK = BK + 16, TM = BM / 32, TN = BN / 32, RA = BM / 32, RB = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
     const int lrow = tid >> 3, lkc = (tid & 7) * 16;        // loader: rows lrow + 32 j, byte column lkc of the K block
@@ -1686,64 +1726,90 @@ __device__ __forceinline__ void ltg_sgemm8(int K, ARow a_row, BRow b_row, float 
     }
     uint8_t* As = lds;                       // [2][BM][LDK]
     uint8_t* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
-    ltg_f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
     ltg_u32x4 ra[RA], rb[RB];
     // (macros, not lambdas: register arrays captured by reference end up in scratch)
-#define SG8_FETCH(k0)                                                                                      \
+#define SG8_FETCH(k0, XA, XB)                                                                              \
     {                                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const ltg_u32x4*>(ap[j] + (k0)); \
-        _Pragma("unroll") for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const ltg_u32x4*>(bp[j] + (k0)); \
+        const int kf_ = min((k0), K - BK);                                                                 \
+        _Pragma("unroll") for (int j = 0; j < RA; ++j) XA[j] = *reinterpret_cast<const ltg_u32x4*>(ap[j] + kf_); \
+        _Pragma("unroll") for (int j = 0; j < RB; ++j) XB[j] = *reinterpret_cast<const ltg_u32x4*>(bp[j] + kf_); \
     }
-#define SG8_STASH(buf)                                                                                     \
+#define SG8_STASH(buf, XA, XB, kk)                                                                         \
     {                                                                                                      \
+        const unsigned in_ = (kk) < K ? 0xFFFFFFFFu : 0u;                                                  \
         _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                                   \
-            ltg_u32x4 v = ra[j];                                                                           \
-            v[0] &= am[j]; v[1] &= am[j]; v[2] &= am[j]; v[3] &= am[j];                                    \
+            ltg_u32x4 v = XA[j];                                                                           \
+            const unsigned mk = am[j] & in_;                                                               \
+            v[0] &= mk; v[1] &= mk; v[2] &= mk; v[3] &= mk;                                                \
             *reinterpret_cast<ltg_u32x4*>(As + (size_t)((buf) * BM + lrow + 32 * j) * LDK + lkc) = v;      \
         }                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                   \
-            ltg_u32x4 v = rb[j];                                                                           \
-            v[0] &= bm[j]; v[1] &= bm[j]; v[2] &= bm[j]; v[3] &= bm[j];                                    \
+            ltg_u32x4 v = XB[j];                                                                           \
+            const unsigned mk = bm[j] & in_;                                                               \
+            v[0] &= mk; v[1] &= mk; v[2] &= mk; v[3] &= mk;                                                \
             *reinterpret_cast<ltg_u32x4*>(Bs + (size_t)((buf) * BN + lrow + 32 * j) * LDK + lkc) = v;      \
         }                                                                                                  \
     }
-    SG8_FETCH(0)
-    SG8_STASH(0)
+#define SG8_MFMA(buf)                                                                                      \
+    {                                                                                                      \
+        const uint8_t* Aw = As + (size_t)((buf) * BM + wm * (BM / 2) + lr) * LDK + 8 * lq;                 \
+        const uint8_t* Bw = Bs + (size_t)((buf) * BN + wn * (BN / 2) + lr) * LDK + 8 * lq;                 \
+        _Pragma("unroll") for (int ks = 0; ks < BK; ks += 32) {                                            \
+            long af[TM], bf[TN];                                                                           \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(Aw + (size_t)(i * 16) * LDK + ks); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const long*>(Bw + (size_t)(j * 16) * LDK + ks); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i], bf[j], acc[i][j], 0, 0, 0); \
+        }                                                                                                  \
+    }
+    SG8_FETCH(0, ra, rb)
+    SG8_STASH(0, ra, rb, 0)
     __syncthreads();
+#ifdef LTG_SG8_SHALLOW
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = k0 + BK < K;   // uniform
-        if (more) SG8_FETCH(k0 + BK)     // the next block's loads fly under this block's MFMAs
-        const uint8_t* Aw = As + (size_t)(buf * BM + wm * (BM / 2) + lr) * LDK + 8 * lq;
-        const uint8_t* Bw = Bs + (size_t)(buf * BN + wn * (BN / 2) + lr) * LDK + 8 * lq;
-#pragma unroll
-        for (int ks = 0; ks < BK; ks += 32) {
-            long af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(Aw + (size_t)(i * 16) * LDK + ks);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const long*>(Bw + (size_t)(j * 16) * LDK + ks);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) SG8_STASH(buf ^ 1)     // the other buffer: its readers finished before the previous barrier
+        SG8_FETCH(k0 + BK, ra, rb)       // the next block's loads fly under this block's MFMAs
+        SG8_MFMA(buf)
+        SG8_STASH(buf ^ 1, ra, rb, k0 + BK)     // the other buffer: its readers finished before the previous barrier
         __syncthreads();
         buf ^= 1;
     }
+#else
+    ltg_u32x4 ra2[RA], rb2[RB];
+    SG8_FETCH(BK, ra, rb)                // block 1 in flight; block 2 follows inside the loop
+    for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+        SG8_FETCH(k0 + 2 * BK, ra2, rb2)
+        SG8_MFMA(0)                              // block k0
+        SG8_STASH(1, ra, rb, k0 + BK)            // (the other buffer: its readers finished before the previous barrier)
+        __syncthreads();
+        SG8_FETCH(k0 + 3 * BK, ra, rb)
+        SG8_MFMA(1)                              // block k0 + BK (zeros past the end)
+        SG8_STASH(0, ra2, rb2, k0 + 2 * BK)
+        __syncthreads();
+    }
+#endif
+#undef SG8_FETCH
+#undef SG8_STASH
+#undef SG8_MFMA
+}
+
+template <int BM, int BN, class ARow, class BRow, class EF>
+__device__ __forceinline__ void ltg_sgemm8(int K, ARow a_row, BRow b_row, float scale, EF epi, uint8_t* __restrict__ lds) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
+    ltg_f32x4 acc[TM][TN];
+    ltg_sgemm8_core<BM, BN>(K, a_row, b_row, acc, lds);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int x = 0; x < 4; ++x) epi(wm * (BM / 2) + i * 16 + 4 * lq + x, wn * (BN / 2) + j * 16 + lr, acc[i][j][x] * scale);
-#undef SG8_FETCH
-#undef SG8_STASH
 }
 
 // branch layers from e4m3 storage, LDS-staged: blockIdx.x = column tile over BOTH branches (popular -> h1, niche -> h2; XCD x keeps

@@ -32,75 +32,10 @@ struct LtgNoQuad {
 // column c (the MFMA's C layout) -- what a TRANSPOSED byte store wants (four consecutive bytes of one output row).
 template <int BM, int BN, class ARow, class BRow, class EF, class EQ>
 __device__ __forceinline__ void ltg_sgemm8q(int K, ARow a_row, BRow b_row, float scale, EF epi, EQ epiq, uint8_t* __restrict__ lds) {
-    constexpr int BK = 128, LDK = BK + 16, TM = BM / 32, TN = BN / 32, RA = BM / 32, RB = BN / 32;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
-    const int lrow = tid >> 3, lkc = (tid & 7) * 16;
-    const uint8_t* ap[RA];
-    const uint8_t* bp[RB];
-    unsigned am[RA], bm[RB];
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        const uint8_t* q = a_row(lrow + 32 * j);
-        am[j] = q ? 0xFFFFFFFFu : 0u;
-        ap[j] = (q ? q : a_row(-1)) + lkc;
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        const uint8_t* q = b_row(lrow + 32 * j);
-        bm[j] = q ? 0xFFFFFFFFu : 0u;
-        bp[j] = (q ? q : b_row(-1)) + lkc;
-    }
-    uint8_t* As = lds;
-    uint8_t* Bs = lds + 2 * BM * LDK;
+    constexpr int TM = BM / 32, TN = BN / 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
     ltg_f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-    ltg_u32x4 ra[RA], rb[RB];
-#define SG8Q_FETCH(k0)                                                                                     \
-    {                                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const ltg_u32x4*>(ap[j] + (k0)); \
-        _Pragma("unroll") for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const ltg_u32x4*>(bp[j] + (k0)); \
-    }
-#define SG8Q_STASH(buf)                                                                                    \
-    {                                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                                   \
-            ltg_u32x4 v = ra[j];                                                                           \
-            v[0] &= am[j]; v[1] &= am[j]; v[2] &= am[j]; v[3] &= am[j];                                    \
-            *reinterpret_cast<ltg_u32x4*>(As + (size_t)((buf) * BM + lrow + 32 * j) * LDK + lkc) = v;      \
-        }                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                   \
-            ltg_u32x4 v = rb[j];                                                                           \
-            v[0] &= bm[j]; v[1] &= bm[j]; v[2] &= bm[j]; v[3] &= bm[j];                                    \
-            *reinterpret_cast<ltg_u32x4*>(Bs + (size_t)((buf) * BN + lrow + 32 * j) * LDK + lkc) = v;      \
-        }                                                                                                  \
-    }
-    SG8Q_FETCH(0)
-    SG8Q_STASH(0)
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = k0 + BK < K;
-        if (more) SG8Q_FETCH(k0 + BK)
-        const uint8_t* Aw = As + (size_t)(buf * BM + wm * (BM / 2) + lr) * LDK + 8 * lq;
-        const uint8_t* Bw = Bs + (size_t)(buf * BN + wn * (BN / 2) + lr) * LDK + 8 * lq;
-#pragma unroll
-        for (int ks = 0; ks < BK; ks += 32) {
-            long af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(Aw + (size_t)(i * 16) * LDK + ks);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const long*>(Bw + (size_t)(j * 16) * LDK + ks);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) SG8Q_STASH(buf ^ 1)
-        __syncthreads();
-        buf ^= 1;
-    }
+    ltg_sgemm8_core<BM, BN>(K, a_row, b_row, acc, lds);      // (csrc/ltg_fast.h: the product loop both blocks share)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -113,8 +48,6 @@ __device__ __forceinline__ void ltg_sgemm8q(int K, ARow a_row, BRow b_row, float
             }
             epiq(wm * (BM / 2) + i * 16 + 4 * lq, wn * (BN / 2) + j * 16 + lr, v);
         }
-#undef SG8Q_FETCH
-#undef SG8Q_STASH
 }
 
 __device__ __forceinline__ unsigned ltg_pack4_fp8(const float* v, float scale) {

@@ -1696,7 +1696,9 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
 // dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
 template <bool BF16, int VAR, bool V = false, bool D16 = false>
 __global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
-                                                      const float* __restrict__ h2, ltg_gen_state st, AdamC ad, int i_begin) {
+                                                      const float* __restrict__ h2, ltg_gen_state st, AdamC ad, int i_begin,
+                                                      const unsigned* __restrict__ poison = nullptr) {
+    if (ltg_poisoned(poison)) return;   // (the ragged tail of the one-call step's forked weight update)
     // VAR 0: 32x32 tiles, scalar Adam epilogue; 1: 64x128, 2: 64x64, 3: 32x128 tiles with the float4 epilogue
     constexpr bool BIG = VAR != 0;
     constexpr int BM = VAR == 0 ? 32 : (VAR == 3 ? 32 : 64), BN = VAR == 0 ? 32 : (VAR == 2 ? 64 : 128);
@@ -2597,15 +2599,15 @@ void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* 
 // stage 1: enc-0 over this rank's item slab.  pre_only: leave the partial pre-activation in acts->h1.
 void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_fwd_opts* o,
                    const ltg_gen_acts* acts, int pre_only, hipStream_t st, float* xd = nullptr, bool touched = false,
-                   LtgGate started = LTG_NO_GATE) {
+                   LtgGate started = LTG_NO_GATE, LtgGate end_wait = LTG_NO_GATE) {
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc;
     const Probe pr{o->probe, st};
     if (!touched) q0_touch(cfg, gen, bt, st);
     if (fast_on(cfg)) {
         LTG_PROBED(pr, LTG_K_ENC0_FWD,
-                   hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R), dim3(ENC_NT), xd ? (size_t)I * sizeof(float) : 0, st, H, I, bt->indptr,
+                   hipLaunchKernelGGL(fk_enc0_fwd, dim3((H / 4 + 63) / 64, R + (end_wait.word ? 1 : 0)), dim3(ENC_NT), xd ? (size_t)I * sizeof(float) : 0, st, H, I, bt->indptr,
                                       bt->indices, bt->values, o->drop_keep, o->keep_prob, cfg->seed, o->rng_step, gen->p[0], gen->p[4], acts->h1,
-                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd, o->rows_per_step, started));
+                                      acts->row_scale, bt->row_norm2, cfg->item_lo, Ig_of(cfg), pre_only, xd, o->rows_per_step, started, end_wait));
         return;
     }
     LTG_PROBED(pr, LTG_K_ENC0_FWD,
@@ -2912,15 +2914,14 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         const int nA = (((n + 31) / 32) * ((h12 + 31) / 32) + 7) & ~7;      // padded: job B starts on a multiple of 8 (XCD chunk map)
         const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
         const int nC = ks * ((h3 + 2 + 31) / 32);
-        const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-        // jobs B / C (dw3, db3, dw4, db4, d_loss: they need the forward only) ride either beside job A (dpre1) or beside stage 2's
-        // embedding products (tuning-knob bit 5): stage 1 is then the critical product alone
-        const bool bc2 = (cfg->reserved0 & 32) != 0;
-        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(bc2 ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
+        // (Round 4, measured and not kept: jobs B / C -- dw3, db3, dw4, db4, d_loss: they need the forward only -- riding in stage 2's launch
+        // beside the embedding products instead of beside job A, so that stage 1 is the critical product alone: D step 59.5-59.6 ->
+        // 61.3-61.6 us on Askubuntu_Sample, same box, three interleaved rounds; profiles/r4_d_step_floor.txt.  The same file has the
+        // step's launch structure: the five grids with their registers and LDS returning at once take 18 us.)
+        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
                                                         w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab));
-        const DBwdBC bc{n2, nB, h3, ntile, w.A1, w.A3, w.G3, w.spart, disc->p[7]};
-        if (bc2) LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2<true>, dim3(n2 + nB + nC), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab, bc));
-        else LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2<false>, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab, bc));
+        const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
+        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab));
         if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
         else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st);
         return check_launch();
@@ -3110,17 +3111,17 @@ static const int32_t* g_slot_map(const ltg_config* cfg, const ltg_batch* bt, con
 // sparse gradient rows of W_q0 (+ partial bias rows) into w.gq0
 static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts, const Workspace& w,
                         hipStream_t st, const ltg_gen_state* gen = nullptr, const AdamC* ad = nullptr, bool row_waves = true,
-                        const unsigned* poison = nullptr) {   // gen + ad: fused lazy Adam step
+                        const unsigned* poison = nullptr, LtgGate started = LTG_NO_GATE, LtgGate end_wait = LTG_NO_GATE, float* lr_slot = nullptr) {   // gen + ad: fused lazy Adam step
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, nu = bt->n_unique;
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_GRAD);
     if (fast_on(cfg) && row_waves) {   // one wave per row over all columns: a third of the waves (see fk_enc0_grad_rows)
         const int ncb = (H / 4 + 63) / 64;
-        const dim3 g((nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW);
+        const dim3 g((nu + ENC0_BIAS_PARTS + G0_NW - 1) / G0_NW + (end_wait.word ? 1 : 0));
 #define LTG_G0_ROWS(N)                                                                                                                                   \
     hipLaunchKernelGGL(fk_enc0_grad_rows<N>, g, dim3(G0_NT), 0, st, B, I, H, nu, bt->uptr, bt->rowidx, bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, \
                        o->fwd.keep_prob, cfg->seed, o->fwd.rng_step, acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg), gen ? *gen : ltg_gen_state{},     \
-                       ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem, poison)
+                       ad ? *ad : AdamC{}, (gen && ad) ? gen->q0_ord + 1 : 0, bt->uitem, poison, started, end_wait, lr_slot)
         if (ncb == 1) LTG_G0_ROWS(1);
         else if (ncb == 2) LTG_G0_ROWS(2);
         else LTG_G0_ROWS(3);
@@ -3141,7 +3142,7 @@ static void g_enc0_grad(const ltg_config* cfg, const ltg_batch* bt, const ltg_g_
 //   stage 1: dh1 tiles + W_p0        stage 2: W_q1, W_q0 (dense product when slot == NULL, else sweep + sparse rows), scalars
 static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o, const ltg_gen_acts* acts,
                    const Workspace& w, const AdamC& ad, const int32_t* slot, bool with_dec1, float* loss_out, hipStream_t st,
-                   bool no_q0 = false, bool q0_bias = false, const unsigned* poison = nullptr, LtgGate end_wait = LTG_NO_GATE) {
+                   bool no_q0 = false, bool q0_bias = false, const unsigned* poison = nullptr, LtgGate end_wait = LTG_NO_GATE, bool bias_from_da1 = false) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     TailArgs a;
     a.B = B; a.I = I; a.H = H; a.Z = Z; a.nu = bt->n_unique;
@@ -3163,7 +3164,7 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
     a.q0_bias = 0;
     if ((stage == 2 || all) && q0_bias) {   // lazy Adam clock: fk_enc0_grad updated the item rows, one block finishes the bias row
         a.n4 = 1;
-        a.q0_bias = 1;
+        a.q0_bias = bias_from_da1 ? 2 : 1;
     }
     a.n5 = ((stage == 2 || all) && with_dec1) ? 1 : 0;
     a.Wp0 = gen->p[2]; a.Wq1 = gen->p[1]; a.mulv = acts->mulv; a.eps = o->fwd.eps; a.is_training = o->fwd.is_training;
@@ -3233,30 +3234,17 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
     const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
-    // Everything on `st` by default.  Measured alternatives: (a) small item slabs, the three weight-gradient + Adam kernels on
-    // the caller's aux stream beside the critical path da2 -> dz -> dh1 -> sweep of W_q0 (each released by a re-recorded
-    // ev_fork after the last READER of the weights it updates has been enqueued on `st`): paid while the kernels of the chain
-    // took 15-25 us each, costs 3 us per step now that they take 6-18 us (the event pairs cost more than the overlap saves;
-    // still selectable with tuning-knob bit 17); (b) I = 200 000, the two HBM sweeps side by side: they only contend;
-    // (c) I = 200 000, the chain of short kernels beside the first sweep: no overlap at all -- the persistent sweep holds
-    // every CU (232 VGPRs x 8 waves + 106 KB LDS per CU), the chain's workgroups are only placed when it drains.
-    const bool have_aux = o->aux_stream && o->ev_fork && o->ev_join && I < 8192 && (cfg->reserved0 & 131072) != 0;
-    const bool small_mode = have_aux;
+    // Everything on `st` unless the lazy clock's chain runs beside the weight update (below).  (Measured and removed: small item slabs,
+    // the three weight-gradient + Adam kernels on the aux stream beside da2 -> dz -> dh1 -> sweep -- the event pairs cost more than the
+    // overlap saves once the chain's kernels take 6-18 us; I = 200 000, the two HBM sweeps side by side: they only contend.)
     hipStream_t aux = (hipStream_t)o->aux_stream;
-    hipEvent_t evf = (hipEvent_t)o->ev_fork, evj = (hipEvent_t)o->ev_join;
-    hipStream_t s_dw = small_mode ? aux : st;      // dW_p1t + Adam
-    hipStream_t s_wg = have_aux ? aux : st;        // the two middle-layer weight-gradient + Adam kernels
-    hipStream_t s_chain = st;                      // dz, dh1, sparse W_q0 gradient, sweep of W_q0
-    auto release_aux = [&]() {
-        (void)hipEventRecord(evf, st);
-        (void)hipStreamWaitEvent(aux, evf, 0);
-    };
+    hipEvent_t evf = (hipEvent_t)o->ev_fork;
+    hipStream_t s_dw = st;
     if (!da2_ready && !only_dec1) {
         const int n = B * H;
         const int gx = (n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024;
         hipLaunchKernelGGL(k_da2, dim3(gx), dim3(NT), 0, st, n, 1, dh2, acts->h2, w.da2);  // da2 = dh2 * (1 - h2^2)
     }
-    if (have_aux) release_aux();  // dlog, h2, da2 and the dh2 products with the old W_p1t are all enqueued
     // persistent workgroups of the streaming decoder weight update (see launch_dw).  Slabs below 65 536 items: 160 -- the rest of the
     // step runs beside the update, and what a kernel of that chain costs there is mostly how many CUs the update leaves it (round 4,
     // same box, per-rank proxy at 25 024 items: 196 workgroups 173.3-174.1 us per step, 160: 170.1-170.5, 128: 184, 96: 205;
@@ -3279,7 +3267,8 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
                 if (dw_groups > 0) gmax = dw_groups;
                 hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, hd);
                 if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
-                    hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32);
+                    hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32,
+                                       hd.poison);
             } else {
                 hipLaunchKernelGGL(k_dec1_bwd_adam_stream<false>, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
                 if (I % 32)
@@ -3295,7 +3284,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         else hipLaunchKernelGGL((k_dec1_bwd_adam<true, 3>), grid2(H + 1, I, 128, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         prs.after(LTG_K_DEC1_BWD_ADAM);
     };
-    if ((o->fake_done & G_AUX_SWEEP) && q0_lazy(cfg, gen) && mid_fast(cfg, B) && !only_dec1 && (cfg->reserved0 & (1 << 26)) == 0) {
+    if ((o->fake_done & G_AUX_SWEEP) && q0_lazy(cfg, gen) && mid_fast(cfg, B) && !only_dec1) {
         // ltg_g_step, large item slab, lazy Adam clock of W_q0.  The decoder weight update (HBM-bound, the largest kernel of the
         // step) needs only dlog and h2; everything else that is left -- dz -> dh1 -> sparse W_q0 gradient -> the other Adam
         // updates -> the clock's step and its rotating slice -- needs only da2.  The two run side by side: the weight update on
@@ -3316,7 +3305,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         return check_launch();
     }
     if ((o->fake_done & G_AUX_SWEEP) && q0_lazy(cfg, gen)) {
-        // (tuning-knob bit 26) only the rotating slice on the aux stream, eligible together with the decoder weight update
+        // (batches the middle-layer fast path does not serve) only the rotating slice on the aux stream, eligible together with the decoder weight update
         (void)hipEventRecord(evf, st);
         (void)hipStreamWaitEvent(aux, evf, 0);
         if (!o->dec1_done) launch_dw();
@@ -3331,37 +3320,32 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         g_chain(cfg, gen, bt, o, acts, w, ad, slot, false, nullptr, st, lazy);
         return check_launch();
     }
-    const Probe pc{o->probe, s_chain}, pw{o->probe, s_wg};
+    const Probe pc{o->probe, st};
     pc.before(LTG_K_DZ);
 #define LTG_V2(KERNEL, ...)                                       \
     do {                                                          \
         if (vz) hipLaunchKernelGGL(KERNEL<true>, __VA_ARGS__);    \
         else hipLaunchKernelGGL(KERNEL<false>, __VA_ARGS__);      \
     } while (0)
-    // (BK = 256 tiles: dz -7 %, dh1 -5 % on their own, but the 66 KB of LDS per workgroup crowd out the kernels of the aux
-    // stream -- the whole G step got 2-3 % slower; measured, not kept)
-    LTG_V2(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, s_chain, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
+    LTG_V2(k_dz, grid2(Z, B, 32, 32), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps, o->fwd.is_training,
            o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv);
     pc.after(LTG_K_DZ);
-    if (small_mode) release_aux();  // dz (the reader of the old W_p0) is enqueued
-    pw.before(LTG_K_WGRAD_P0);
-    LTG_V2(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, s_wg, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
+    pc.before(LTG_K_WGRAD_P0);
+    LTG_V2(k_wgrad_adam, grid2(H, Z + 1, 32, 32), dim3(NT), 0, st, B, Z, H, acts->z, w.da2, gen->p[2], gen->m[2], gen->v[2],
            gen->p[6], gen->m[6], gen->v[6], ad);
-    pw.after(LTG_K_WGRAD_P0);
+    pc.after(LTG_K_WGRAD_P0);
     pc.before(LTG_K_DH1);
-    LTG_V2(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, s_chain, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
+    LTG_V2(k_dh1, grid2(H, B, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1);
     pc.after(LTG_K_DH1);
-    if (small_mode) release_aux();  // dh1 (the reader of the old W_q1) is enqueued
-    pw.before(LTG_K_WGRAD_Q1);
-    LTG_V2(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, s_wg, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
+    pc.before(LTG_K_WGRAD_Q1);
+    LTG_V2(k_wgrad_adam, grid2(2 * Z, H + 1, 32, 32), dim3(NT), 0, st, B, H, 2 * Z, acts->h1, w.dmlv, gen->p[1], gen->m[1],
            gen->v[1], gen->p[5], gen->m[5], gen->v[5], ad);
 #undef LTG_V2
-    pw.after(LTG_K_WGRAD_Q1);
-    if (small_mode) (void)hipEventRecord(evj, aux);
+    pc.after(LTG_K_WGRAD_Q1);
     const int nu = bt->n_unique;
     const Probe pe{o->probe, st};
     pe.before(LTG_K_ENC0_BWD_ADAM);
-    hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), s_chain, B, I, H, nu, bt->uptr, bt->rowidx,
+    hipLaunchKernelGGL(k_enc0_grad, dim3(nu + ENC0_BIAS_PARTS), dim3(NT), (size_t)4 * H * sizeof(float), st, B, I, H, nu, bt->uptr, bt->rowidx,
                        bt->csr_pos, bt->indices, bt->values, o->fwd.drop_keep, o->fwd.keep_prob, cfg->seed, o->fwd.rng_step,
                        acts->row_scale, w.da1, w.gq0, cfg->item_lo, Ig_of(cfg));
     if (q0_lazy(cfg, gen)) q0_lazy_update(cfg, gen, bt, o, w, ad, st);
@@ -3378,7 +3362,6 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         hipLaunchKernelGGL(k_enc0_bwd_adam, dim3((unsigned)gx), dim3(NT), 0, st, I, H, nu, slot, w.gq0, *gen, ad);
     }
     pe.after(LTG_K_ENC0_BWD_ADAM);
-    if (small_mode) (void)hipStreamWaitEvent(st, evj, 0);  // join: the caller's stream again orders everything
     return check_launch();
 }
 
@@ -3559,28 +3542,36 @@ int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32
 int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream) {
     clear_errors();
     if (!pipe || !pipe->sync || !pipe->side_stream) return LTG_EINVAL;
-    hipStream_t st = (hipStream_t)stream, sd = (hipStream_t)pipe->side_stream;
-    unsigned zero[2] = {0u, 0u}, got[2] = {0u, 0u};
-    if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
-    if (hipMemcpy(pipe->sync + 3, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return LTG_ELAUNCH;
+    hipStream_t st = (hipStream_t)stream;
     // a waiter on the side stream FIRST, then its producer on `stream`: with one hardware queue under both, the producer cannot start
-    // before the waiter has given up (5 ms)
-    hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pipe->sync + 3, 1u, pipe->sync + 4, 5});
-    hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, st, LtgGate{pipe->sync + 3, 1u, nullptr, 0});
-    if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
-    if (hipMemcpy(got, pipe->sync + 3, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) return LTG_ELAUNCH;
-    if (check_launch() != LTG_OK) return LTG_ELAUNCH;
-    return (got[0] == 1u && got[1] == 0u) ? 1 : 0;
+    // before the waiter has given up (5 ms).  The same for the tail stream when the pipe has one.
+    for (int which = 0; which < 2; ++which) {
+        hipStream_t sd = (hipStream_t)(which == 0 ? pipe->side_stream : pipe->tail_stream);
+        if (!sd) continue;
+        unsigned zero[2] = {0u, 0u}, got[2] = {0u, 0u};
+        if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
+        if (hipMemcpy(pipe->sync + 3, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return LTG_ELAUNCH;
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pipe->sync + 3, 1u, pipe->sync + 4, 5});
+        hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, st, LtgGate{pipe->sync + 3, 1u, nullptr, 0});
+        if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
+        if (hipMemcpy(got, pipe->sync + 3, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) return LTG_ELAUNCH;
+        if (check_launch() != LTG_OK) return LTG_ELAUNCH;
+        if (!(got[0] == 1u && got[1] == 0u)) return 0;
+    }
+    return 1;
 }
 
 int ltg_g_pipe_join(const ltg_pipe* pipe, ltg_stream stream) {
     clear_errors();
-    if (!pipe || !pipe->ev_dec1 || !pipe->ev_slice || !pipe->side_stream) return LTG_EINVAL;
+    if (!pipe || !pipe->ev_dec1 || !pipe->side_stream) return LTG_EINVAL;
     if (pipe->sync && (pipe->flags & LTG_PIPE_EVENTS) == 0) {   // gates: nothing was recorded per call -- everything on the side stream so far
         if (hipEventRecord((hipEvent_t)pipe->ev_dec1, (hipStream_t)pipe->side_stream) != hipSuccess) return LTG_ELAUNCH;
     }
     if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_dec1, 0) != hipSuccess) return LTG_ELAUNCH;
-    if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_slice, 0) != hipSuccess) return LTG_ELAUNCH;
+    if (pipe->tail_stream && pipe->ev_tail) {   // the Adam tail of the last call (its own stream in the device-word mode)
+        if (hipEventRecord((hipEvent_t)pipe->ev_tail, (hipStream_t)pipe->tail_stream) != hipSuccess) return LTG_ELAUNCH;
+        if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)pipe->ev_tail, 0) != hipSuccess) return LTG_ELAUNCH;
+    }
     return LTG_OK;
 }
 
@@ -3592,13 +3583,13 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     if (!bt->uptr || !bt->rowidx || !bt->csr_pos || !o->cnt || !fake->row || fake->n < 0) return LTG_EINVAL;
     if (bt->n_unique < 0 || (size_t)bt->n_unique > gq0_rows(cfg, bt->n_rows)) return LTG_EINVAL;
     if (!ltg_g_step_sharded_ok(cfg, gen, bt->n_rows)) return LTG_EINVAL;
-    if (!pp->side_stream || !pp->ev_fork || !pp->ev_dec1 || !pp->ev_slice || !pp->h1pre || !pp->rowpart_all || !pp->dh2) return LTG_EINVAL;
+    if (!pp->side_stream || !pp->ev_fork || !pp->ev_dec1 || !pp->h1pre || !pp->rowpart_all || !pp->dh2) return LTG_EINVAL;
     const int R = comm ? comm->n_ranks : 1, rank = comm ? comm->rank : 0;
     if (R < 1 || rank < 0 || rank >= R || (comm && (!comm->all_reduce || !comm->all_gather))) return LTG_EINVAL;
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim, nf = fake->n;
     if (ltg_workspace_bytes(cfg, B, nf) > ws_bytes) return LTG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream, sd = (hipStream_t)pp->side_stream;
-    hipEvent_t ev_fork = (hipEvent_t)pp->ev_fork, ev_dec1 = (hipEvent_t)pp->ev_dec1, ev_slice = (hipEvent_t)pp->ev_slice;
+    hipEvent_t ev_fork = (hipEvent_t)pp->ev_fork, ev_dec1 = (hipEvent_t)pp->ev_dec1;
     const bool fork_dec1 = (pp->flags & LTG_PIPE_NO_DEC1_FORK) == 0;
     // the lazy clock's slice of the previous step: in this call's catch-up launch (default), on the side stream, or at the end of its own step
     const bool defer_slice = fork_dec1 && (pp->flags & LTG_PIPE_NO_SLICE_FORK) == 0;
@@ -3607,7 +3598,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // with device words the slice runs on the side stream between this call's catch-up and the next one's (two more words), beside
     // enc-1 / dec-0 instead of inside the catch-up launch on the critical stream
     const bool side_slice = gates && defer_slice && (pp->flags & LTG_PIPE_SLICE_IN_TOUCH) == 0;
-    const bool fork_slice = defer_slice && !gates && (pp->flags & LTG_PIPE_SLICE_ON_SIDE) != 0, merge_slice = defer_slice && !fork_slice && !side_slice;
+    const bool merge_slice = defer_slice && !side_slice;   // (events, or LTG_PIPE_SLICE_IN_TOUCH: the slice rides in the catch-up launch)
     Workspace w = carve(cfg, B, nf, (char*)ws);
     if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
     const Probe pr{o->probe, st};
@@ -3625,11 +3616,18 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     //   2  waits that gave up = the pipe's POISON: every kernel of the step that writes h2 or the model returns at once when it is set
     // Every poll is made by ONE thread, either a one-wave kernel of the side stream or the last thread of the kernel in front of the
     // one that needs the gate: no workgroup of a large launch ever holds a CU while it waits for a producer that still needs one.
+    //   9  dh1 of call seq is complete (stored by the sparse gradient kernel when it starts; one wave in front of the Adam tail on the
+    //      tail stream polls for it);  10  the tail of call seq has ended (one wave behind it) -- polled by the last thread of the next
+    //      call's enc-0, in front of enc-1, which reads what the tail updates
     const unsigned* poison = (fork_dec1 && pp->sync && (pp->flags & LTG_PIPE_EVENTS) == 0) ? pp->sync + 2 : nullptr;
+    // the Adam tail (W_p0, W_q1, the biases: it needs dh1's outputs only) on its OWN stream beside the sparse gradient kernel, the next
+    // call's catch-up and enc-0; needs <= G0_LIGHT batch rows per partial bias row (its bias job then re-sums them in the same order)
+    hipStream_t stl = (hipStream_t)pp->tail_stream;
+    const bool tail_own = gates && side_slice && stl && pp->ev_tail && (pp->flags & (LTG_PIPE_TAIL_INLINE | LTG_PIPE_WIDE_GRAD)) == 0 &&
+                          (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS <= G0_LIGHT;
 #define LTG_HIP(x) do { if ((x) != hipSuccess) return LTG_ELAUNCH; } while (0)
 #define LTG_COMM(x) do { if ((x) != 0) return LTG_ELAUNCH; } while (0)
     // ---- the clock slice forked by the PREVIOUS call is done (it must not meet the catch-up below on a row); the rows this batch reads
-    if (fork_slice) LTG_HIP(hipStreamWaitEvent(st, ev_slice, 0));
     const int qP = gen->q0_period;
     if (merge_slice && gen->q0_ord > 0 && gen->q0_ord % qP < I) {
         const int start = gen->q0_ord % qP, ns = (I - start + qP - 1) / qP;
@@ -3649,7 +3647,8 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     {
         ltg_gen_acts a1 = *acts;
         a1.h1 = pp->h1pre;
-        fwd_stage_enc(cfg, gen, bt, &o->fwd, &a1, 1, st, nullptr, true, side_slice ? LtgGate{pp->sync + 5, pp->seq, nullptr, 0} : LTG_NO_GATE);
+        fwd_stage_enc(cfg, gen, bt, &o->fwd, &a1, 1, st, nullptr, true, side_slice ? LtgGate{pp->sync + 5, pp->seq, nullptr, 0} : LTG_NO_GATE,
+                      tail_own ? LtgGate{pp->sync + 10, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE);
     }
     if (side_slice) {
         const int start = gen->q0_ord % qP;
@@ -3707,12 +3706,6 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
             LTG_HIP(hipEventRecord(ev_fork, st));
             LTG_HIP(hipStreamWaitEvent(sd, ev_fork, 0));
             sdw = sd;
-            if (fork_slice) {
-                const int start = gen->q0_ord % qP;
-                if (gen->q0_ord > 0 && start < I)
-                    hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1));
-                LTG_HIP(hipEventRecord(ev_slice, sd));
-            }
         }
         // (a ragged slab's last I % 32 rows go through the generic tile kernel behind the streaming one, and that reads h2 throughout:
         // word 1 then opens with word 7)
@@ -3732,9 +3725,17 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz_dh2, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, pp->dh2, acts->h2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv, w.da2));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-    g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, (pp->flags & LTG_PIPE_WIDE_GRAD) == 0, poison);
-    g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true, poison,
-           side_slice ? LtgGate{pp->sync + 6, pp->seq, pp->sync + 2, 0} : LTG_NO_GATE);
+    const LtgGate slice_done = side_slice ? LtgGate{pp->sync + 6, pp->seq, pp->sync + 2, 0} : LTG_NO_GATE;
+    if (tail_own) {
+        g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, true, poison, LtgGate{pp->sync + 9, pp->seq, nullptr, 0}, slice_done,
+                    gen->q0_lr_hist + ((gen->q0_ord + 1) & (LTG_Q0_HIST - 1)));
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, stl, LtgGate{pp->sync + 9, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
+        g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, stl, true, true, poison, LTG_NO_GATE, true);
+        hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, stl, LtgGate{pp->sync + 10, pp->seq, nullptr, 0}, LTG_NO_GATE);
+    } else {
+        g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, (pp->flags & LTG_PIPE_WIDE_GRAD) == 0, poison);
+        g_jobs(-1, cfg, gen, bt, o, acts, w, ad, nullptr, false, nullptr, st, true, true, poison, slice_done);
+    }
     if (!defer_slice) {   // the slice of THIS step at its end, in program order (the cut-point schedule)
         const int ord = gen->q0_ord + 1, start = ord % qP;
         if (start < I) hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, st, I, H, start, qP, ord, *gen, make_adam(cfg, 1));

@@ -123,14 +123,17 @@ class Pipe:
         from ._hip import EventPair
         dev = engine.device
         self.side_stream = torch.cuda.Stream(dev)
-        self._ev = (EventPair(timing=False), EventPair(timing=False))     # (fork, dec1), (slice, -)
+        # the Adam tail's own stream (device-word hand-over only; LTGAN_TAIL_STREAM=0: the tail stays on the caller's stream)
+        self.tail_stream = torch.cuda.Stream(dev) if os.environ.get("LTGAN_TAIL_STREAM", "1") != "0" else None
+        self._ev = (EventPair(timing=False), EventPair(timing=False))     # (fork, dec1), (tail, -)
         f = dict(dtype=torch.float32, device=dev)
         self.h1pre = torch.zeros(rows, engine.H, **f)
         self.rowpart_all = torch.zeros(n_ranks * rows * 5, **f)
         self.dh2 = torch.zeros(rows, engine.H, **f)
         self.sync = torch.zeros(16, dtype=torch.int32, device=dev)        # words of the device-side hand-overs; [2] = waits that gave up = the pipe's poison
         self.c = cabi.ltg_pipe(self.side_stream.cuda_stream, self._ev[0].start, self._ev[0].stop, self._ev[1].start, _ptr(self.h1pre),
-                               _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0, _ptr(self.sync))
+                               _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0, _ptr(self.sync),
+                               self.tail_stream.cuda_stream if self.tail_stream is not None else None)
         self.probed_for = None      # the caller's stream the side stream was last tested against (Engine._pipe_ready)
         self.handover = None        # "device-words" | "events"
         engine._pipes.add(self)     # Engine.check_pipes(): nothing reads the model out behind a wait that gave up
@@ -138,6 +141,10 @@ class Pipe:
     def new_side_stream(self):
         self.side_stream = torch.cuda.Stream(self.sync.device)
         self.c.side_stream = self.side_stream.cuda_stream
+
+    def new_tail_stream(self, drop=False):
+        self.tail_stream = None if drop else torch.cuda.Stream(self.sync.device)
+        self.c.tail_stream = self.tail_stream.cuda_stream if self.tail_stream is not None else None
 
     def buffers(self):
         return [self.h1pre, self.rowpart_all, self.dh2]
@@ -440,9 +447,10 @@ class Engine:
     def g_flush(self):
         """every deferred zero-gradient Adam step of W_q0, all rows: before W_q0 / its moments are read outside a forward"""
         if self.lazy_q0 and self._q0_dirty:
+            self.check_pipes()                                       # (end of a G phase / before the model is read out: one host sync.  BEFORE the
+                                                                     # flush: behind a wait that gave up the clock's ordinals are not to be trusted)
             cabi.check(self.lib.ltg_g_flush(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_g_flush")
             self._q0_dirty = False
-            self.check_pipes()                                       # (end of a G phase / before the model is read out: one host sync)
             # every row is current: restart the ordinals (the int32 clock never grows without bound; stream order keeps the
             # memset behind the flush kernel)
             self.q0_last.zero_()
@@ -507,16 +515,30 @@ class Engine:
             pipe.handover = "events"
         else:
             pipe.handover = "events"
-            for _ in range(6):
+
+            def probe():
                 ok = self.lib.ltg_g_pipe_probe(C.byref(pipe.c), st) if hasattr(self.lib, "ltg_g_pipe_probe") else 0   # (an older build under LTG_AB_COMPAT)
                 if ok < 0:
                     cabi.check(ok, "ltg_g_pipe_probe")
-                if ok == 1:
+                return ok == 1
+            tail = pipe.c.tail_stream
+            pipe.c.tail_stream = None                # the side stream first ...
+            for _ in range(6):
+                if probe():
                     pipe.handover = "device-words"
                     break
                 pipe.new_side_stream()
             if pipe.handover == "events":
                 pipe.c.flags |= cabi.LTG_PIPE_EVENTS
+                pipe.new_tail_stream(drop=True)
+            elif tail:                               # ... then the tail's own stream: a third concurrent queue, or the tail stays on the caller's stream
+                pipe.c.tail_stream = tail
+                for k in range(6):
+                    if probe():
+                        break
+                    pipe.new_tail_stream(drop=(k == 5))
+                if pipe.tail_stream is not None:
+                    pipe.handover = "device-words + tail stream"
         pipe.probed_for = st
 
     def pipe_join(self, pipe):
