@@ -258,7 +258,7 @@ class KernelProfiler:
         else:
             ach, peak, unit, bound = fl / (avg * 1e-3) / 1e12, peak_f / 1e12, "TFLOP/s", "mfma"
         traffic = None
-        for fn in (() if self.eng.sharded else ("r3c_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):   # (the passes measured the UNSHARDED kernel sizes)   # PMC-derived HBM bytes per launch of this kernel on this workload,
+        for fn in (() if self.eng.sharded else ("r4_pmc_traffic.json", "r3c_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):   # (the passes measured the UNSHARDED kernel sizes)   # PMC-derived HBM bytes per launch of this kernel on this workload,
             try:                                                       # measured offline (profiles/README.md); newest round first
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     traffic = json.load(f)["workloads"][self.a.workload][name]["traffic_bytes"]

@@ -1225,8 +1225,7 @@ struct TailArgs {
     const float *dlog, *h2, *z, *da2, *h1, *dmlv, *G;
     const float *xd, *da1;        // xd != NULL: job 4 = the dense product xd^T . da1 + Adam (no sparse rows, no slot map)
     const int32_t* slot;
-    int q0_bias;                  // job 4 = only the bias row of the first encoder layer (lazy Adam clock: the item rows were updated by fk_enc0_grad);
-                                  // 2: its gradient is summed from da1 here, not read from fk_enc0_grad's partial rows (the tail on its own stream)
+    int q0_bias;                  // job 4 = only the bias row of the first encoder layer (lazy Adam clock: the item rows were updated by fk_enc0_grad)
     const float* rowout;
     const int32_t* cnt;
     float anneal, lam;
@@ -1278,44 +1277,17 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     }
     if (bid < a.n4 && a.q0_bias) {   // b_q0 from the partial bias rows of fk_enc0_grad + this step's learning rate into the clock's ring
         const int H4 = H >> 2;
-        if (threadIdx.x == 0 && a.q0_bias == 1) st.q0_lr_hist[(st.q0_ord + 1) & (LTG_Q0_HIST - 1)] = ad.lr_t;
+        if (threadIdx.x == 0) st.q0_lr_hist[(st.q0_ord + 1) & (LTG_Q0_HIST - 1)] = ad.lr_t;
         float4* b4 = reinterpret_cast<float4*>(st.p[4]);
         float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
         float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
         const float4* G4 = reinterpret_cast<const float4*>(a.G);
-        const float4* D4 = reinterpret_cast<const float4*>(a.da1);
         for (int c = threadIdx.x; c < H4; c += NT) {
-            float4 g;
-            if (a.q0_bias == 2) {
-                // the tail runs BESIDE the sparse gradient kernel (own stream): the partial bias rows are summed here, in that kernel's
-                // order -- ENC0_BIAS_PARTS parts of `per` batch rows, each a serial sum from zero (its light-row path: per <= G0_LIGHT,
-                // checked by the caller), the parts added in ascending order -- so b_q0 gets the same bits either way
-                const int per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
-                g = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int pj = 0; pj < ENC0_BIAS_PARTS; ++pj) {
-                    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int r0 = min(B, pj * per), r1 = min(B, (pj + 1) * per);
-                    // the part's rows all in flight at once (clamped addresses, a row past the end counts with weight 0 -- as in the
-                    // gradient kernel), then the serial sum: a loop of load -> add would be `per` dependent round trips per part
-                    float4 d[G0_LIGHT];
-#pragma unroll
-                    for (int t = 0; t < G0_LIGHT; ++t) d[t] = D4[(size_t)min(r0 + t, B - 1) * H4 + c];
-#pragma unroll
-                    for (int t = 0; t < G0_LIGHT; ++t) {
-                        const float sc = r0 + t < r1 ? 1.f : 0.f;
-                        sp.x = __builtin_fmaf(sc, d[t].x, sp.x); sp.y = __builtin_fmaf(sc, d[t].y, sp.y);
-                        sp.z = __builtin_fmaf(sc, d[t].z, sp.z); sp.w = __builtin_fmaf(sc, d[t].w, sp.w);
-                    }
-                    if (pj == 0) g = sp;
-                    else { g.x += sp.x; g.y += sp.y; g.z += sp.z; g.w += sp.w; }
-                }
-            } else {
-            g = G4[(size_t)a.nu * H4 + c];
+            float4 g = G4[(size_t)a.nu * H4 + c];
 #pragma unroll
             for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
                 const float4 t = G4[(size_t)(a.nu + j) * H4 + c];
                 g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-            }
             }
             float4 p = b4[c], mm = mb4[c], vv = vb4[c];
             adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
@@ -1391,6 +1363,47 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
 
 // ---------------------------------------------------------------------------------------------------------------------
 // wide discriminator, LTG_PREC_FP8 (BASELINE config 5): forward layers fed from OPERAND-FORMAT storage
+// b_q0's Adam step with its gradient summed from da1 HERE, for the one-call step whose Adam tail runs on its own stream beside the
+// sparse gradient kernel (fk_g_tail's bias job reads that kernel's partial bias rows; a kernel of its own so that its 16 rows in flight do
+// not set fk_g_tail's register count).  Same bits as the partial rows: ENC0_BIAS_PARTS parts of `per` batch rows, each a serial sum from
+// zero in the gradient kernel's light-row order (per <= G0_LIGHT, checked by the caller; a row past the end counts with weight 0), the
+// parts added in ascending order.
+__global__ __launch_bounds__(NT) void fk_q0_bias_from_da1(int B, int H, const float* __restrict__ da1, ltg_gen_state st, AdamC ad,
+                                                          const unsigned* __restrict__ poison) {
+    if (ltg_poisoned(poison)) return;
+    const int H4 = H >> 2, per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+    float4* b4 = reinterpret_cast<float4*>(st.p[4]);
+    float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
+    float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
+    const float4* D4 = reinterpret_cast<const float4*>(da1);
+    for (int c = blockIdx.x * NT + threadIdx.x; c < H4; c += gridDim.x * NT) {
+        float4 p = b4[c], mm = mb4[c], vv = vb4[c];
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pj = 0; pj < ENC0_BIAS_PARTS; ++pj) {
+            float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r0 = min(B, pj * per), r1 = min(B, (pj + 1) * per);
+            float4 d[G0_LIGHT];
+#pragma unroll
+            for (int t = 0; t < G0_LIGHT; ++t) d[t] = D4[(size_t)min(r0 + t, B - 1) * H4 + c];
+#pragma unroll
+            for (int t = 0; t < G0_LIGHT; ++t) {
+                const float sc = r0 + t < r1 ? 1.f : 0.f;
+                sp.x = __builtin_fmaf(sc, d[t].x, sp.x); sp.y = __builtin_fmaf(sc, d[t].y, sp.y);
+                sp.z = __builtin_fmaf(sc, d[t].z, sp.z); sp.w = __builtin_fmaf(sc, d[t].w, sp.w);
+            }
+            if (pj == 0) g = sp;
+            else { g.x += sp.x; g.y += sp.y; g.z += sp.z; g.w += sp.w; }
+        }
+        adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
+        adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
+        adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
+        adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
+        b4[c] = p;
+        mb4[c] = mm;
+        vb4[c] = vv;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The fp8 mode of round 1 read every operand as fp32 and converted it on the way into LDS: 4 bytes moved per 1-byte operand,
 // bound by L2 traffic (d_l1: 101 us for 11.5 GFLOP).  Here the operands LIVE in e4m3, k-contiguous: the frozen embedding table

@@ -176,6 +176,7 @@ class Engine:
         self.lib = cabi.load()
         import weakref
         self._pipes = weakref.WeakSet()                              # the Pipe objects created for this engine (check_pipes)
+        self.check_on_flush = True                                   # False: a probe that times the host's issue rate (scripts/host_bound_probe.py)
         self._pinned = None                                          # pin_stream()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
@@ -447,7 +448,8 @@ class Engine:
     def g_flush(self):
         """every deferred zero-gradient Adam step of W_q0, all rows: before W_q0 / its moments are read outside a forward"""
         if self.lazy_q0 and self._q0_dirty:
-            self.check_pipes()                                       # (end of a G phase / before the model is read out: one host sync.  BEFORE the
+            if self.check_on_flush:
+                self.check_pipes()                                   # (end of a G phase / before the model is read out: one host sync.  BEFORE the
                                                                      # flush: behind a wait that gave up the clock's ordinals are not to be trusted)
             cabi.check(self.lib.ltg_g_flush(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_g_flush")
             self._q0_dirty = False

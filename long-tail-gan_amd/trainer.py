@@ -160,8 +160,10 @@ class Trainer:
                 eng.pipe_join(self.pipe)    # the forked weight update and clock slice of the last step
             eng.q0_defer = False
             if ok:
+                dirty = eng._q0_dirty
                 eng.g_flush()               # (+ Engine.check_pipes: one host sync per phase; raises if a hand-over wait gave up)
-                self.check_pipe()           # (a phase without a dirty clock still checks)
+                if not dirty and eng.check_on_flush:
+                    self.check_pipe()       # (a phase without a dirty clock still checks)
         finally:
             eng.q0_defer = False
             eng.pin_stream(False)

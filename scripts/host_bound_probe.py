@@ -16,6 +16,7 @@ idx, _ = synthetic_index("custom:%d" % items, users=1600)
 dev = "cuda:0"
 for kind in ("single", "sharded"):
     eng = Engine(idx.n_items, device=dev)
+    eng.check_on_flush = False          # (the end-of-phase poison check synchronises the host: it would hide the issue rate this probe is after)
     data = DeviceData(idx, 100, dev, item_lo=0, item_hi=idx.n_items) if kind == "sharded" else DeviceData(idx, 100, dev)
     tr = (ShardedTrainer if kind == "sharded" else Trainer)(eng, data, num_sub_epochs=1)
     for _ in range(3):
