@@ -408,8 +408,6 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  *           call seq + 1 must not meet it on a row
  *   word 9  dh1 of call seq is complete (stored by the sparse gradient kernel when it starts; a one-wave kernel in front of the Adam
  *           tail on ltg_pipe.tail_stream polls);  word 10  that tail has ended (one wave behind it): enc-1 of call seq + 1 reads what it updates
- *   word 11 (slabs of 65 536 items or more) the first of the weight update's TWO launches over the halves of the slab has ended: the
- *           streaming forward of call seq + 1 runs as two launches too, the first beside the update's second half, the second behind word 7
  *   word 2  polls that gave up (each is bounded: 30 s) = the pipe's POISON
  * Every poll is made by ONE thread: a one-wave kernel of the side stream, or -- on the caller's stream -- the last thread of the kernel
  * IN FRONT of the one that needs the word (enc-1 for word 1, dec-0 for word 7, enc-0 for word 10, the step's last kernel for word 6): stream order then
@@ -458,7 +456,6 @@ typedef struct ltg_pipe {
 #define LTG_PIPE_WIDE_GRAD 8     /* the sparse W_q0 gradient in its column-blocked shape (three times the waves) although it runs beside the update */
 #define LTG_PIPE_TAIL_INLINE 64  /* the Adam tail on the caller's stream although the pipe has a tail stream */
 #define LTG_PIPE_TAIL_OWN 128    /* ... on the tail stream also WITH a communicator (default there: inline -- measured, see ltg_g_step_sharded) */
-#define LTG_PIPE_NO_SPLIT (1 << 17) /* slabs of 65 536 items or more: weight update and streaming forward as ONE launch each (default: two, word 11) */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
 int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);

@@ -90,7 +90,7 @@ class ltg_sample_inputs(C.Structure):
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
 LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
-LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH, LTG_PIPE_TAIL_INLINE, LTG_PIPE_TAIL_OWN, LTG_PIPE_NO_SPLIT = 1, 2, 8, 16, 32, 64, 128, 1 << 17
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH, LTG_PIPE_TAIL_INLINE, LTG_PIPE_TAIL_OWN = 1, 2, 8, 16, 32, 64, 128
 
 
 class ltg_comm(C.Structure):

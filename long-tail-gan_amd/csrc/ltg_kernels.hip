@@ -413,21 +413,10 @@ __device__ __forceinline__ void st_stash_w(unsigned short* __restrict__ Wl, cons
 // PF: W tiles of HBM loads in flight per workgroup (register sets of 20 VGPRs each).  Measured at 200 000 items (85 us): PF = 3
 // changes nothing; without the logits stores 69 us, with 1 of the 19 MFMA / LDS-read rounds 66 us, with neither 56 us (the
 // 243 MB of W at 4.3 TB/s): loads, product and stores add up rather than overlap -- one lock-step workgroup per CU.
-// Tile range (the one-call step of a very large slab runs this kernel in TWO launches, tiles [0, T0) beside the second half of the
-// previous step's weight update, [T0, ntiles) behind it): workgroup g always walks the tiles g, g + G, ... of the WHOLE slab (T0 is a
-// multiple of G), a launch that is not the last leaves every lane's running (max, sum exp) in `carry` ([G][512][8] floats) and the next
-// one resumes from it -- the statistics, and so everything downstream, keep the bits of the single launch.  end_wait: see fk_dec0.
-struct StRange {
-    int tile_begin, tile_end;   // tile_end <= 0: all tiles
-    float* carry;               // NULL: no carry in or out
-    int carry_in, carry_out;
-    LtgGate end_wait;
-};
-#define LTG_ST_ALL StRange{0, 0, nullptr, 0, 0, LTG_NO_GATE}
 template <bool STATS, int PF = 2>
 __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, const float* __restrict__ h2,
                                                            const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
-                                                           float* __restrict__ logits, float* __restrict__ stat, StRange rg = LTG_ST_ALL) {
+                                                           float* __restrict__ logits, float* __restrict__ stat) {
     extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup).  Rows >= M MIRROR row M - 1:
@@ -449,18 +438,10 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
             af[ks] = __builtin_bit_cast(ltg_bf16x8, t);
         }
     }
-    const int ntiles = rg.tile_end > 0 ? rg.tile_end : (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
+    const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
     float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-    float* cy = rg.carry ? rg.carry + ((size_t)blockIdx.x * ST_NT + tid) * 8 : nullptr;
-    if (STATS && cy && rg.carry_in) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            rm[q] = cy[q];
-            rs[q] = cy[4 + q];
-        }
-    }
     StW r0, r1, r2;
-    int t = rg.tile_begin + blockIdx.x, cur = 0;
+    int t = blockIdx.x, cur = 0;
     if (t < ntiles) {
         st_fetch_w(Wb, I, t * ST_BN, r0);
         st_stash_w(st_lds, r0);
@@ -521,15 +502,6 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
         }
     }
 #undef ST_STEP
-    if (blockIdx.x == 0 && tid == 0) ltg_gate_wait_tail(rg.end_wait);
-    if (STATS && cy && rg.carry_out) {   // (not the last launch over this slab: the statistics are finished by the one that is)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            cy[q] = rm[q];
-            cy[4 + q] = rs[q];
-        }
-        return;
-    }
     if constexpr (STATS) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -673,8 +645,7 @@ struct LtgH2Done {
 template <bool D16>
 __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, int H, const float* __restrict__ dlog,
                                                                 const float* __restrict__ h2, ltg_gen_state st, AdamC ad,
-                                                                LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr}, int tile_begin = 0,
-                                                                int tile_end = 0) {
+                                                                LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr}) {
     __shared__ __attribute__((aligned(16))) unsigned short Dl[2][128 * DW_LDD];
     __shared__ __attribute__((aligned(16))) float Cs[8 * 32 * DW_LDC];   // per-wave [32][80] gradient blocks
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
@@ -734,9 +705,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
             __hip_atomic_store(hd.word, hd.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // full tiles only: the host sends the ragged tail (I % 32 rows) to k_dec1_bwd_adam.  [tile_begin, tile_end): this launch's share of
-    // the slab (a very large slab's update runs as two launches so that the next forward's first half can follow the first one)
-    const int ntiles = tile_end > 0 ? tile_end : I / 32, G = gridDim.x;
+    const int ntiles = I / 32, G = gridDim.x;   // full tiles only: the host sends the ragged tail (I % 32 rows) to k_dec1_bwd_adam
     // dlog tile loader: thread -> (row b = tid / 4, 8 items at 8 * (tid % 4))
     const int lb = tid >> 2, lseg = tid & 3;
     const float* lrow = dlog + (size_t)min(lb, B - 1) * I;
@@ -761,7 +730,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
         }
         *reinterpret_cast<ltg_u32x4*>(D + lb * DW_LDD + 8 * lseg) = p;
     };
-    int t = tile_begin + blockIdx.x, cur = 0;
+    int t = blockIdx.x, cur = 0;
     float4 x0, x1;
     if (t < ntiles) {
         fetch(t, x0, x1);
@@ -2469,17 +2438,10 @@ inline int dh2_kchunk(int I) {
 // without knowing nnz, so the table bound is used: one heavy user in a short batch can never overflow it.
 inline size_t gq0_rows(const ltg_config* cfg, int /*max_rows*/) { return (size_t)cfg->n_items; }
 
-// a slab's tiles cut for the two-launch forward / weight update of the one-call step (0: one launch): at a multiple of the forward's
-// 256 workgroups, slabs of 65 536 items or more
-inline int st_split_tile(int I) {
-    const int ntl = I / 32;
-    return ntl >= 2048 ? (ntl / 2) / 256 * 256 : 0;
-}
-
 constexpr int RD_MAXI = 4096;   // "small item slab": a row of logits fits the registers of one workgroup (ltg_fast.h)
 struct Workspace {
     // generator backward
-    float *rowpart, *segpart, *carry, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
+    float *rowpart, *segpart, *nb, *Pb, *scal, *dlog, *part, *dh2, *da2, *dmlv, *da1, *gq0;
     int32_t* slotmap;   // [I] item -> gradient row of the current batch (only used when the caller passes no slot[] cache)
     // discriminator
     float *A1, *A3, *y, *ds, *lrow, *dpre1, *dpre3, *slab;
@@ -2512,7 +2474,6 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
     }
     w.rowpart = take(R * RP);
     w.segpart = take(segpart_floats(I, R));
-    w.carry = take(st_split_tile(cfg->n_items) > 0 ? (size_t)256 * ST_NT * 8 : 1);   // running softmax statistics between the two forward launches
     w.nb = take(R);
     w.Pb = take(R);
     w.scal = take(16);
@@ -2666,13 +2627,12 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 // (Measured and not kept, round 3: the same loop as TWO independent 4-wave workgroups per CU -- half the batch rows each, 2 x 77 KB of
 // LDS, 244 VGPRs, bit-identical outputs -- so that one half's loads overlap the other's MFMAs and stores: 110.4 vs 107.9 us per launch
 // at 200 000 items on one box, min 81.8 vs 78.6; whole step 968-970 vs 965-968 us.  The serialisation is not inside the workgroup.)
-int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int R, const ltg_gen_acts* acts, float* stat, hipStream_t st,
-                           StRange rg = LTG_ST_ALL) {
+int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int R, const ltg_gen_acts* acts, float* stat, hipStream_t st) {
     const int I = cfg->n_items, H = cfg->h_enc;
     const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
     const size_t lds = (size_t)2 * ST_BN * ST_LDW * 2;
-    if (stat) hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat, rg);
-    else hipLaunchKernelGGL(k_dec1_fwd_stream<false>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, (float*)nullptr, rg);
+    if (stat) hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat);
+    else hipLaunchKernelGGL(k_dec1_fwd_stream<false>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, (float*)nullptr);
     return G;
 }
 
@@ -3276,8 +3236,7 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
 
 static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_g_opts* o,
                             const ltg_gen_acts* acts, const float* dh2, const Workspace& w, hipStream_t st, bool da2_ready = false,
-                            bool only_dec1 = false, int dw_groups = 0, LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr},
-                            int dw_tile_begin = 0, int dw_tile_end = 0) {   // [begin, end): this launch's tiles of the streaming update (end 0 = all + ragged tail)
+                            bool only_dec1 = false, int dw_groups = 0, LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr}) {
     const int B = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
@@ -3304,8 +3263,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         prs.before(LTG_K_DEC1_BWD_ADAM);
         const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
         if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->reserved0 & 15) == 0) {
-            const int ntl = (dw_tile_end > 0 ? dw_tile_end : I / 32) - dw_tile_begin;   // tiles of this launch
-            const bool last_part = dw_tile_end <= 0 || dw_tile_end >= I / 32;
+            const int ntl = I / 32;
             if (dlog16_ok(cfg, gen, B)) {   // (the producer, g_stage_bwd_dec, stored dlog as bf16 under the same predicate)
                 // persistent workgroups: 224 = 28 per XCD (measured 657 us at 200 000 items; 256: 678, 240: 669, 192: 671) -- and 32 CUs
                 // stay free for whatever runs beside it.  Tuning-knob bits 27-30 = k: 256 - 8 k instead.
@@ -3315,10 +3273,9 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
                 // 224 or with 196 workgroups -- 60 CUs left to the chain and the collective running beside it)
                 if (!gk && ntl > gmax) gmax = (ntl + (ntl + gmax - 1) / gmax - 1) / ((ntl + gmax - 1) / gmax);
                 if (dw_groups > 0) gmax = dw_groups;
-                hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, hd, dw_tile_begin,
-                                   dw_tile_end > 0 ? dw_tile_end : 0);
-                if ((I % 32) && last_part)   // ragged tail: the generic tile kernel on the last I % 32 item rows
-                    hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I % 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, (I / 32) * 32,
+                hipLaunchKernelGGL(k_dec1_bwd_adam_stream<true>, dim3(ntl < gmax ? ntl : gmax), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, hd);
+                if (I % 32)   // ragged tail: the generic tile kernel on the last I % 32 item rows
+                    hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2, false, true>), grid2(H + 1, I - ntl * 32, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, ntl * 32,
                                        hd.poison);
             } else {
                 hipLaunchKernelGGL(k_dec1_bwd_adam_stream<false>, dim3(ntl < 256 ? ntl : 256), dim3(ST_NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad);
@@ -3667,8 +3624,6 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     //   2  waits that gave up = the pipe's POISON: every kernel of the step that writes h2 or the model returns at once when it is set
     // Every poll is made by ONE thread, either a one-wave kernel of the side stream or the last thread of the kernel in front of the
     // one that needs the gate: no workgroup of a large launch ever holds a CU while it waits for a producer that still needs one.
-    //  11  (slabs of 65 536 items or more) the FIRST of the weight update's two launches of call seq has ended -- polled by the last thread
-    //      of the next call's dec-0, in front of the first of the streaming forward's two launches; word 7 then gates the second
     //   9  dh1 of call seq is complete (stored by the sparse gradient kernel when it starts; one wave in front of the Adam tail on the
     //      tail stream polls for it);  10  the tail of call seq has ended (one wave behind it) -- polled by the last thread of the next
     //      call's enc-0, in front of enc-1, which reads what the tail updates
@@ -3720,21 +3675,16 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // (dec-0 overwrites h2, which the previous step's weight update reads in its prologue: enc-1's last thread polled for word 1 -- or,
     // with events, the stream waits for the whole update; the streaming forward behind dec-0 needs the update's END: word 7)
     if (fork_dec1 && !gates) LTG_HIP(hipStreamWaitEvent(st, ev_dec1, 0));
-    // Slabs of 65 536 items or more (device words): the weight update runs as TWO launches over the halves of the slab (word 11 between
-    // them), and so does the streaming forward -- its first half beside the update's second, its second behind the update's end.  The
-    // update is the step's longest piece there (0.5 ms at 200 000 items) and the forward used to wait for all of it.
-    const int T0 = (gates && (pp->flags & LTG_PIPE_NO_SPLIT) == 0) ? st_split_tile(I) : 0;
+    // (Round 4, measured and removed: slabs of 65 536 items or more with the weight update AND the streaming forward as two launches each
+    // over the halves of the slab, the forward's first half beside the update's second -- bit-identical through carried per-lane softmax
+    // statistics, but slower: 777-813 against 753-792 us per step at 200 000 items, same box.  Beside the update the forward's half takes
+    // 290 us instead of 44 and the update 30 us longer: the step is HBM-bound, overlapping two bandwidth-bound kernels moves no byte
+    // less.  profiles/r4_ab_c4_two_launch_split.txt, r4_c4_timeline_two_launch_split.txt.)
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
-                                                  acts->h2, gates ? LtgGate{pp->sync + (T0 > 0 ? 11 : 7), pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE, poison));
+                                                  acts->h2, gates ? LtgGate{pp->sync + 7, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE, poison));
     {
         int G = 0;
-        pr.before(LTG_K_DEC1_FWD);
-        if (T0 > 0) {
-            launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st, StRange{0, T0, w.carry, 0, 1, LtgGate{pp->sync + 7, pp->seq - 1u, pp->sync + 2, 0}});
-            G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st, StRange{T0, 0, w.carry, 1, 0, LTG_NO_GATE});
-        } else
-            G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st);
-        pr.after(LTG_K_DEC1_FWD);
+        LTG_PROBED(pr, LTG_K_DEC1_FWD, G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st));
         g_row_partial(cfg, bt, nf > 0 ? fake : nullptr, acts, rowpart, st, w.segpart, nullptr, G);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_ROWPART, LTG_COMM(comm->all_gather(rowpart, pp->rowpart_all, (size_t)B * RP, LTG_NCCL_FLOAT32, comm->comm, stream)));
@@ -3778,14 +3728,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         // word 1 then opens with word 7)
         const bool h2_early = gates && (I % 32) == 0;
         const LtgH2Done hd_last = h2_early ? LtgH2Done{pp->sync + 8, pp->sync + 1, pp->seq, poison} : LtgH2Done{nullptr, nullptr, 0u, poison};
-        int rc;
-        if (T0 > 0) {   // two launches; every one of them reads h2 in its prologue: the hand-over of h2 belongs to the last
-            rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups, LtgH2Done{nullptr, nullptr, 0u, poison}, 0, T0);
-            if (rc != LTG_OK) return rc;
-            hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 11, pp->seq, nullptr, 0}, LTG_NO_GATE);
-            rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups, hd_last, T0, I / 32);
-        } else
-            rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups, hd_last);
+        const int rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups, hd_last);
         if (rc != LTG_OK) return rc;
         if (gates) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 7, pp->seq, nullptr, 0},
                                       h2_early ? LTG_NO_GATE : LtgGate{pp->sync + 1, pp->seq, nullptr, 0});

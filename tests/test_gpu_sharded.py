@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("workload,users,precision,mode", [("custom:1000", 250, "fp32", ""), ("ml20m", 200, "fp32", ""), ("ml20m", 200, "bf16", ""),
                                                            ("custom:1000", 250, "fp32", "dsplit"), ("ml20m", 200, "bf16", "wide_fp8"),
                                                            ("ml20m", 200, "bf16", "cutpoints"), ("c4", 200, "bf16", ""),
-                                                           ("ml20m", 200, "bf16", "wide_fp8_full")])
+                                                           ("ml20m", 200, "bf16", "wide_fp8_full"), ("ml20m", 200, "bf16", "tail_own")])
 def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mode):
     """mode "dsplit": the discriminator's pair rows are split over the two ranks too (ltg_d_grad -> gradient all-reduce ->
     ltg_d_apply) -- same d_loss trajectory and weights as the unsharded step.  mode "wide_fp8": BASELINE config 5's shape inside
@@ -21,8 +21,12 @@ def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mo
     over item slabs large enough for the streaming decoder kernels and the lazy Adam clock of W_q0; "wide_fp8_full": the same with
     config 5's full sizes (2048, 1024, 512, 256).  bf16 slabs of 8192 items or more run the G step as ONE call with the exchanges
     issued from inside it (ltg_g_step_sharded; here through host callbacks over gloo); "cutpoints": the five-call sequence with
-    torch.distributed collectives instead.  ("c4", 200 users): BASELINE config 4's 200 000 items, 100 000 per rank."""
+    torch.distributed collectives instead.  ("c4", 200 users): BASELINE config 4's 200 000 items, 100 000 per rank.  "tail_own": the Adam tail on its own stream although the step has a communicator
+    (LTG_PIPE_TAIL_OWN; the default with a communicator keeps it on the caller's stream)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "tail_own":
+        env["LTGAN_PIPE_FLAGS"] = "128"
+        mode = ""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29577", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), precision] + ([mode] if mode else [])
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
