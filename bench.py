@@ -128,6 +128,7 @@ class KernelProfiler:
         n = sh["n"]
         P = h0 * h1 + h1 + h0 * h2 + h2 + h12 * h3 + h3 + h3 + 1
         ks = (n + 255) // 256
+        d_forked = bool(getattr(e, "_dfork", None) is not None and e._dfork.ok)
         stream = self.a.precision == "bf16" and I >= 8192 and I % 8 == 0 and B <= 128     # stream_ok() of csrc/ltg_kernels.hip
         if stream:
             kchunk = max(128, -(-(-(-I // 256)) // 32) * 32)  # dh2_stream_chunk()
@@ -143,8 +144,11 @@ class KernelProfiler:
             "dec1_fwd": (2 * B * H * I, wread + 4 * (I + B * H + B * I)),
             "d_l1": (2 * n * h0 * h12, 4 * (2 * n * h0 + h0 * h12 + n * h12)),
             "d_l2": (2 * n * h12 * h3, 4 * (n * h12 + h12 * h3 + n * h3)),
-            "d_bwd1": (2 * n * h3 * h12 + 2 * n * (h12 + 1) * h3 + 2 * n * h3,
-                       4 * (n * h3 + h12 * h3 + 2 * n * h12 + n * h3 + ks * (h12 * h3 + 2 * h3 + 1))),
+            # (with the step's fork -- Engine.d_fork, ltg_d_opts.aux_stream -- the launch on the step's own stream is job A alone:
+            # dpre1 = ((ds G3) . w3^T) * dact(A1); jobs B / C run in a second launch of the same kernel on the aux stream)
+            "d_bwd1": ((2 * n * h3 * h12, 4 * (n * h3 + h12 * h3 + 2 * n * h12)) if d_forked else
+                       (2 * n * h3 * h12 + 2 * n * (h12 + 1) * h3 + 2 * n * h3,
+                        4 * (n * h3 + h12 * h3 + 2 * n * h12 + n * h3 + ks * (h12 * h3 + 2 * h3 + 1)))),
             "d_bwd2": (2 * n * (h0 + 1) * h12, 4 * (2 * n * h0 + n * h12 + ks * ((h0 + 1) * h12))),
             "d_adam": (0, P * (4 * ks + 24)),
             "dh2": (2 * B * I * H, wread + 4 * (B * I + nsplit * B * H)),

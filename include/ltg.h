@@ -227,6 +227,15 @@ typedef struct ltg_d_opts {
     const uint8_t* drop_real[3]; /* optional keep flags [n_real][h1], [n_real][h2], [n_real][h3] */
     const uint8_t* drop_fake[3];
     const ltg_probe* probe; /* optional */
+    /* optional (ABI v12; ltg_d_step at the fp32 default sizes): jobs B / C of the backward's first stage -- dw3, db3, dw4, db4, d_loss: they
+     * need the forward only -- run on `aux_stream` beside the critical chain job A -> stage 2, handed over through device words like
+     * ltg_pipe's: sync = 4 zeroed words owned by the caller (0: forward complete, 1: jobs B / C ended, 2: polls that gave up = poison:
+     * the Adam sweep then returns at once and the caller must treat it as fatal), seq = the call's ordinal on these words (+ 1 per
+     * call, starting at 1).  The two streams must run concurrently (ltg_g_pipe_probe tests a pair).  NULL: one stream, five launches. */
+    ltg_stream aux_stream;
+    uint32_t* sync;
+    uint32_t seq;
+    int32_t reserved0;
 } ltg_d_opts;
 
 typedef struct ltg_g_opts {

@@ -71,7 +71,7 @@ class ltg_pairs(C.Structure):
 
 class ltg_d_opts(C.Structure):
     _fields_ = [("keep_prob", C.c_float), ("adam_t", C.c_int32), ("rng_step", C.c_uint64), ("drop_real", vp * 3),
-                ("drop_fake", vp * 3), ("probe", C.POINTER(ltg_probe))]
+                ("drop_fake", vp * 3), ("probe", C.POINTER(ltg_probe)), ("aux_stream", vp), ("sync", vp), ("seq", C.c_uint32), ("reserved0", C.c_int32)]
 
 
 class ltg_g_opts(C.Structure):

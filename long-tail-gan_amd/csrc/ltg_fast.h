@@ -721,7 +721,10 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
                                                 const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
                                                 const float* __restrict__ spart, const float* __restrict__ b4p,
                                                 const float* __restrict__ w3, float keep, float* __restrict__ dpre1,
-                                                float* __restrict__ slab) {
+                                                float* __restrict__ slab, LtgGate started = LTG_NO_GATE) {
+    // started (the step's jobs B / C on the caller's aux stream, ltg_d_opts.aux_stream): opened when this launch -- job A alone then --
+    // runs: the forward in front of it is complete, which is all jobs B / C wait for
+    if (blockIdx.x == 0 && threadIdx.x == 0) ltg_gate_set(started);
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (pv.nr >= 0) return;
 #endif
@@ -861,7 +864,13 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
 
 // Backward stage 2: dw1 / db1 and dw2 / db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), 16 x 32 tiles.
 __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
-                                                const float* __restrict__ dpre1, float* __restrict__ slab) {
+                                                const float* __restrict__ dpre1, float* __restrict__ slab, LtgGate end_wait = LTG_NO_GATE) {
+    // end_wait (jobs B / C of stage 1 on the aux stream): the Adam sweep behind this kernel adds THEIR slab entries too -- one more block
+    // at the end of the grid polls for their word
+    if (end_wait.word && blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
+        return;
+    }
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (pv.nr >= 0) return;
 #endif
@@ -926,7 +935,9 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
 // One Adam sweep over the discriminator's trainable tensors laid out back to back (train.py:163): g = sum of the chunk
 // slabs; 16 bytes per lane.  Block 0 also adds up d_loss (train.py:142) from slot P of the slabs.
 __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const float* __restrict__ slab, float* __restrict__ p,
-                                                float* __restrict__ m, float* __restrict__ v, AdamC ad, float* __restrict__ loss_out) {
+                                                float* __restrict__ m, float* __restrict__ v, AdamC ad, float* __restrict__ loss_out,
+                                                const unsigned* __restrict__ poison = nullptr) {
+    if (ltg_poisoned(poison)) return;   // (the wait for the aux stream's jobs gave up: the discriminator is not touched)
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (ks >= 0) return;
 #endif

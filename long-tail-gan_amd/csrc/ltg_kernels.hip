@@ -129,8 +129,12 @@ __device__ __forceinline__ void ltg_gate_wait_tail(LtgGate g) {
 __device__ __forceinline__ bool ltg_poisoned(const unsigned* __restrict__ p) {
     return p && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
-__device__ __forceinline__ void ltg_gate_set(LtgGate g) {   // by ONE thread, after everything the consumer may rely on has completed
-    if (!g.word) return;                                     // (a kernel boundary in front of the caller: the producers here are whole kernels)
+// by ONE thread.  Every producer in this library is a WHOLE KERNEL that ended in front of the kernel that stores the word (the store
+// is the first thing a kernel does when it starts, or a one-wave kernel of its own behind the producer), and the end of a kernel is
+// already the device-wide release of what it wrote; the agent-scope release below is belt and braces -- measured in round 4 against a
+// build without it: bit-identical over 3 400 soak steps and no timing difference (profiles/r4_ab_gate_fence.txt), so it stays.
+__device__ __forceinline__ void ltg_gate_set(LtgGate g) {
+    if (!g.word) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_store(g.word, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2624,6 +2628,10 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 
 // the streaming decoder forward (stream_ok): logits of R <= 128 rows over the local slab; stat != NULL: per-group softmax statistics
 // as well.  Returns the number of statistic groups.
+// (Round 4, built and not run: 64-item tiles with the eight waves as 4 row groups x 2 item halves -- a wave then owns 32 batch rows, so
+// every B fragment it reads from LDS feeds two MFMAs: half the LDS bytes per FLOP, the untested suspect for this kernel's 0.46 of the
+// HBM rate -- needs two stationary fragment sets = 152 registers per lane: hipcc allocates 256 VGPRs + 776 bytes of scratch per lane for
+// it as written, i.e. the variant spills in its inner loop; it would need SGPR-base addressing throughout to fit.)
 // (Measured and not kept, round 3: the same loop as TWO independent 4-wave workgroups per CU -- half the batch rows each, 2 x 77 KB of
 // LDS, 244 VGPRs, bit-identical outputs -- so that one half's loads overlap the other's MFMAs and stores: 110.4 vs 107.9 us per launch
 // at 200 000 items on one box, min 81.8 vs 78.6; whole step 968-970 vs 965-968 us.  The serialisation is not inside the workgroup.)
@@ -2875,7 +2883,7 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
 // One Adam sweep of the discriminator from `ks` gradient slabs of stride `stride` (lrow: the per-row loss terms of the
 // round-1 kernels, else the loss sits in slot P of the slabs)
 static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLayout& L, int ks, int stride, const float* slab, int n,
-                    const float* lrow, const AdamC& ad, float* loss_out, const Probe& pr, hipStream_t st) {
+                    const float* lrow, const AdamC& ad, float* loss_out, const Probe& pr, hipStream_t st, const unsigned* poison = nullptr) {
     const int P = L.off[8];
     // one flat float4 sweep when the eight tensors (and moments) lie back to back -- and no operand-format shadows have to follow
     // the weights (fp8 mode: k_d_adam rewrites the e4m3 copies of the three matrices it updates)
@@ -2899,7 +2907,7 @@ static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLa
         return;
     }
     pr.before(LTG_K_D_ADAM);
-    if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, stride, slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out);
+    if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, stride, slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out, poison);
     else hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, stride, slab, *disc, ad, n, lrow, loss_out);
     pr.after(LTG_K_D_ADAM);
 }
@@ -2920,16 +2928,30 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         const int nA = (((n + 31) / 32) * ((h12 + 31) / 32) + 7) & ~7;      // padded: job B starts on a multiple of 8 (XCD chunk map)
         const int nB = ks * ((h12 + 1 + 31) / 32) * ((h3 + 31) / 32);
         const int nC = ks * ((h3 + 2 + 31) / 32);
-        // (Round 4, measured and not kept: jobs B / C -- dw3, db3, dw4, db4, d_loss: they need the forward only -- riding in stage 2's launch
-        // beside the embedding products instead of beside job A, so that stage 1 is the critical product alone: D step 59.5-59.6 ->
-        // 61.3-61.6 us on Askubuntu_Sample, same box, three interleaved rounds; profiles/r4_d_step_floor.txt.  The same file has the
-        // step's launch structure: the five grids with their registers and LDS returning at once take 18 us.)
-        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
-                                                        w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab));
+        // Jobs B / C (dw3, db3, dw4, db4, d_loss) need the forward only, not dpre1; job A -> stage 2 -> Adam is the critical chain.  With
+        // ltg_d_opts.aux_stream + sync they run on the caller's AUX stream beside job A and stage 2, handed over through two device
+        // words like the G step's forks (word 0: the forward is complete, stored by job A's launch when it starts, polled by one wave
+        // in front of jobs B / C; word 1: they have ended, polled by an extra block of stage 2 in front of the Adam sweep; word 2: a poll
+        // gave up = poison, the sweep then returns at once).  (Measured and not kept, same round: the same jobs riding in stage 2's OWN
+        // launch instead of beside job A: 59.5-59.6 -> 61.3-61.6 us per step; profiles/r4_d_step_floor.txt, which also has the step's
+        // launch structure: the five grids returning at once take 18 us.)
+        const bool fork = o->aux_stream && o->sync && !grad_out && (cfg->reserved0 & 64) == 0;      // (tuning-knob bit 6: no fork)
+        const unsigned* poison = fork ? o->sync + 2 : nullptr;
+        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(fork ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
+                                                        w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab,
+                                                        fork ? LtgGate{o->sync, o->seq, nullptr, 0} : LTG_NO_GATE));
+        if (fork) {
+            hipStream_t ax = (hipStream_t)o->aux_stream;
+            hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, ax, LtgGate{o->sync, o->seq, o->sync + 2, 0}, LTG_NO_GATE);
+            hipLaunchKernelGGL(fk_d_bwd1, dim3(nB + nC), dim3(NT), 0, ax, pv, h12, h3, 0, nB, ntile, L, SP, w.A1, w.A3, w.G3, w.spart, disc->p[7], disc->p[4],
+                               o->keep_prob, w.dpre1, w.slab, LTG_NO_GATE);
+            hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, ax, LtgGate{o->sync + 1, o->seq, nullptr, 0}, LTG_NO_GATE);
+        }
         const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab));
+        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2 + (fork ? 1 : 0)), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab,
+                                                        fork ? LtgGate{o->sync + 1, o->seq, o->sync + 2, 0} : LTG_NO_GATE));
         if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
-        else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st);
+        else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st, poison);
         return check_launch();
     }
     if (d_fp8_opfmt(cfg, disc)) {

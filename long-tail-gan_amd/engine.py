@@ -163,6 +163,40 @@ class Pipe:
         torch.cuda.synchronize(self.sync.device)
 
 
+class DFork:
+    """Caller-owned aux stream and device words of ltg_d_step's fork (include/ltg.h: ltg_d_opts.aux_stream / sync / seq): jobs B / C of the
+    discriminator's backward run beside the critical chain of the step.  The two streams must be concurrent (tested once per caller
+    stream with ltg_g_pipe_probe; otherwise the step stays on one stream)."""
+
+    def __init__(self, engine):
+        self.stream = torch.cuda.Stream(engine.device)
+        self.sync = torch.zeros(16, dtype=torch.int32, device=engine.device)
+        self.seq = 0
+        self.probed_for = None
+        self.ok = False
+
+    def ready(self, engine, st):
+        if self.probed_for != st:
+            self.ok = False
+            if hasattr(engine.lib, "ltg_g_pipe_probe"):
+                for _ in range(4):
+                    probe = cabi.ltg_pipe(self.stream.cuda_stream, None, None, None, None, None, None, 0, 0, _ptr(self.sync), None)
+                    rc = engine.lib.ltg_g_pipe_probe(C.byref(probe), st)
+                    if rc < 0:
+                        cabi.check(rc, "ltg_g_pipe_probe")
+                    if rc == 1:
+                        self.ok = True
+                        break
+                    self.stream = torch.cuda.Stream(engine.device)
+            self.sync.zero_()
+            self.seq = 0
+            self.probed_for = st
+        return self.ok
+
+    def expired_waits(self):
+        return int(self.sync[2].item())
+
+
 class Engine:
     def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
                  precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8,
@@ -177,6 +211,8 @@ class Engine:
         import weakref
         self._pipes = weakref.WeakSet()                              # the Pipe objects created for this engine (check_pipes)
         self.check_on_flush = True                                   # False: a probe that times the host's issue rate (scripts/host_bound_probe.py)
+        self.d_fork = os.environ.get("LTGAN_D_FORK", "1") != "0"     # ltg_d_step: jobs B / C of the backward on an aux stream (measurement switch)
+        self._dfork = None
         self._pinned = None                                          # pin_stream()
         self.device = _require_gpu(device)
         torch.cuda.set_device(self.device)
@@ -386,6 +422,12 @@ class Engine:
         dr = (cabi.vp * 3)(*[_ptr(t) for t in (drop_real or (None, None, None))])
         df = (cabi.vp * 3)(*[_ptr(t) for t in (drop_fake or (None, None, None))])
         o = cabi.ltg_d_opts(keep_prob, self.next_adam_t(), rng_step, dr, df, _pp(probe))
+        if self.d_fork and self.d_precision == cabi.LTG_PREC_FP32:
+            if self._dfork is None:
+                self._dfork = DFork(self)
+            if self._dfork.ready(self, self.stream()):
+                self._dfork.seq = (self._dfork.seq + 1) & 0xFFFFFFFF
+                o.aux_stream, o.sync, o.seq = self._dfork.stream.cuda_stream, _ptr(self._dfork.sync), self._dfork.seq
         rc = self.lib.ltg_d_step(C.byref(self.cfg), C.byref(self.disc_c), C.byref(real.c), C.byref(fake.c), C.byref(o),
                                  _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
         cabi.check(rc, "ltg_d_step")
@@ -461,10 +503,10 @@ class Engine:
     def check_pipes(self):
         """raises if a device-side wait of a one-call G step gave up (ltg_pipe.sync[2]).  The kernels behind such a wait have skipped
         their work, so the model is the one from before that step -- but the run is not the run that was asked for.  Synchronises."""
-        for pipe in list(self._pipes):
+        for pipe in list(self._pipes) + ([self._dfork] if self._dfork is not None else []):
             n = pipe.expired_waits()
             if n:
-                raise cabi.LtgError("%d device-side wait(s) of the G step's hand-overs gave up: the steps behind them were skipped, "
+                raise cabi.LtgError("%d device-side wait(s) of a step's hand-overs gave up: the steps behind them were skipped, "
                                     "the results of that phase are not trustworthy" % n)
 
     # ------------------------------------------------------------------ the G step cut at its exchange points

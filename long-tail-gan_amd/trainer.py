@@ -117,6 +117,8 @@ class Trainer:
                     eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j], probe=pr)
         finally:
             eng.pin_stream(False)           # (also when a step raised: nothing may stay pinned to a stale stream handle)
+        if eng._dfork is not None and eng.check_on_flush:
+            eng.check_pipes()               # (the D steps' fork: a device-side wait that gave up poisons it -- one host sync per phase)
         return self.d_losses
 
     # ---------------------------------------------------------------- phase G (train.py:307-329)

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_batch) == 8 + 9 * 8 and cabi.ltg_batch.uitem.offset == 8 + 8 * 8 and C.sizeof(cabi.ltg_gen_acts) == 8 * 8
     assert C.sizeof(cabi.ltg_fwd_opts) == 8 + 8 + 3 * 8 + 8 and cabi.ltg_fwd_opts.rows_per_step.offset == 40
     assert C.sizeof(cabi.ltg_pairs) == 8 + 3 * 8
-    assert C.sizeof(cabi.ltg_d_opts) == 8 + 8 + 7 * 8
+    assert C.sizeof(cabi.ltg_d_opts) == 8 + 8 + 7 * 8 + 8 + 8 + 8 and cabi.ltg_d_opts.sync.offset == 80
     assert C.sizeof(cabi.ltg_g_opts) == C.sizeof(cabi.ltg_fwd_opts) + 16 + 8 + 8 * 8 + 24 and cabi.ltg_g_opts.dec1_done.offset == C.sizeof(cabi.ltg_g_opts) - 24
     assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8 + 8
     assert C.sizeof(cabi.ltg_probe) == 8 + 16

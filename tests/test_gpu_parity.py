@@ -374,6 +374,48 @@ def _d_step_case(nr, nf, warm):
         _check_adam_move(move_got, move_want, ad.m[k].reshape(-1), ad.lr_t(3), ("theta", k))
 
 
+def test_d_step_with_its_backward_jobs_on_the_aux_stream_is_bit_identical():
+    """ltg_d_opts.aux_stream / sync (Engine.d_fork): jobs B / C of the backward's first stage (dw3, db3, dw4, db4, d_loss) beside the
+    critical chain job A -> stage 2, handed over through device words -- the same kernels writing the same slab entries, so six steps
+    from equal states must leave the same bits as the one-stream step: losses, every weight, every moment."""
+    import torch
+    from ltgan.engine import Pairs
+    I, hs = 500, (100, 150, 250, 300)
+    rng = np.random.default_rng(17)
+    D = O.init_discriminator(I, *hs, seed=3)
+    emb, darr = Hh.disc_to_engine(D)
+    a, b = _engine(I, "fp32", hs=hs, lr=1e-3), _engine(I, "fp32", hs=hs, lr=1e-3)
+    b.d_fork = False
+    dev = a.device
+    for e in (a, b):
+        e.set_discriminator(emb, darr)
+    losses = [[], []]
+    for step in range(6):
+        nr, nf = int(rng.integers(600, 1000)), int(rng.integers(600, 1000))
+        mk = lambda n: Pairs(torch.from_numpy(rng.integers(0, I, n).astype(np.int32)).to(dev), torch.from_numpy(rng.integers(0, I, n).astype(np.int32)).to(dev))
+        real, fake = mk(nr), mk(nf)
+        for k, e in enumerate((a, b)):
+            losses[k].append(e.d_step(real, fake, 0.7, rng_step=40 + step).clone())
+    torch.cuda.synchronize()
+    assert a._dfork is not None and b._dfork is None
+    if not a._dfork.ok:
+        pytest.skip("the aux stream shares a hardware queue with the caller's stream on this box: the step stays on one stream")
+    assert a._dfork.expired_waits() == 0 and a._dfork.seq == 6
+    for x, y in zip(*losses):
+        assert torch.equal(x, y)
+    for i in range(8):
+        assert torch.equal(a.d_p[i], b.d_p[i]) and torch.equal(a.d_m[i], b.d_m[i]) and torch.equal(a.d_v[i], b.d_v[i]), i
+    # a poisoned fork: the Adam sweep returns at once, the host raises when it next looks
+    before = [t.clone() for t in a.d_p]
+    a._dfork.sync[2] = 1
+    a.d_step(real, fake, 0.7, rng_step=99)
+    torch.cuda.synchronize()
+    for x, y in zip(before, a.d_p):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError, match="gave up"):
+        a.check_pipes()
+
+
 @pytest.mark.parametrize("hs,nr,nf,cuts,dq", [((100, 150, 250, 300), 900, 950, (0, 463, 925, 1388, 1850), "fp32"), ((12, 20, 28, 16), 33, 7, (0, 1, 1, 35, 40), "fp32"),
                                               ((2048, 1024, 512, 256), 260, 250, (0, 255, 510), "fp32"), ((2048, 1024, 512, 256), 260, 250, (0, 255, 510), "fp8"),
                                               ((512, 256, 256, 128), 700, 650, (0, 600, 1350), "fp8")])
