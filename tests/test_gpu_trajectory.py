@@ -126,6 +126,44 @@ def test_pipelined_g_phase_equals_the_step_by_step_loop():
         assert torch.equal(x, y), k
 
 
+def test_small_slab_loop_with_the_forked_discriminator_step_is_bit_identical():
+    """Small item slabs (Askubuntu_Sample's regime): ltg_d_step runs its backward's jobs B / C on the aux stream (Engine.d_fork).  Two global
+    epochs of the real loop with and without the fork: identical fake pairs, losses and every tensor of both models."""
+    import torch
+    from ltgan.dataset import DeviceData
+    from ltgan.engine import Engine
+    from ltgan.synthetic import synthetic_index
+    from ltgan.trainer import Trainer
+    idx, _ = synthetic_index("custom:1000", users=430, seed=23)
+    runs = []
+    for fork in (False, True):
+        eng = Engine(idx.n_items, lr=1e-3, precision="bf16", seed=5, d_seed=9)
+        eng.d_fork = fork
+        data = DeviceData(idx, 100, eng.device)
+        tr = Trainer(eng, data, num_sub_epochs=3, shuffle_seed=4)
+        assert tr.pipe is None and tr.batched_tower
+        losses = []
+        for _ in range(2):
+            tr.create_phase()
+            losses.append(tr.d_phase().clone())
+            losses.append(tr.g_phase().clone())
+        torch.cuda.synchronize()
+        if fork:
+            assert eng._dfork is not None
+            if not eng._dfork.ok:
+                pytest.skip("the aux stream shares a hardware queue with the caller's stream on this box")
+            assert eng._dfork.expired_waits() == 0 and eng._dfork.seq > 0
+        else:
+            assert eng._dfork is None
+        runs.append((data.fake_gen.clone(), losses, [t.clone() for t in eng.g_p + eng.g_m + eng.g_v + eng.d_p + eng.d_m + eng.d_v]))
+    a, b = runs
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)
+    for k, (x, y) in enumerate(zip(a[2], b[2])):
+        assert torch.equal(x, y), k
+
+
 def test_an_expired_device_side_wait_is_reported_by_the_trainer():
     """The hand-overs of the one-call G step poll words of device memory with a bound; a poll that gives up is counted in
     ltg_pipe.sync[2] and must surface as an error at the end of the phase (Trainer.check_pipe), not as silently wrong weights."""
