@@ -452,6 +452,7 @@ def other_workloads(a, device, users=6400):
                     "d_step_us": float(np.median([p["t_d"] for p in ph])) / (a.sub_epochs * nb) * 1e6,
                     "warm_moments": bool(warm),
                     "lazy_q0": bool(eng.lazy_q0),
+                    "handover": getattr(getattr(tr, "pipe", None), "handover", None),     # how the one-call G step's streams meet (engine.py: _pipe_ready)
                     **step_fracs(idx, data, eng, a.sub_epochs, tr.active, dt, 1),
                     "dominant_kernel": None if r is None else {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}}
         del tr, prof, eng, data, idx

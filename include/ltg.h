@@ -471,7 +471,8 @@ int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32
 int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,
                        const ltg_pairs* fake, const ltg_g_opts* opts, const ltg_gen_acts* acts, const ltg_comm* comm,
                        const ltg_pipe* pipe, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream);
-/* 1: `stream` and pipe->side_stream run concurrently (a waiter on one does not hold up the other), as the device-word hand-over needs;
+/* 1: `stream` and pipe->side_stream (and pipe->tail_stream, and those two with each other) run concurrently (a waiter on one does not hold
+ * up the other), as the device-word hand-over needs;
  * 0: they share a hardware queue (HIP maps streams onto a few of them) -- use another side stream, or LTG_PIPE_EVENTS; < 0: error.
  * Synchronises both streams; uses sync[3..4].  Call it once per (stream, side stream) pair before the first step. */
 int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream);

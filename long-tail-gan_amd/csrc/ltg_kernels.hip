@@ -3575,15 +3575,20 @@ int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream) {
     hipStream_t st = (hipStream_t)stream;
     // a waiter on the side stream FIRST, then its producer on `stream`: with one hardware queue under both, the producer cannot start
     // before the waiter has given up (5 ms).  The same for the tail stream when the pipe has one.
-    for (int which = 0; which < 2; ++which) {
+    // Pairs (waiter's stream, setter's stream): the caller's stream against each side stream, and -- when the pipe has both -- the tail
+    // stream against the side stream: they never wait for each other, but in one queue the Adam tail would sit behind the ~100-us weight
+    // update and the next call's enc-0, which polls for the tail's end, with it (seen in round 4: a process with many streams alive put
+    // both onto one hardware queue: 180 instead of 147 us per step at 20 000 items).
+    for (int which = 0; which < 3; ++which) {
         hipStream_t sd = (hipStream_t)(which == 0 ? pipe->side_stream : pipe->tail_stream);
-        if (!sd) continue;
+        hipStream_t sp = which == 2 ? (hipStream_t)pipe->side_stream : st;
+        if (!sd || (which == 2 && !pipe->side_stream)) continue;     // (`stream` itself may be the null stream: handle 0)
         unsigned zero[2] = {0u, 0u}, got[2] = {0u, 0u};
-        if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
+        if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(sp) != hipSuccess) return LTG_ELAUNCH;
         if (hipMemcpy(pipe->sync + 3, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return LTG_ELAUNCH;
         hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pipe->sync + 3, 1u, pipe->sync + 4, 5});
-        hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, st, LtgGate{pipe->sync + 3, 1u, nullptr, 0});
-        if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LTG_ELAUNCH;
+        hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sp, LtgGate{pipe->sync + 3, 1u, nullptr, 0});
+        if (hipStreamSynchronize(sd) != hipSuccess || hipStreamSynchronize(sp) != hipSuccess) return LTG_ELAUNCH;
         if (hipMemcpy(got, pipe->sync + 3, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) return LTG_ELAUNCH;
         if (check_launch() != LTG_OK) return LTG_ELAUNCH;
         if (!(got[0] == 1u && got[1] == 0u)) return 0;
@@ -3678,6 +3683,8 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     } else
         q0_touch(cfg, gen, bt, st, poison);
     // ---- forward: enc-0 over the local slab -> exchange 1 -> enc-1 (bias + tanh in its loader), dec-0, local logits + statistics
+    // (Round 4, measured and removed: without a communicator, bias + tanh in enc-0 and the plain enc-1 behind it, h1 alternating between
+    // two buffers: 143.5-147.2 against 145.2-148.1 us per step at 20 000 items, equal at 200 000 -- within the noise, one mode fewer.)
     {
         ltg_gen_acts a1 = *acts;
         a1.h1 = pp->h1pre;

@@ -577,10 +577,10 @@ class Engine:
                 pipe.new_tail_stream(drop=True)
             elif tail:                               # ... then the tail's own stream: a third concurrent queue, or the tail stays on the caller's stream
                 pipe.c.tail_stream = tail
-                for k in range(6):
+                for k in range(10):     # (a process that has created many streams: the next few may share the side stream's queue)
                     if probe():
                         break
-                    pipe.new_tail_stream(drop=(k == 5))
+                    pipe.new_tail_stream(drop=(k == 9))
                 if pipe.tail_stream is not None:
                     pipe.handover = "device-words + tail stream"
         pipe.probed_for = st

@@ -12,6 +12,7 @@ python bench.py --workload ml20m --users 6400 --no-cpu-baseline --no-other-workl
 python bench.py --workload custom:25024 --parallelism item-shard --no-cpu-baseline --no-other-workloads 2>/dev/null | tail -1 > $O/r4_bench_mid25k_item_shard.json
 python bench.py --d-sizes 2048,1024,512,256 --d-precision fp8 --no-cpu-baseline --no-other-workloads 2>/dev/null | tail -1 > $O/r4_bench_askubuntu_wide_fp8.json
 python bench.py --workload ml20m --users 136000 --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads 2>/dev/null | tail -1 > $O/r4_bench_ml20m_full_136k_users.json
+python bench.py --workload c4 --users 1000000 --steps 1 --warmup 1 --no-cpu-baseline --no-other-workloads 2>/dev/null | tail -1 > $O/r4_bench_c4_full_1m_users.json
 python scripts/host_bound_probe.py 25024 2>/dev/null | grep "items=" > $O/r4_host_issue_mid25k.txt
 for wl in "askubuntu:" "c4_3200users:--workload c4 --users 3200" "ml20m_3200users:--workload ml20m --users 3200" "mid25k:--workload custom:25024 --parallelism item-shard" "askubuntu_wide_fp8:--d-sizes 2048,1024,512,256 --d-precision fp8"; do
   name=${wl%%:*}; extra=${wl#*:}
@@ -28,7 +29,7 @@ f=$(find $O/trace_mid -name "*kernel_trace.csv" | head -1); python profiles/make
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/$O/trace_ask -- python3 $R/bench.py --steps 1 --warmup 1 --no-probe --no-cpu-baseline --no-other-workloads > $R/$O/trace_ask.log 2>&1
 cd $R
-f=$(find $O/trace_ask -name "*kernel_trace.csv" | head -1); python profiles/make_timeline.py "$f" fk_enc0_fwd 3 > $O/r4_askubuntu_g_step_timeline.txt; rm -rf $O/trace_ask
+f=$(find $O/trace_ask -name "*kernel_trace.csv" | head -1); python profiles/make_timeline.py "$f" fk_enc0_fwd 3 > $O/r4_askubuntu_g_step_timeline.txt; python profiles/make_timeline.py "$f" fk_d_l1 3 > $O/r4_d_step_timeline.txt; rm -rf $O/trace_ask
 for wl in "askubuntu:" "c4:--workload c4 --users 1600"; do
   name=${wl%%:*}; extra=${wl#*:}
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
