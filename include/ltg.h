@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 12
+#define LTG_ABI_VERSION 13
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -430,7 +430,18 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  * mode must be concurrent (ltg_g_pipe_probe).  After a call that FAILED the caller synchronises, zeroes the words and restarts seq at 0.
  * Before anything else reads W_p1t / W_q0 / their moments (ltg_g_flush, ltg_vae_forward, a checkpoint) the caller runs
  * ltg_g_pipe_join on the stream that will read them.  Results equal ltg_g_step's / the cut-point sequence's bit for bit (same
- * kernels, same order of additions; the slice only runs later). */
+ * kernels, same order of additions; the slice only runs later).
+ *
+ * Catch-up AHEAD (ABI v13; device-word mode with the slice on the side stream, batches that carry `uitem`, h_enc <= 768): the catch-up
+ * of the lazy clock -- the rows of W_q0 the batch reads, brought up to the caller's clock before enc-0 -- is the FIRST kernel of the
+ * step's critical chain and moves 24 B per parameter of every distinct row.  A caller that knows the NEXT batch sets
+ * ltg_pipe.next_uitem / next_nu: call t then brings those rows up to ordinal t ON THE SIDE STREAM, behind its slice (so word 6 covers
+ * it), beside its own forward -- every row except the ones batch t itself holds (those get step t's gradient from the sparse gradient
+ * kernel and are at t with it).  Which rows batch t holds is read from ltg_pipe.q0_mark (one int32 per local item, zeroed once by the
+ * caller and with every reset of seq): the catch-up -- or the ahead kernel of the call before -- stores the call's ordinal there.  The
+ * zero-gradient steps are the same expressions in the same order, only earlier: results do not change by a bit.  Call t + 1 on the
+ * SAME batch the pipe announced, with nothing else having moved gen->q0_ord in between, sets ltg_pipe.caught_up = 1 and the library
+ * launches no catch-up.  ltg_g_step_sharded_ahead_ok says whether a call with these arguments runs the ahead kernel. */
 #define LTG_NCCL_FLOAT32 7
 #define LTG_NCCL_SUM 0
 typedef struct ltg_comm {
@@ -456,6 +467,11 @@ typedef struct ltg_pipe {
     ltg_stream tail_stream; /* optional THIRD stream (ABI v12; device-word mode only): the step's Adam tail -- W_p0, W_q1 and the biases; it needs
                              * the backward's dh1 only -- runs there beside the sparse W_q0 gradient, the next call's catch-up and enc-0
                              * (words 9 / 10); used when comm == NULL (or LTG_PIPE_TAIL_OWN).  NULL: the tail stays the step's last kernel on the caller's stream */
+    /* catch-up ahead (ABI v13; all optional, see above) */
+    int32_t* q0_mark;           /* [n_items] int32, zeroed by the caller (and again whenever seq restarts): ordinal of the last call whose batch holds the row */
+    const int32_t* next_uitem;  /* the NEXT call's ltg_batch.uitem (its distinct local items) or NULL */
+    int32_t next_nu;            /* ... and its n_unique */
+    int32_t caught_up;          /* 1: the previous call on this pipe was given THIS batch as next_uitem / next_nu and gen->q0_ord moved by that call only */
 } ltg_pipe;
 #define LTG_PIPE_NO_DEC1_FORK 1  /* everything on the caller's stream, in program order */
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
@@ -468,6 +484,8 @@ typedef struct ltg_pipe {
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
 int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);
+/* 1: ltg_g_step_sharded with this batch and this pipe (next_uitem set) brings the announced rows up to date, and honours caught_up */
+int ltg_g_step_sharded_ahead_ok(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pipe* pipe);
 int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,
                        const ltg_pairs* fake, const ltg_g_opts* opts, const ltg_gen_acts* acts, const ltg_comm* comm,
                        const ltg_pipe* pipe, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream);

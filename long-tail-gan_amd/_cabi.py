@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 12
+LTG_ABI_VERSION = 13
 LTG_Q0_HIST = 1024
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
@@ -99,12 +99,14 @@ class ltg_comm(C.Structure):
 
 class ltg_pipe(C.Structure):
     _fields_ = [("side_stream", vp), ("ev_fork", vp), ("ev_dec1", vp), ("ev_tail", vp),
-                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("seq", C.c_uint32), ("sync", vp), ("tail_stream", vp)]
+                ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("seq", C.c_uint32), ("sync", vp), ("tail_stream", vp),
+                ("q0_mark", vp), ("next_uitem", vp), ("next_nu", C.c_int32), ("caught_up", C.c_int32)]
 
 
 # every symbol include/ltg.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ltg_g_step_sharded_ok": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.c_int32]),
+    "ltg_g_step_sharded_ahead_ok": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pipe)]),
     "ltg_g_step_sharded": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state), C.POINTER(ltg_batch),
                                      C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), C.POINTER(ltg_comm),
                                      C.POINTER(ltg_pipe), vp, vp, C.c_size_t, vp]),

@@ -1989,6 +1989,23 @@ __device__ __forceinline__ bool q0_row_steps(float4& p, float4& mm, float4& vv, 
     }
     return true;
 }
+// ONE zero-gradient step with the learning rate given (the step the caller is performing: its rate is not in the ring yet)
+__device__ __forceinline__ bool q0_zero_step(float4& p, float4& mm, float4& vv, float lr, const AdamC ad) {
+    const bool m0 = mm.x == 0.f && mm.y == 0.f && mm.z == 0.f && mm.w == 0.f;
+    const bool v0 = vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
+    if (m0 && v0) return false;
+    if (m0) {
+        vv.x *= ad.b2; vv.y *= ad.b2; vv.z *= ad.b2; vv.w *= ad.b2;
+    } else {
+#define LTG_ADAM0(f)          \
+    mm.f = ad.b1 * mm.f;      \
+    vv.f = ad.b2 * vv.f;      \
+    p.f = adam_move(p.f, lr * mm.f, vv.f, ad.eps);
+        LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
+#undef LTG_ADAM0
+    }
+    return true;
+}
 __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* __restrict__ m4, float4* __restrict__ v4, int H4, int from, int to,
                                                const float* __restrict__ lr_hist, const float4* __restrict__ G4, const AdamC ad) {
     const int nz = G4 ? to - 1 : to;   // last zero-gradient step
@@ -2012,9 +2029,11 @@ __device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* 
 // rows of the batch's distinct items (G-step batches carry the list): up to `target`, before enc-0 reads them
 __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
                                                            const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target,
-                                                           ltg_gen_state st, AdamC ad, const unsigned* __restrict__ poison = nullptr) {
+                                                           ltg_gen_state st, AdamC ad, const unsigned* __restrict__ poison = nullptr,
+                                                           int32_t* __restrict__ mark = nullptr, unsigned seq = 0u) {
     // (one-call step, slice on the side stream: the slice of the previous call is done with every row before this kernel starts -- the
     // previous call's last kernel on this stream waited for word 6, ltg_gate_wait_tail; poison: that wait gave up)
+    // mark: ltg_pipe.q0_mark -- "call seq's batch holds this row" for the ahead kernel of the same call (k_q0_touch_ahead)
     if (ltg_poisoned(poison)) return;
     const int u = blockIdx.x;
     if (u >= nu) return;
@@ -2025,6 +2044,7 @@ __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const 
         const int from = st.q0_last[i];
         float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
                vv = reinterpret_cast<const float4*>(st.v[0])[off];
+        if (mark && threadIdx.x == 0) mark[i] = (int32_t)seq;
         __syncthreads();   // every thread has read q0_last[i]
         if (from >= target) return;
         if ((int)threadIdx.x < H4 && q0_row_steps(p, mm, vv, from, target, st.q0_lr_hist, ad)) {
@@ -2037,12 +2057,46 @@ __global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const 
     }
     const int i = uitem ? uitem[u] : indices[csr_pos[uptr[u]]];
     const int from = st.q0_last[i];
+    if (mark && threadIdx.x == 0) mark[i] = (int32_t)seq;
     if (from >= target) return;
     const size_t off = (size_t)i * H4;
     q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
                    from, target, st.q0_lr_hist, nullptr, ad);
     __syncthreads();   // every thread has read q0_last[i]
     if (threadIdx.x == 0) st.q0_last[i] = target;
+}
+
+// The NEXT batch's rows, during the current call (ordinal `seq`, Adam step `cur` = q0_ord + 1), on the side stream behind the slice:
+// up to `cur` -- zero-gradient steps from the ring up to cur - 1, then step cur itself with this call's learning rate (the sparse gradient
+// kernel stores it into the ring, possibly later) -- for every row the CURRENT batch does not hold (mark != seq: nobody else reads or
+// writes those rows during this call); the rows it holds reach `cur` through the sparse gradient kernel.  Either way the row is marked
+// for the next call (seq + 1), whose catch-up launch the host then leaves out (ltg_pipe.caught_up).
+__global__ __launch_bounds__(Q0_NT) void k_q0_touch_ahead(int H, int nu, const int32_t* __restrict__ uitem, int cur, ltg_gen_state st, AdamC ad,
+                                                          int32_t* __restrict__ mark, unsigned seq, const unsigned* __restrict__ poison) {
+    if (ltg_poisoned(poison)) return;
+    const int u = blockIdx.x;
+    if (u >= nu) return;
+    const int H4 = H >> 2;
+    const int i = uitem[u];
+    const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
+    const bool held = (unsigned)mark[i] == seq;
+    const int from = st.q0_last[i];
+    // (requested beside the mark and the clock; a held row's values may be mid-update by the sparse gradient kernel: they are discarded)
+    float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
+           vv = reinterpret_cast<const float4*>(st.v[0])[off];
+    __syncthreads();   // every thread has read mark[i] and q0_last[i]
+    if (threadIdx.x == 0) mark[i] = (int32_t)(seq + 1u);
+    if (held || from >= cur) return;
+    if ((int)threadIdx.x < H4) {
+        bool moved = q0_row_steps(p, mm, vv, from, cur - 1, st.q0_lr_hist, ad);
+        moved = q0_zero_step(p, mm, vv, ad.lr_t, ad) || moved;
+        if (moved) {
+            reinterpret_cast<float4*>(st.p[0])[off] = p;
+            reinterpret_cast<float4*>(st.m[0])[off] = mm;
+            reinterpret_cast<float4*>(st.v[0])[off] = vv;
+        }
+    }
+    if (threadIdx.x == 0) st.q0_last[i] = cur;
 }
 
 // The catch-up of a batch's rows AND the rotating slice (rows start, start + stride, ...) in ONE launch, both up to `target`: a row
@@ -2594,13 +2648,14 @@ inline bool q0_lazy(const ltg_config* cfg, const ltg_gen_state* gen) {
            cfg->n_items >= 8192;   // smaller slabs update W_q0 as a dense product: nothing to defer
 }
 // the item rows this batch reads, up to the caller's clock (no-ops for rows that are current)
-void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st, const unsigned* poison = nullptr) {
+void q0_touch(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, hipStream_t st, const unsigned* poison = nullptr,
+              int32_t* mark = nullptr, unsigned seq = 0u) {
     if (!q0_lazy(cfg, gen) || bt->n_rows <= 0) return;
     const AdamC ad = make_adam(cfg, 1);   // b1, b2, eps; the learning rates come from the history ring
     if (bt->uptr && bt->csr_pos) {
         if (bt->n_unique > 0)
             hipLaunchKernelGGL(k_q0_touch_unique, dim3(bt->n_unique), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
-                               gen->q0_ord, *gen, ad, poison);
+                               gen->q0_ord, *gen, ad, poison, mark, seq);
     } else {
         hipLaunchKernelGGL(k_q0_touch_rows, dim3(bt->n_rows), dim3(Q0_NT), 0, st, cfg->h_enc, bt->n_rows, bt->indptr, bt->indices, gen->q0_ord, *gen, ad);
     }
@@ -3569,6 +3624,17 @@ int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32
             q0_lazy(cfg, gen)) ? 1 : 0;
 }
 
+// the catch-up ahead (include/ltg.h): device words with the slice on the side stream, marks, batches with their distinct-item lists
+static bool q0_ahead_capable(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pipe* pp) {
+    if (!cfg || !gen || !bt || !pp || !pp->q0_mark || !pp->sync || !bt->uitem || !bt->uptr || !bt->csr_pos) return false;
+    const int fl = pp->flags;
+    if (fl & (LTG_PIPE_NO_DEC1_FORK | LTG_PIPE_NO_SLICE_FORK | LTG_PIPE_EVENTS | LTG_PIPE_SLICE_IN_TOUCH)) return false;
+    return q0_lazy(cfg, gen) && (cfg->h_enc >> 2) <= Q0_NT;
+}
+int ltg_g_step_sharded_ahead_ok(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pipe* pp) {
+    return (cfg_ok(cfg) && gen && bt && pp && ltg_g_step_sharded_ok(cfg, gen, bt->n_rows) && q0_ahead_capable(cfg, gen, bt, pp)) ? 1 : 0;
+}
+
 int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream) {
     clear_errors();
     if (!pipe || !pipe->sync || !pipe->side_stream) return LTG_EINVAL;
@@ -3634,6 +3700,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // enc-1 / dec-0 instead of inside the catch-up launch on the critical stream
     const bool side_slice = gates && defer_slice && (pp->flags & LTG_PIPE_SLICE_IN_TOUCH) == 0;
     const bool merge_slice = defer_slice && !side_slice;   // (events, or LTG_PIPE_SLICE_IN_TOUCH: the slice rides in the catch-up launch)
+    const bool ahead = side_slice && q0_ahead_capable(cfg, gen, bt, pp);   // catch-up of the NEXT batch's rows during this call (include/ltg.h)
     Workspace w = carve(cfg, B, nf, (char*)ws);
     if (o->y_pre) w.y = const_cast<float*>(o->y_pre);   // y_generated from ltg_fake_tower_batched
     const Probe pr{o->probe, st};
@@ -3672,6 +3739,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         const int start = gen->q0_ord % qP, ns = (I - start + qP - 1) / qP;
         hipLaunchKernelGGL(k_q0_touch_slice, dim3(bt->n_unique + ns), dim3(Q0_NT), 0, st, I, H, bt->n_unique, bt->uptr, bt->csr_pos, bt->indices, bt->uitem,
                            gen->q0_ord, start, qP, *gen, make_adam(cfg, 1));
+    } else if (side_slice && ahead && pp->caught_up) {
+        // the previous call brought this batch's rows up to q0_ord on the side stream (k_q0_touch_ahead; its end is behind word 6, which
+        // that call's last kernel on this stream waited for) and marked them: no catch-up launch
     } else if (side_slice) {
         // the slice step t - 1 owes (rows i = ord (mod period) up to ord) on the SIDE stream, between this call's catch-up and the next call's:
         // word 5 is opened by enc-0 when it starts (the catch-up in front of it is complete: the rows of this batch are at ord, the slice
@@ -3679,7 +3749,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         // stream's next kernel (the waiter in front of the weight update) when it starts, and the NEXT call's catch-up polls for it
         // (issued in the order the device needs them: the critical stream's kernels first)
         // (the previous call's last kernel waited for word 6 before it ended: ltg_gate_wait_tail in fk_g_tail)
-        q0_touch(cfg, gen, bt, st, poison);
+        q0_touch(cfg, gen, bt, st, poison, ahead ? pp->q0_mark : nullptr, pp->seq);
     } else
         q0_touch(cfg, gen, bt, st, poison);
     // ---- forward: enc-0 over the local slab -> exchange 1 -> enc-1 (bias + tanh in its loader), dec-0, local logits + statistics
@@ -3696,6 +3766,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
         if (gen->q0_ord > 0 && start < I)
             hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1), poison);
+        if (ahead && pp->next_uitem && pp->next_nu > 0)
+            hipLaunchKernelGGL(k_q0_touch_ahead, dim3(pp->next_nu), dim3(Q0_NT), 0, sd, H, pp->next_nu, pp->next_uitem, gen->q0_ord + 1, *gen, ad, pp->q0_mark,
+                               pp->seq, poison);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
     LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,

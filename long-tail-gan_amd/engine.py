@@ -131,9 +131,14 @@ class Pipe:
         self.rowpart_all = torch.zeros(n_ranks * rows * 5, **f)
         self.dh2 = torch.zeros(rows, engine.H, **f)
         self.sync = torch.zeros(16, dtype=torch.int32, device=dev)        # words of the device-side hand-overs; [2] = waits that gave up = the pipe's poison
+        # catch-up ahead (include/ltg.h, ABI v13): "the current batch holds this row" marks; LTGAN_Q0_AHEAD=0: every call launches its own catch-up
+        self.q0_mark = torch.zeros(engine.I, dtype=torch.int32, device=dev) if os.environ.get("LTGAN_Q0_AHEAD", "1") != "0" else None
         self.c = cabi.ltg_pipe(self.side_stream.cuda_stream, self._ev[0].start, self._ev[0].stop, self._ev[1].start, _ptr(self.h1pre),
                                _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0, _ptr(self.sync),
-                               self.tail_stream.cuda_stream if self.tail_stream is not None else None)
+                               self.tail_stream.cuda_stream if self.tail_stream is not None else None,
+                               _ptr(self.q0_mark) if self.q0_mark is not None else None, None, 0, 0)
+        self.ahead = None           # (uitem address, n_unique, q0_ord, seq) of the call whose rows the last call brought up to date
+        self.ahead_calls = 0        # calls that launched no catch-up of their own
         self.probed_for = None      # the caller's stream the side stream was last tested against (Engine._pipe_ready)
         self.handover = None        # "device-words" | "events"
         engine._pipes.add(self)     # Engine.check_pipes(): nothing reads the model out behind a wait that gave up
@@ -159,7 +164,11 @@ class Pipe:
         otherwise leave the next one waiting for words nobody sets)"""
         torch.cuda.synchronize(self.sync.device)
         self.sync.zero_()
+        if self.q0_mark is not None:
+            self.q0_mark.zero_()
         self.c.seq = 0
+        self.ahead = None
+        self.c.next_uitem, self.c.next_nu, self.c.caught_up = None, 0, 0
         torch.cuda.synchronize(self.sync.device)
 
 
@@ -527,12 +536,26 @@ class Engine:
             return False
         return bool(self.lib.ltg_g_step_sharded_ok(C.byref(self.cfg), C.byref(self.gen_c), int(rows)))
 
-    def g_step_sharded(self, batch, fake, acts, gopts, pipe, comm=None, loss_out=None):
-        """every launch of the step and its exchanges from one call (comm: _rccl.RcclComm / HostComm; None = one rank)"""
+    def g_step_sharded(self, batch, fake, acts, gopts, pipe, comm=None, loss_out=None, next_batch=None):
+        """every launch of the step and its exchanges from one call (comm: _rccl.RcclComm / HostComm; None = one rank).
+        next_batch: the batch of the NEXT call on this pipe when the caller knows it -- its rows of W_q0 are brought up to the lazy clock
+        during this call on the side stream, and the next call launches no catch-up (include/ltg.h: catch-up ahead)"""
         loss_out = self.loss_buf if loss_out is None else loss_out
         ws = self.workspace(batch.n_rows, fake.n)
         self._pipe_ready(pipe)
+        if pipe.c.seq >= 0x7FFFFFF0:                                   # (the marks compare ordinals: restart long before they could repeat)
+            self.pipe_join(pipe)
+            pipe.reset()
         pipe.c.seq = (pipe.c.seq + 1) & 0xFFFFFFFF                     # the call's ordinal on this pipe (what its gates count in)
+        key = (batch.c.uitem, int(batch.c.n_unique), int(self.gen_c.q0_ord), int(pipe.c.seq))
+        pipe.c.caught_up = 1 if (pipe.ahead is not None and pipe.ahead == key) else 0
+        pipe.ahead_calls += pipe.c.caught_up
+        pipe.ahead = None
+        pipe.c.next_uitem, pipe.c.next_nu = None, 0
+        if (next_batch is not None and pipe.q0_mark is not None and next_batch.c.uitem and self.q0_defer and
+                self.lib.ltg_g_step_sharded_ahead_ok(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(pipe.c)) == 1):
+            pipe.c.next_uitem, pipe.c.next_nu = next_batch.c.uitem, int(next_batch.c.n_unique)
+            pipe.ahead = (next_batch.c.uitem, int(next_batch.c.n_unique), int(self.gen_c.q0_ord) + 1, (int(pipe.c.seq) + 1) & 0xFFFFFFFF)
         rc = self.lib.ltg_g_step_sharded(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
                                          C.byref(gopts), C.byref(acts.c), C.byref(comm.c) if comm is not None else None, C.byref(pipe.c),
                                          _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())

@@ -198,7 +198,8 @@ class ShardedTrainer(Trainer):
                         y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
         if self.pipe is not None:
             # ONE call: every launch of the step and its three exchanges in-stream (ltg_g_step_sharded)
-            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j])
+            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j],
+                               next_batch=getattr(self, "_next_batch", None))
             return
         # the step cut at its exchange points, collectives through torch.distributed (configurations ltg_g_step_sharded does not
         # serve: fp32 decoder operands, small slabs, the dense W_q0 sweep)

@@ -180,7 +180,8 @@ class Trainer:
         if self.pipe is not None:
             go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, rs, ds, probe=pr,
                             y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
-            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j])
+            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j],
+                               next_batch=getattr(self, "_next_batch", None))
         else:
             eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
                        keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=rs,
@@ -193,12 +194,15 @@ class Trainer:
         ok = False
         try:
             self._tower_ahead()        # every fake tower of the phase in a few large launches
+            seq = [self.active[k] for k in self.order]
             for j in range(self.S):
                 a = self.anneal()
-                for k in self.order:
-                    b = self.active[k]
+                for n, b in enumerate(seq):
                     a = self.anneal()
                     self.update_count += 1
+                    # the batch of the NEXT step (known: the phase's order is fixed): its rows of W_q0 are caught up during this one
+                    nb = seq[n + 1] if n + 1 < len(seq) else (seq[0] if j + 1 < self.S else None)
+                    self._next_batch = d.view(nb)["batch"] if nb is not None else None
                     self._g_one(j, b, d.view(b), a)
                 self.last_anneal.append(a)
             ok = True

@@ -92,10 +92,12 @@ def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, 
         assert torch.equal(a, b), k
 
 
-def test_pipelined_g_phase_equals_the_step_by_step_loop():
+def test_pipelined_g_phase_equals_the_step_by_step_loop(monkeypatch):
     """Large item slabs run phase G (train.py:307-329) as one ltg_g_step_sharded call per step -- decoder weight update and lazy-clock slice
-    forked beside the NEXT step -- with every fake tower evaluated ahead.  Two global epochs (C, S x D, S x G) of the real loop on a synthetic
-    9 000-item dataset: identical fake pairs, and every generator tensor, Adam moment and loss equals the loop over ltg_g_step bit for bit."""
+    forked beside the NEXT step, the next batch's rows of W_q0 caught up AHEAD on the side stream (no catch-up launch of its own; also with
+    LTGAN_Q0_AHEAD=0: every call catches up its own rows) -- with every fake tower evaluated ahead.  Two global epochs (C, S x D, S x G) of
+    the real loop on a synthetic 9 000-item dataset: identical fake pairs, and every generator tensor, Adam moment and loss equals the loop
+    over ltg_g_step bit for bit."""
     import torch
     from ltgan.dataset import DeviceData
     from ltgan.engine import Engine
@@ -103,11 +105,12 @@ def test_pipelined_g_phase_equals_the_step_by_step_loop():
     from ltgan.trainer import Trainer
     idx, _ = synthetic_index("custom:9000", users=430, seed=21)
     runs = []
-    for pipe in (False, True):
+    for pipe in (False, True, "own-catch-up"):
+        monkeypatch.setenv("LTGAN_Q0_AHEAD", "0" if pipe == "own-catch-up" else "1")
         eng = Engine(idx.n_items, h_sizes=(20, 24, 40, 36), lr=1e-3, precision="bf16", seed=5, d_seed=9)
         data = DeviceData(idx, 100, eng.device)
-        tr = Trainer(eng, data, num_sub_epochs=3, shuffle_seed=4, pipe_step=pipe)
-        assert (tr.pipe is not None) == pipe and eng.lazy_q0
+        tr = Trainer(eng, data, num_sub_epochs=3, shuffle_seed=4, pipe_step=bool(pipe))
+        assert (tr.pipe is not None) == bool(pipe) and eng.lazy_q0
         losses = []
         for _ in range(2):
             tr.create_phase()
@@ -117,13 +120,20 @@ def test_pipelined_g_phase_equals_the_step_by_step_loop():
         tr.check_pipe()                                                    # no device-side wait of the hand-overs gave up
         if pipe:
             assert tr.pipe.handover in ("device-words + tail stream", "device-words", "events") and tr.pipe.expired_waits() == 0, tr.pipe.handover
+            steps = int(tr.update_count)          # G steps so far (two phases)
+            if pipe is True and tr.pipe.handover != "events":
+                # every step but the first of each phase found its rows caught up by the step before
+                assert tr.pipe.ahead_calls == steps - 2, (tr.pipe.ahead_calls, steps)
+            else:
+                assert tr.pipe.ahead_calls == 0
         runs.append((data.fake_gen.clone(), data.fake_pop.clone(), losses, [t.clone() for t in eng.g_p + eng.g_m + eng.g_v + eng.d_p]))
-    a, b = runs
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for x, y in zip(a[2], b[2]):
-        assert torch.equal(x, y)
-    for k, (x, y) in enumerate(zip(a[3], b[3])):
-        assert torch.equal(x, y), k
+    a = runs[0]
+    for b in runs[1:]:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y)
+        for k, (x, y) in enumerate(zip(a[3], b[3])):
+            assert torch.equal(x, y), k
 
 
 def test_small_slab_loop_with_the_forked_discriminator_step_is_bit_identical():
