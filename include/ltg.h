@@ -413,8 +413,8 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  *   word 7  the weight update of call seq has ENDED (one wave behind it): the streaming forward of call seq + 1 reads the shadow rows
  *           and the bias it writes
  *   word 5  enc-0 of call seq has started = the catch-up of the batch's rows is complete (a one-wave kernel in front of the slice polls)
- *   word 6  the clock slice of call seq has ended (stored by the next kernel of the side stream when it starts): the catch-up of
- *           call seq + 1 must not meet it on a row
+ *   word 6  the clock's work beside call seq -- its slice and, ABI v13, the catch-up of the next batch's rows -- has ended (stored by the
+ *           next kernel of the side stream when it starts): the catch-up of call seq + 1 must not meet it on a row
  *   word 9  dh1 of call seq is complete (stored by the sparse gradient kernel when it starts; a one-wave kernel in front of the Adam
  *           tail on ltg_pipe.tail_stream polls);  word 10  that tail has ended (one wave behind it): enc-1 of call seq + 1 reads what it updates
  *   word 2  polls that gave up (each is bounded: 30 s) = the pipe's POISON
@@ -441,7 +441,7 @@ int ltg_gather_cand_logits(const ltg_config* cfg, const ltg_sample_inputs* in, c
  * caller and with every reset of seq): the catch-up -- or the ahead kernel of the call before -- stores the call's ordinal there.  The
  * zero-gradient steps are the same expressions in the same order, only earlier: results do not change by a bit.  Call t + 1 on the
  * SAME batch the pipe announced, with nothing else having moved gen->q0_ord in between, sets ltg_pipe.caught_up = 1 and the library
- * launches no catch-up.  ltg_g_step_sharded_ahead_ok says whether a call with these arguments runs the ahead kernel. */
+ * launches no catch-up.  ltg_g_step_sharded_plan says whether a call with these arguments runs the ahead kernel. */
 #define LTG_NCCL_FLOAT32 7
 #define LTG_NCCL_SUM 0
 typedef struct ltg_comm {
@@ -466,12 +466,16 @@ typedef struct ltg_pipe {
                          * NULL: the hand-overs are events (ev_fork / ev_dec1), as with LTG_PIPE_EVENTS */
     ltg_stream tail_stream; /* optional THIRD stream (ABI v12; device-word mode only): the step's Adam tail -- W_p0, W_q1 and the biases; it needs
                              * the backward's dh1 only -- runs there beside the sparse W_q0 gradient, the next call's catch-up and enc-0
-                             * (words 9 / 10); used when comm == NULL (or LTG_PIPE_TAIL_OWN).  NULL: the tail stays the step's last kernel on the caller's stream */
+                             * (words 9 / 10); used with LTG_PIPE_TAIL_OWN only.  NULL: the tail is the step's last kernel on the caller's stream */
     /* catch-up ahead (ABI v13; all optional, see above) */
     int32_t* q0_mark;           /* [n_items] int32, zeroed by the caller (and again whenever seq restarts): ordinal of the last call whose batch holds the row */
     const int32_t* next_uitem;  /* the NEXT call's ltg_batch.uitem (its distinct local items) or NULL */
     int32_t next_nu;            /* ... and its n_unique */
     int32_t caught_up;          /* 1: the previous call on this pipe was given THIS batch as next_uitem / next_nu and gen->q0_ord moved by that call only */
+    /* second shadow buffer (ABI v13; optional, device-word mode): [n_items][608] bf16 like gen->wp1t_bf16, K padding zero.  The weight update
+     * of the call writes the new shadow rows HERE instead of in place, so it starts when dlogits is complete -- beside the dh2 product, the
+     * last reader of gen->wp1t_bf16 -- instead of behind it.  AFTER the call the caller exchanges gen->wp1t_bf16 and shadow_out. */
+    uint16_t* shadow_out;
 } ltg_pipe;
 #define LTG_PIPE_NO_DEC1_FORK 1  /* everything on the caller's stream, in program order */
 #define LTG_PIPE_NO_SLICE_FORK 2 /* the lazy clock's slice on the caller's stream, at the end of its own step */
@@ -479,13 +483,17 @@ typedef struct ltg_pipe {
                                       side stream between the catch-up of call t and that of call t + 1 */
 #define LTG_PIPE_EVENTS 16       /* fork and join of the weight update as hipEventRecord / hipStreamWaitEvent pairs instead of device words */
 #define LTG_PIPE_WIDE_GRAD 8     /* the sparse W_q0 gradient in its column-blocked shape (three times the waves) although it runs beside the update */
-#define LTG_PIPE_TAIL_INLINE 64  /* the Adam tail on the caller's stream although the pipe has a tail stream */
-#define LTG_PIPE_TAIL_OWN 128    /* ... on the tail stream also WITH a communicator (default there: inline -- measured, see ltg_g_step_sharded) */
+#define LTG_PIPE_TAIL_OWN 128    /* the Adam tail on ltg_pipe.tail_stream (default: the step's last kernel on the caller's stream -- measured, see ltg_g_step_sharded) */
 /* bits 8-16 of flags: persistent workgroups of the forked weight update (0 = the library's choice) */
 
 int ltg_g_step_sharded_ok(const ltg_config* cfg, const ltg_gen_state* gen, int32_t n_rows);
-/* 1: ltg_g_step_sharded with this batch and this pipe (next_uitem set) brings the announced rows up to date, and honours caught_up */
-int ltg_g_step_sharded_ahead_ok(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pipe* pipe);
+/* What ltg_g_step_sharded will do with this batch and this pipe (the caller's bookkeeping depends on it), bits:
+ *   LTG_PLAN_AHEAD   it brings the rows announced in next_uitem up to date and honours caught_up
+ *   LTG_PLAN_SHADOW  its weight update writes pipe->shadow_out (the caller exchanges it with gen->wp1t_bf16 after the call)
+ * 0 also when the call would be refused. */
+#define LTG_PLAN_AHEAD 1
+#define LTG_PLAN_SHADOW 2
+int ltg_g_step_sharded_plan(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* batch, const ltg_pipe* pipe);
 int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* batch,
                        const ltg_pairs* fake, const ltg_g_opts* opts, const ltg_gen_acts* acts, const ltg_comm* comm,
                        const ltg_pipe* pipe, float* loss_out, void* ws, size_t ws_bytes, ltg_stream stream);

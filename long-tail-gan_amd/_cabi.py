@@ -15,6 +15,7 @@ LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
 LTG_ABI_VERSION = 13
+LTG_PLAN_AHEAD, LTG_PLAN_SHADOW = 1, 2
 LTG_Q0_HIST = 1024
 
 ERRORS = {0: "LTG_OK", -1: "LTG_EINVAL", -2: "LTG_EWORKSPACE", -3: "LTG_ELAUNCH"}
@@ -90,7 +91,7 @@ class ltg_sample_inputs(C.Structure):
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, C.c_int, vp, vp)
 LTG_NCCL_FLOAT32, LTG_NCCL_SUM = 7, 0
-LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH, LTG_PIPE_TAIL_INLINE, LTG_PIPE_TAIL_OWN = 1, 2, 8, 16, 32, 64, 128
+LTG_PIPE_NO_DEC1_FORK, LTG_PIPE_NO_SLICE_FORK, LTG_PIPE_WIDE_GRAD, LTG_PIPE_EVENTS, LTG_PIPE_SLICE_IN_TOUCH, LTG_PIPE_TAIL_OWN = 1, 2, 8, 16, 32, 128
 
 
 class ltg_comm(C.Structure):
@@ -100,13 +101,13 @@ class ltg_comm(C.Structure):
 class ltg_pipe(C.Structure):
     _fields_ = [("side_stream", vp), ("ev_fork", vp), ("ev_dec1", vp), ("ev_tail", vp),
                 ("h1pre", vp), ("rowpart_all", vp), ("dh2", vp), ("flags", C.c_int32), ("seq", C.c_uint32), ("sync", vp), ("tail_stream", vp),
-                ("q0_mark", vp), ("next_uitem", vp), ("next_nu", C.c_int32), ("caught_up", C.c_int32)]
+                ("q0_mark", vp), ("next_uitem", vp), ("next_nu", C.c_int32), ("caught_up", C.c_int32), ("shadow_out", vp)]
 
 
 # every symbol include/ltg.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ltg_g_step_sharded_ok": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.c_int32]),
-    "ltg_g_step_sharded_ahead_ok": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pipe)]),
+    "ltg_g_step_sharded_plan": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pipe)]),
     "ltg_g_step_sharded": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state), C.POINTER(ltg_batch),
                                      C.POINTER(ltg_pairs), C.POINTER(ltg_g_opts), C.POINTER(ltg_gen_acts), C.POINTER(ltg_comm),
                                      C.POINTER(ltg_pipe), vp, vp, C.c_size_t, vp]),

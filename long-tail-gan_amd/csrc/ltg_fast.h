@@ -1379,40 +1379,51 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
 // not set fk_g_tail's register count).  Same bits as the partial rows: ENC0_BIAS_PARTS parts of `per` batch rows, each a serial sum from
 // zero in the gradient kernel's light-row order (per <= G0_LIGHT, checked by the caller; a row past the end counts with weight 0), the
 // parts added in ascending order.
+// Shape: one thread per (float4 column, part) -- 32 columns x ENC0_BIAS_PARTS parts per workgroup, the part's rows requested at once, the
+// parts added through LDS in ascending order (one thread walking all the parts took eight dependent round trips: 11.7 us on the tail
+// stream, in front of the word the next call's enc-0 polls for).
+constexpr int Q0B_COLS = NT / 8;
 __global__ __launch_bounds__(NT) void fk_q0_bias_from_da1(int B, int H, const float* __restrict__ da1, ltg_gen_state st, AdamC ad,
                                                           const unsigned* __restrict__ poison) {
+    static_assert(Q0B_COLS * 8 == NT && ENC0_BIAS_PARTS == 8, "one thread per (column, part)");
+    __shared__ float4 parts[8][Q0B_COLS];
     if (ltg_poisoned(poison)) return;
     const int H4 = H >> 2, per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
+    const int cl = threadIdx.x % Q0B_COLS, pj = threadIdx.x / Q0B_COLS, c = blockIdx.x * Q0B_COLS + cl;
+    const float4* D4 = reinterpret_cast<const float4*>(da1);
+    {
+        float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r0 = min(B, pj * per), r1 = min(B, (pj + 1) * per);
+        float4 d[G0_LIGHT];
+#pragma unroll
+        for (int t = 0; t < G0_LIGHT; ++t) d[t] = D4[(size_t)min(r0 + t, B - 1) * H4 + min(c, H4 - 1)];
+#pragma unroll
+        for (int t = 0; t < G0_LIGHT; ++t) {
+            const float sc = r0 + t < r1 ? 1.f : 0.f;
+            sp.x = __builtin_fmaf(sc, d[t].x, sp.x); sp.y = __builtin_fmaf(sc, d[t].y, sp.y);
+            sp.z = __builtin_fmaf(sc, d[t].z, sp.z); sp.w = __builtin_fmaf(sc, d[t].w, sp.w);
+        }
+        parts[pj][cl] = sp;
+    }
+    __syncthreads();
+    if (pj != 0 || c >= H4) return;
     float4* b4 = reinterpret_cast<float4*>(st.p[4]);
     float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
     float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
-    const float4* D4 = reinterpret_cast<const float4*>(da1);
-    for (int c = blockIdx.x * NT + threadIdx.x; c < H4; c += gridDim.x * NT) {
-        float4 p = b4[c], mm = mb4[c], vv = vb4[c];
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pj = 0; pj < ENC0_BIAS_PARTS; ++pj) {
-            float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int r0 = min(B, pj * per), r1 = min(B, (pj + 1) * per);
-            float4 d[G0_LIGHT];
+    float4 p = b4[c], mm = mb4[c], vv = vb4[c];
+    float4 g = parts[0][cl];
 #pragma unroll
-            for (int t = 0; t < G0_LIGHT; ++t) d[t] = D4[(size_t)min(r0 + t, B - 1) * H4 + c];
-#pragma unroll
-            for (int t = 0; t < G0_LIGHT; ++t) {
-                const float sc = r0 + t < r1 ? 1.f : 0.f;
-                sp.x = __builtin_fmaf(sc, d[t].x, sp.x); sp.y = __builtin_fmaf(sc, d[t].y, sp.y);
-                sp.z = __builtin_fmaf(sc, d[t].z, sp.z); sp.w = __builtin_fmaf(sc, d[t].w, sp.w);
-            }
-            if (pj == 0) g = sp;
-            else { g.x += sp.x; g.y += sp.y; g.z += sp.z; g.w += sp.w; }
-        }
-        adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
-        adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
-        adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
-        adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
-        b4[c] = p;
-        mb4[c] = mm;
-        vb4[c] = vv;
+    for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
+        const float4 sp = parts[j][cl];
+        g.x += sp.x; g.y += sp.y; g.z += sp.z; g.w += sp.w;
     }
+    adam1(p.x, mm.x, vv.x, g.x, ad.lr_t, ad);
+    adam1(p.y, mm.y, vv.y, g.y, ad.lr_t, ad);
+    adam1(p.z, mm.z, vv.z, g.z, ad.lr_t, ad);
+    adam1(p.w, mm.w, vv.w, g.w, ad.lr_t, ad);
+    b4[c] = p;
+    mb4[c] = mm;
+    vb4[c] = vv;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -532,9 +532,13 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
 // that follows on the critical stream reads 23.5 MB instead of 47) and half the accumulator registers (76 instead of 152)
 template <bool D16, int NH = 1>
 __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int chunk, const float* __restrict__ dlog,
-                                                      const unsigned short* __restrict__ Wb, float* __restrict__ part) {
+                                                      const unsigned short* __restrict__ Wb, float* __restrict__ part,
+                                                      LtgGate started = LTG_NO_GATE) {
     extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    // started: opened by the first workgroup as soon as this kernel runs -- dlogits is complete.  With TWO shadow buffers (ltg_pipe.shadow_out)
+    // that is all the forked weight update waits for: it writes the other buffer while this product reads Wb.
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) ltg_gate_set(started);
     constexpr int NTL = ST_KP / 16 / NH;  // 38 (19) column tiles of the accumulator
     const int half = NH == 2 ? (int)blockIdx.y : 0;
     auto fetch_w = [&](int i0_, StW& r_) {
@@ -3265,7 +3269,7 @@ static void g_jobs(int stage, const ltg_config* cfg, const ltg_gen_state* gen, c
     if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_g_tail<true>, g, dim3(NT), 0, st, a, *gen, ad);
     else hipLaunchKernelGGL(fk_g_tail<false>, g, dim3(NT), 0, st, a, *gen, ad);
     if ((stage == 2 || all) && q0_bias && bias_from_da1)
-        hipLaunchKernelGGL(fk_q0_bias_from_da1, dim3(1), dim3(NT), 0, st, B, H, w.da1, *gen, ad, poison);
+        hipLaunchKernelGGL(fk_q0_bias_from_da1, dim3(((H >> 2) + Q0B_COLS - 1) / Q0B_COLS), dim3(NT), 0, st, B, H, w.da1, *gen, ad, poison);
     pr.after(kid);
 }
 
@@ -3631,8 +3635,15 @@ static bool q0_ahead_capable(const ltg_config* cfg, const ltg_gen_state* gen, co
     if (fl & (LTG_PIPE_NO_DEC1_FORK | LTG_PIPE_NO_SLICE_FORK | LTG_PIPE_EVENTS | LTG_PIPE_SLICE_IN_TOUCH)) return false;
     return q0_lazy(cfg, gen) && (cfg->h_enc >> 2) <= Q0_NT;
 }
-int ltg_g_step_sharded_ahead_ok(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pipe* pp) {
-    return (cfg_ok(cfg) && gen && bt && pp && ltg_g_step_sharded_ok(cfg, gen, bt->n_rows) && q0_ahead_capable(cfg, gen, bt, pp)) ? 1 : 0;
+// the pipe's hand-overs are device words (not events, not program order)
+static bool pipe_gates(const ltg_pipe* pp) { return pp->sync && (pp->flags & (LTG_PIPE_NO_DEC1_FORK | LTG_PIPE_EVENTS)) == 0; }
+// the weight update writes the pipe's second shadow buffer
+static bool shadow_pingpong(const ltg_gen_state* gen, const ltg_pipe* pp) {
+    return pipe_gates(pp) && pp->shadow_out && gen->wp1t_bf16 && pp->shadow_out != gen->wp1t_bf16;
+}
+int ltg_g_step_sharded_plan(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_batch* bt, const ltg_pipe* pp) {
+    if (!cfg_ok(cfg) || !gen || !bt || !pp || !ltg_g_step_sharded_ok(cfg, gen, bt->n_rows)) return 0;
+    return (q0_ahead_capable(cfg, gen, bt, pp) ? LTG_PLAN_AHEAD : 0) | (shadow_pingpong(gen, pp) ? LTG_PLAN_SHADOW : 0);
 }
 
 int ltg_g_pipe_probe(const ltg_pipe* pipe, ltg_stream stream) {
@@ -3725,11 +3736,12 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // the Adam tail (W_p0, W_q1, the biases: it needs dh1's outputs only) on its OWN stream beside the sparse gradient kernel, the next
     // call's catch-up and enc-0; needs <= G0_LIGHT batch rows per partial bias row (its bias job then re-sums them in the same order)
     hipStream_t stl = (hipStream_t)pp->tail_stream;
-    // Without a communicator only: with the three RCCL kernels in the stream the per-rank proxy measured 163.4-163.5 us per step with the
-    // tail on its own stream against 160.5-161.1 with it inline (three interleaved rounds, one box), the unsharded 20 000-item step
-    // 146.0-147.1 against 150.9-151.9.  (LTG_PIPE_TAIL_OWN forces it with a communicator, LTG_PIPE_TAIL_INLINE without.)
-    const bool tail_own = gates && side_slice && stl && pp->ev_tail && (pp->flags & (LTG_PIPE_TAIL_INLINE | LTG_PIPE_WIDE_GRAD)) == 0 &&
-                          (!comm || (pp->flags & LTG_PIPE_TAIL_OWN) != 0) &&
+    // OPT-IN (LTG_PIPE_TAIL_OWN).  It was the default without a communicator while the catch-up launch led the critical stream (20 000 items:
+    // 146.0-147.1 against 150.9-151.9 us per step).  With the catch-up ahead and two shadow buffers the tail's own chain -- waiter, tail, bias
+    // kernel, word 10 -- is what the next enc-0 then waits for: 20 000 items 142.0-143.6 on its own stream against 139.1-139.5 inline (equal,
+    // 138.7-140.4 / 138.1-140.6, once the bias kernel was spread over 8 x as many threads), 200 000 items 802-825 against 745-767; with the
+    // three RCCL calls in the stream (per-rank proxy) 154.4-157.0 against 154.6-155.1.
+    const bool tail_own = gates && side_slice && stl && pp->ev_tail && (pp->flags & LTG_PIPE_TAIL_OWN) != 0 && (pp->flags & LTG_PIPE_WIDE_GRAD) == 0 &&
                           (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS <= G0_LIGHT;
 #define LTG_HIP(x) do { if ((x) != hipSuccess) return LTG_ELAUNCH; } while (0)
 #define LTG_COMM(x) do { if ((x) != 0) return LTG_ELAUNCH; } while (0)
@@ -3761,6 +3773,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         fwd_stage_enc(cfg, gen, bt, &o->fwd, &a1, 1, st, nullptr, true, side_slice ? LtgGate{pp->sync + 5, pp->seq, nullptr, 0} : LTG_NO_GATE,
                       tail_own ? LtgGate{pp->sync + 10, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE);
     }
+    // (Round 4, measured and removed: the clock's kernels on the pipe's THIRD stream instead of between two weight updates on the side
+    // stream -- 142.8-143.4 against 141.4-142.4 us per step at 20 000 items, 155.3-156.7 against 155.1-157.2 at 25 024: no difference.  What
+    // bounds the step at these sizes is the cycle update -> streaming forward -> dlogits -> dh2 product -> update, not either stream's load.)
     if (side_slice) {
         const int start = gen->q0_ord % qP;
         hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
@@ -3801,8 +3816,12 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
                        w.dlog, acts->lse, w.scal, loss_out, cfg->item_lo);
     {
         const int kchunk = dh2_stream_chunk(I), nsplit = (I + kchunk - 1) / kchunk;
+        // Two shadow buffers (ltg_pipe.shadow_out): the update of this call writes the OTHER buffer, so the dh2 product -- the last reader of
+        // this call's shadow -- leaves the cycle update -> streaming forward -> dlogits -> [dh2 product] -> update that bounds the step at
+        // 20 000 - 25 000 items: the update's gate (word 0) opens when the product STARTS (dlogits is complete), not when it has ended.
+        const bool pingpong = gates && shadow_pingpong(gen, pp);
         LTG_PROBED(pr, LTG_K_DH2, hipLaunchKernelGGL((k_dh2_stream<true, DH2_NH>), dim3(nsplit, DH2_NH), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk,
-                                                     w.dlog, gen->wp1t_bf16, w.part));
+                                                     w.dlog, gen->wp1t_bf16, w.part, pingpong ? LtgGate{pp->sync, pp->seq, nullptr, 0} : LTG_NO_GATE));
         // ---- ONE fork, behind the dh2 product (the last reader of this step's W_p1t shadow), onto the side stream:
         //   (1) the clock slice of the PREVIOUS step -- rows i = q0_ord (mod period) up to q0_ord; every row of this batch is at q0_ord
         //       already (q0_touch), so the slice skips them whatever the rest of this step does to them; joined at the start of the next
@@ -3816,7 +3835,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         const int n_da2 = B * H;
         if (gates)   // the slab sum first: it is the next kernel of the critical stream, the side stream's launches take the host ~30 us
             hipLaunchKernelGGL(k_da2, dim3((n_da2 + NT - 1) / NT < 2048 ? (n_da2 + NT - 1) / NT : 2048), dim3(NT), 0, st, n_da2, nsplit, w.part, (const float*)nullptr,
-                               pp->dh2, LtgGate{pp->sync, pp->seq, nullptr, 0});
+                               pp->dh2, pingpong ? LTG_NO_GATE : LtgGate{pp->sync, pp->seq, nullptr, 0});
         if (gates) {   // the side stream's work starts behind a one-wave kernel that polls the word the slab sum (below) sets when it starts
             hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync, pp->seq, pp->sync + 2, 0},
                                side_slice ? LtgGate{pp->sync + 6, pp->seq, nullptr, 0} : LTG_NO_GATE);
@@ -3829,11 +3848,20 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
         // (a ragged slab's last I % 32 rows go through the generic tile kernel behind the streaming one, and that reads h2 throughout:
         // word 1 then opens with word 7)
         const bool h2_early = gates && (I % 32) == 0;
+        // (Round 4, measured and removed: word 7 stored by the update's LAST workgroup -- every thread releases its stores at agent scope,
+        // the workgroups count themselves -- instead of by a kernel behind it: 142 -> 184 us per step at 20 000 items, 155 -> 195 at
+        // 25 024, 749 -> 856 at 200 000: 1 256 waves each writing the dirty lines of an L2 back cost far more than the ~4 us the word opens earlier.)
         const LtgH2Done hd_last = h2_early ? LtgH2Done{pp->sync + 8, pp->sync + 1, pp->seq, poison} : LtgH2Done{nullptr, nullptr, 0u, poison};
-        const int rc = g_stage_bwd_rest(cfg, gen, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups, hd_last);
+        ltg_gen_state gen_dw = *gen;
+        if (pingpong) gen_dw.wp1t_bf16 = pp->shadow_out;   // (the caller exchanges the two pointers after the call)
+        const int rc = g_stage_bwd_rest(cfg, &gen_dw, bt, &od, acts, nullptr, w, sdw, true, true, dw_groups, hd_last);
         if (rc != LTG_OK) return rc;
-        if (gates) hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 7, pp->seq, nullptr, 0},
-                                      h2_early ? LTG_NO_GATE : LtgGate{pp->sync + 1, pp->seq, nullptr, 0});
+        // (Round 4, measured and removed: word 7 stored by the NEXT call's first waiter on the side stream when it starts, instead of by one
+        // wave behind the update: 149.8 against 146.8 us per step at 20 000 items, 165.7 against 161.5 at 25 024 -- slower; and a host that is
+        // not launches ahead of the device, a two-rank rig with host-side exchanges, stalls dec-0 on it.)
+        if (gates)
+            hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 7, pp->seq, nullptr, 0},
+                               h2_early ? LTG_NO_GATE : LtgGate{pp->sync + 1, pp->seq, nullptr, 0});
         else if (fork_dec1) LTG_HIP(hipEventRecord(ev_dec1, sd));
         if (!gates)
             hipLaunchKernelGGL(k_da2, dim3((n_da2 + NT - 1) / NT < 2048 ? (n_da2 + NT - 1) / NT : 2048), dim3(NT), 0, st, n_da2, nsplit, w.part, (const float*)nullptr,

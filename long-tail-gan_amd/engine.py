@@ -123,8 +123,8 @@ class Pipe:
         from ._hip import EventPair
         dev = engine.device
         self.side_stream = torch.cuda.Stream(dev)
-        # the Adam tail's own stream (device-word hand-over only; LTGAN_TAIL_STREAM=0: the tail stays on the caller's stream)
-        self.tail_stream = torch.cuda.Stream(dev) if os.environ.get("LTGAN_TAIL_STREAM", "1") != "0" else None
+        # the Adam tail's own stream: only with LTG_PIPE_TAIL_OWN (device-word hand-over; the default keeps the tail on the caller's stream)
+        self.tail_stream = torch.cuda.Stream(dev) if (int(flags) & cabi.LTG_PIPE_TAIL_OWN) else None
         self._ev = (EventPair(timing=False), EventPair(timing=False))     # (fork, dec1), (tail, -)
         f = dict(dtype=torch.float32, device=dev)
         self.h1pre = torch.zeros(rows, engine.H, **f)
@@ -137,6 +137,11 @@ class Pipe:
                                _ptr(self.rowpart_all), _ptr(self.dh2), int(flags), 0, _ptr(self.sync),
                                self.tail_stream.cuda_stream if self.tail_stream is not None else None,
                                _ptr(self.q0_mark) if self.q0_mark is not None else None, None, 0, 0)
+        # second shadow buffer of W_p1t (include/ltg.h: ltg_pipe.shadow_out): the weight update of a call writes it and the two are exchanged
+        # after the call, so the update starts beside the dh2 product instead of behind it.  LTGAN_SHADOW_PINGPONG=0: in place.
+        self.shadow = (torch.zeros_like(engine.g_shadow) if engine.g_shadow is not None and os.environ.get("LTGAN_SHADOW_PINGPONG", "1") != "0"
+                       else None)
+        self.c.shadow_out = _ptr(self.shadow) if self.shadow is not None else None
         self.ahead = None           # (uitem address, n_unique, q0_ord, seq) of the call whose rows the last call brought up to date
         self.ahead_calls = 0        # calls that launched no catch-up of their own
         self.probed_for = None      # the caller's stream the side stream was last tested against (Engine._pipe_ready)
@@ -515,6 +520,8 @@ class Engine:
         for pipe in list(self._pipes) + ([self._dfork] if self._dfork is not None else []):
             n = pipe.expired_waits()
             if n:
+                torch.cuda.synchronize(self.device)
+                self.refresh_shadow()      # (a skipped weight update did not write the shadow buffer the host has switched to since)
                 raise cabi.LtgError("%d device-side wait(s) of a step's hand-overs gave up: the steps behind them were skipped, "
                                     "the results of that phase are not trustworthy" % n)
 
@@ -552,8 +559,8 @@ class Engine:
         pipe.ahead_calls += pipe.c.caught_up
         pipe.ahead = None
         pipe.c.next_uitem, pipe.c.next_nu = None, 0
-        if (next_batch is not None and pipe.q0_mark is not None and next_batch.c.uitem and self.q0_defer and
-                self.lib.ltg_g_step_sharded_ahead_ok(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(pipe.c)) == 1):
+        plan = self.lib.ltg_g_step_sharded_plan(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(pipe.c))
+        if next_batch is not None and next_batch.c.uitem and self.q0_defer and (plan & cabi.LTG_PLAN_AHEAD):
             pipe.c.next_uitem, pipe.c.next_nu = next_batch.c.uitem, int(next_batch.c.n_unique)
             pipe.ahead = (next_batch.c.uitem, int(next_batch.c.n_unique), int(self.gen_c.q0_ord) + 1, (int(pipe.c.seq) + 1) & 0xFFFFFFFF)
         rc = self.lib.ltg_g_step_sharded(C.byref(self.cfg), C.byref(self.gen_c), C.byref(self.disc_c), C.byref(batch.c), C.byref(fake.c),
@@ -561,11 +568,20 @@ class Engine:
                                          _ptr(loss_out), _ptr(ws), ws.numel(), self.stream())
         if rc != 0:
             pipe.reset()               # (the call may have stopped between its gate launches: words of this ordinal that nobody will set)
+            self.refresh_shadow()      # (... or between the update's launch and the exchange below)
         cabi.check(rc, "ltg_g_step_sharded")
+        if plan & cabi.LTG_PLAN_SHADOW:    # the update wrote the pipe's buffer: it is the shadow from now on, the old one the next call's target
+            self.g_shadow, pipe.shadow = pipe.shadow, self.g_shadow
+            self.gen_c.wp1t_bf16, pipe.c.shadow_out = _ptr(self.g_shadow), _ptr(pipe.shadow)
         if not self.q0_defer:
             self.pipe_join(pipe)       # a standalone step: nothing stays in flight behind the call (a trainer joins once per phase)
         self._q0_stepped()             # (standalone: flushes the clock and checks the pipe's poison -- g_flush)
         return loss_out
+
+    def refresh_shadow(self):
+        """the bf16 shadow of W_p1t rebuilt from the fp32 rows (after loading weights; after a failed pipelined call)"""
+        if self.g_shadow is not None:
+            cabi.check(self.lib.ltg_refresh_shadow(C.byref(self.cfg), C.byref(self.gen_c), self.stream()), "ltg_refresh_shadow")
 
     def _pipe_ready(self, pipe):
         """The device-word hand-over of ltg_g_step_sharded needs two CONCURRENT streams; HIP maps streams onto a few hardware queues, so

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(cabi.ltg_sample_inputs) == 8 + 7 * 8 + 8 + 3 * 8 + 8
     assert C.sizeof(cabi.ltg_probe) == 8 + 16
     assert C.sizeof(cabi.ltg_comm) == 8 + 8 + 2 * 8 and cabi.ltg_comm.all_reduce.offset == 16
-    assert C.sizeof(cabi.ltg_pipe) == 7 * 8 + 8 + 8 + 8 + 8 + 8 + 8 and cabi.ltg_pipe.q0_mark.offset == 80 and cabi.ltg_pipe.next_nu.offset == 96 and cabi.ltg_pipe.caught_up.offset == 100 and cabi.ltg_pipe.tail_stream.offset == 72 and cabi.ltg_pipe.h1pre.offset == 32 and cabi.ltg_pipe.flags.offset == 56 and cabi.ltg_pipe.seq.offset == 60 and cabi.ltg_pipe.sync.offset == 64
+    assert C.sizeof(cabi.ltg_pipe) == 7 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 and cabi.ltg_pipe.shadow_out.offset == 104 and cabi.ltg_pipe.q0_mark.offset == 80 and cabi.ltg_pipe.next_nu.offset == 96 and cabi.ltg_pipe.caught_up.offset == 100 and cabi.ltg_pipe.tail_stream.offset == 72 and cabi.ltg_pipe.h1pre.offset == 32 and cabi.ltg_pipe.flags.offset == 56 and cabi.ltg_pipe.seq.offset == 60 and cabi.ltg_pipe.sync.offset == 64
 
 
 def test_struct_layouts_match_the_header_as_gcc_lays_it_out(tmp_path):

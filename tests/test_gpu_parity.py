@@ -1013,10 +1013,10 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
     # find an item through uptr -> csr_pos -> indices, as before
     # "-wide-grad": the sparse gradient in its column-blocked shape (the default of the one-call step is one wave per row over all columns)
     # "-events": fork / join of the weight update as event pairs instead of device words
-    # "-tail-inline": the Adam tail as the step's last kernel on the caller's stream (the default runs it on its own stream beside the sparse
-    # gradient kernel and the next call's catch-up, its bias job re-summing the partial bias rows in the gradient kernel's order)
+    # "-tail-own": the Adam tail on the pipe's third stream beside the sparse gradient kernel and the next call's enc-0, its bias job re-summing
+    # the partial bias rows in the gradient kernel's order (the default: the step's last kernel on the caller's stream)
     pipe_flags = {"one-call": 0, "one-call-events": cabi_flags("LTG_PIPE_EVENTS"), "one-call-slice-in-touch": cabi_flags("LTG_PIPE_SLICE_IN_TOUCH"),
-                  "one-call-no-uitem": 0, "one-call-tail-inline": cabi_flags("LTG_PIPE_TAIL_INLINE"),
+                  "one-call-no-uitem": 0, "one-call-tail-own": cabi_flags("LTG_PIPE_TAIL_OWN"),
                   "one-call-wide-grad": cabi_flags("LTG_PIPE_WIDE_GRAD")}
     for variant in ("dense", "lazy", "lazy-no-uitem") + (tuple(pipe_flags) if precision == "bf16" else ()):
         lazy = variant != "dense"

@@ -21,8 +21,8 @@ def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mo
     over item slabs large enough for the streaming decoder kernels and the lazy Adam clock of W_q0; "wide_fp8_full": the same with
     config 5's full sizes (2048, 1024, 512, 256).  bf16 slabs of 8192 items or more run the G step as ONE call with the exchanges
     issued from inside it (ltg_g_step_sharded; here through host callbacks over gloo); "cutpoints": the five-call sequence with
-    torch.distributed collectives instead.  ("c4", 200 users): BASELINE config 4's 200 000 items, 100 000 per rank.  "tail_own": the Adam tail on its own stream although the step has a communicator
-    (LTG_PIPE_TAIL_OWN; the default with a communicator keeps it on the caller's stream)."""
+    torch.distributed collectives instead.  ("c4", 200 users): BASELINE config 4's 200 000 items, 100 000 per rank.  "tail_own": the Adam tail on the pipe's third stream
+    (LTG_PIPE_TAIL_OWN; the default keeps it on the caller's stream)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if mode == "tail_own":
         env["LTGAN_PIPE_FLAGS"] = "128"

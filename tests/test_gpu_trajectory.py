@@ -213,18 +213,19 @@ def test_an_expired_device_side_wait_is_reported_by_the_trainer():
     assert tr.pipe.expired_waits() == 0 and tr.pipe.c.seq == 0 and int(tr.pipe.sync.abs().sum().item()) == 0
 
 
-@pytest.mark.parametrize("queues,expect", [("1", "events\n"), ("2", "device-words\n"), ("4", "device-words + tail stream\n")])
-def test_one_call_step_falls_back_to_events_when_its_streams_share_a_hardware_queue(queues, expect):
+@pytest.mark.parametrize("queues,flags,expect", [("1", "0", "events\n"), ("2", "0", "device-words\n"), ("2", "128", "device-words\n"),
+                                                 ("4", "128", "device-words + tail stream\n")])
+def test_one_call_step_falls_back_to_events_when_its_streams_share_a_hardware_queue(queues, flags, expect):
     """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues.  With ONE, a waiter on the side stream sits in front of its producer in
     the same queue: ltg_g_pipe_probe must see that and the engine must fall back to event pairs; with TWO the side stream gets a queue
-    of its own but the Adam tail's stream cannot (the tail then stays on the caller's stream); with four all three streams run
-    concurrently -- with the same bits as the step-by-step loop in every mode (scripts/soak_onecall.py compares every tensor).  A fresh
+    of its own but the Adam tail's stream (LTG_PIPE_TAIL_OWN = 128, opt-in) cannot (the tail then stays on the caller's stream); with four
+    all three streams run concurrently -- with the same bits as the step-by-step loop in every mode (scripts/soak_onecall.py compares every tensor).  A fresh
     process: the variable is read at HIP start-up."""
     import os
     import subprocess
     import sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, LTGAN_PIPE_FLAGS=flags)
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_onecall.py"), "9000", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout.replace(" expired", "\n expired")
