@@ -3776,6 +3776,9 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // (Round 4, measured and removed: the clock's kernels on the pipe's THIRD stream instead of between two weight updates on the side
     // stream -- 142.8-143.4 against 141.4-142.4 us per step at 20 000 items, 155.3-156.7 against 155.1-157.2 at 25 024: no difference.  What
     // bounds the step at these sizes is the cycle update -> streaming forward -> dlogits -> dh2 product -> update, not either stream's load.)
+    // (... nor did starting them late, behind word 0 on the third stream -- beside the weight update and the backward chain instead of beside
+    // the streaming forward, the row statistics and dlogits: 142.2-142.7 against 139.2-139.7 us at 20 000 items, 159.2-159.4 against
+    // 157.7-158.8 at 25 024, 831-833 against 823 at 200 000.)
     if (side_slice) {
         const int start = gen->q0_ord % qP;
         hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
