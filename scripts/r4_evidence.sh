@@ -25,7 +25,7 @@ done
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/$O/trace_mid -- python3 $R/bench.py --workload custom:25024 --parallelism item-shard --steps 1 --warmup 1 --no-probe --no-cpu-baseline --no-other-workloads > $R/$O/trace_mid.log 2>&1
 cd $R
-f=$(find $O/trace_mid -name "*kernel_trace.csv" | head -1); python profiles/make_timeline.py "$f" k_q0_touch_unique 2 > $O/r4_mid25k_timeline.txt; rm -rf $O/trace_mid
+f=$(find $O/trace_mid -name "*kernel_trace.csv" | head -1); python profiles/make_timeline.py "$f" fk_enc0_fwd 2 > $O/r4_mid25k_timeline.txt; rm -rf $O/trace_mid
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/$O/trace_ask -- python3 $R/bench.py --steps 1 --warmup 1 --no-probe --no-cpu-baseline --no-other-workloads > $R/$O/trace_ask.log 2>&1
 cd $R
