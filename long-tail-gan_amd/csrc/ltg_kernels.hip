@@ -3779,13 +3779,17 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // (... nor did starting them late, behind word 0 on the third stream -- beside the weight update and the backward chain instead of beside
     // the streaming forward, the row statistics and dlogits: 142.2-142.7 against 139.2-139.7 us at 20 000 items, 159.2-159.4 against
     // 157.7-158.8 at 25 024, 831-833 against 823 at 200 000.)
+    // (... and again with two shadow buffers in, when the side stream runs back to back -- update, slice, catch-up ahead, three one-wave
+    // kernels = the step's length: the clock's kernels on the third stream then start earlier, beside the previous update's last third:
+    // 143.1-147.3 against 137.8-138.9 us at 20 000 items, 153.5-154.3 against 152.2-153.5 at 25 024, 746-806 against 762-817 at 200 000.)
     if (side_slice) {
         const int start = gen->q0_ord % qP;
-        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sd, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
+        hipStream_t sc = sd;
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, sc, LtgGate{pp->sync + 5, pp->seq, pp->sync + 2, 0}, LTG_NO_GATE);
         if (gen->q0_ord > 0 && start < I)
-            hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sd, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1), poison);
+            hipLaunchKernelGGL(k_q0_sweep, dim3((I - start + qP - 1) / qP), dim3(Q0_NT), 0, sc, I, H, start, qP, gen->q0_ord, *gen, make_adam(cfg, 1), poison);
         if (ahead && pp->next_uitem && pp->next_nu > 0)
-            hipLaunchKernelGGL(k_q0_touch_ahead, dim3(pp->next_nu), dim3(Q0_NT), 0, sd, H, pp->next_nu, pp->next_uitem, gen->q0_ord + 1, *gen, ad, pp->q0_mark,
+            hipLaunchKernelGGL(k_q0_touch_ahead, dim3(pp->next_nu), dim3(Q0_NT), 0, sc, H, pp->next_nu, pp->next_uitem, gen->q0_ord + 1, *gen, ad, pp->q0_mark,
                                pp->seq, poison);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));

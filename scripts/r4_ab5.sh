@@ -20,6 +20,6 @@ for rep in 1 2 3; do
   for wl in "c3:--workload ml20m --users 6400" "mid:--workload custom:25024 --parallelism item-shard" "c4:--workload c4 --users 3200"; do
     name=${wl%%:*}; extra=${wl#*:}
     run ${name}_default X=1 -- $extra
-    run ${name}_clock_late LTGAN_PIPE_FLAGS=131072 -- $extra
+    run ${name}_clock_own LTGAN_PIPE_FLAGS=131072 -- $extra
   done
 done
