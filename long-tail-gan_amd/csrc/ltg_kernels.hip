@@ -803,6 +803,9 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
         const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                    \
         DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + 4 * w) * (ST_KP * 2), (unsigned)(rl * (ST_KP * 2) + 8 * ch)) = ltg_u32x2{pk.x, pk.y}; \
     }
+    /* (Round 4, measured and removed: BOTH register sets holding loads of the next tile through its MFMA phase -- its stages 0 and 1 requested at
+       the end of the current tile, 237 VGPRs, no scratch: 138.9-143.9 against 138.6-140.3 us per step at 20 000 items, 151.7-154.1 against
+       153.1-155.6 at 25 024, 766-800 against 781-785 at 200 000: noise.  Beside the chain the update is not short of bytes in flight.) */
 #define DW_STAGES() \
         DW_LD(B, t, 2, 2, lo)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
