@@ -25,6 +25,7 @@ for pipe in (False, True):
     tr.check_pipe()
     if pipe:
         print("hand-over:", tr.pipe.handover, "expired waits:", tr.pipe.expired_waits(), "steps:", tr.pipe.c.seq)
+        print("steps without a catch-up launch of their own:", tr.pipe.ahead_calls, "second shadow buffer:", tr.pipe.shadow is not None)
     runs.append([t.clone() for t in eng.g_p + eng.g_m + eng.g_v + eng.d_p])
 bad = [k for k, (x, y) in enumerate(zip(*runs)) if not torch.equal(x, y)]
 print("tensors:", len(runs[0]), "differing:", bad)
