@@ -100,6 +100,37 @@ def test_argument_validation_returns_codes_without_gpu():
     assert lib.ltg_rank_metrics(C.byref(good), None, None, None, 100, 20, 50, None, None) == -1
     assert lib.ltg_g_step_sharded(C.byref(good), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.ltg_g_step_sharded_ok(C.byref(good), None, 100) == 0 and lib.ltg_g_pipe_join(None, None) == -1
+    assert lib.ltg_g_step_sharded_plan(C.byref(good), None, None, None) == 0
+
+
+def test_one_call_step_plan_is_a_pure_function_of_its_arguments():
+    """ltg_g_step_sharded_plan (ABI v13) tells the host what a call will do -- catch the next batch's rows up ahead, write the second
+    shadow buffer -- so that the host's bookkeeping (caught_up, the exchange of the two shadow pointers) never guesses.  Host-only: the
+    pointers below are never dereferenced."""
+    from ltgan import _cabi as cabi
+    lib = cabi.load()
+    big = cabi.ltg_config(25024, 600, 200, 25024, 100, 150, 250, 300, 0, 0, 0, 0, 1, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
+    assert big.precision == cabi.LTG_PREC_BF16
+    fake = lambda k: 0x10000 * (k + 1)                       # distinct non-NULL addresses
+    arr = lambda o: (cabi.vp * 8)(*[fake(o + i) for i in range(8)])
+    gen = cabi.ltg_gen_state(arr(0), arr(8), arr(16), fake(30), fake(31), fake(32), 0, 32)
+    bt = cabi.ltg_batch(100, 50, fake(40), fake(41), None, None, fake(42), fake(43), fake(44), fake(45), fake(46))
+    assert lib.ltg_g_step_sharded_ok(C.byref(big), C.byref(gen), 100) == 1
+    pipe = lambda flags=0, sync=fake(50), mark=fake(51), shadow=fake(52): cabi.ltg_pipe(fake(60), fake(61), fake(62), None, fake(63), fake(64), fake(65),
+                                                                                       flags, 1, sync, None, mark, None, 0, 0, shadow)
+    plan = lambda p, b=bt: lib.ltg_g_step_sharded_plan(C.byref(big), C.byref(gen), C.byref(b), C.byref(p))
+    assert plan(pipe()) == cabi.LTG_PLAN_AHEAD | cabi.LTG_PLAN_SHADOW
+    assert plan(pipe(mark=None)) == cabi.LTG_PLAN_SHADOW and plan(pipe(shadow=None)) == cabi.LTG_PLAN_AHEAD
+    assert plan(pipe(shadow=fake(30))) == cabi.LTG_PLAN_AHEAD                  # the "second" buffer is the shadow itself: in place
+    for fl in (cabi.LTG_PIPE_EVENTS, cabi.LTG_PIPE_NO_DEC1_FORK):               # no device words: neither
+        assert plan(pipe(flags=fl)) == 0
+    assert plan(pipe(sync=None)) == 0
+    for fl in (cabi.LTG_PIPE_NO_SLICE_FORK, cabi.LTG_PIPE_SLICE_IN_TOUCH):      # the slice not on the side stream: no catch-up ahead
+        assert plan(pipe(flags=fl)) == cabi.LTG_PLAN_SHADOW
+    no_uitem = cabi.ltg_batch(100, 50, fake(40), fake(41), None, None, fake(42), fake(43), fake(44), fake(45), None)
+    assert plan(pipe(), no_uitem) == cabi.LTG_PLAN_SHADOW
+    small = cabi.ltg_config(1000, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1, 0, 1e-4, 0.9, 0.999, 1e-8, 1)
+    assert lib.ltg_g_step_sharded_plan(C.byref(small), C.byref(gen), C.byref(bt), C.byref(pipe())) == 0    # the call itself would be refused
 
 
 def test_checkpoint_rng_state_round_trips_as_plain_types():
