@@ -753,15 +753,15 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     // the tenth access mirror the last element: same load, same result, same store).  The gradient of element (row,
     // chunk) is fetched from the LDS slab of whichever wave computed that column block.  No lane predicates, no
     // wave-dependent branches: every s_waitcnt in the loop is an exact count.  theta / m / v travel in six
-    // software-pipelined stages (2+2+2+2+1+1 float4 per lane) alternating over two register sets; the loads of the
-    // next stage -- at the end of a tile: of the NEXT tile's first stage -- are issued before the current stage is
-    // consumed, so HBM requests stay in flight through the MFMA phase and the barriers.  (Deeper stages do not fit: the
-    // stationary fragments hold 80 of the 256 VGPRs.)
+    // software-pipelined stages (2+2+2+2+1+1 float4 per lane) rotating over three register sets; the loads of the stage
+    // after next -- at the end of a tile: of the NEXT tile's first two stages -- are issued before the current stage is
+    // consumed, so HBM requests stay in flight through the MFMA phase and the barriers.  (A fourth set does not fit: the
+    // stationary fragments hold 80 of the 256 VGPRs, the kernel uses 248.)
     float* Cw = Cs + w * (32 * DW_LDC);                        // this wave's product slab
     const int H4 = H >> 2, nel = 4 * H4;                       // float4 per row / per wave and tile (host: 9 * 64 < nel <= 10 * 64)
     const unsigned rowB = (unsigned)H * 4u;
     const unsigned lo = 16u * lane, lo9 = 16u * (unsigned)(min(576 + lane, nel - 1) - 576);
-    ltg_f32x4 Ap[2], Am[2], Av[2], Bp[2], Bm[2], Bv[2];
+    ltg_f32x4 Ap[2], Am[2], Av[2], Bp[2], Bm[2], Bv[2], Cp[2], Cm[2], Cv[2];
 #define DW_ADAM1(f)                                  \
     {                                                \
         float p_ = p.f, m_ = mm.f, v_ = v2.f;        \
@@ -803,37 +803,21 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
         const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                    \
         DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + 4 * w) * (ST_KP * 2), (unsigned)(rl * (ST_KP * 2) + 8 * ch)) = ltg_u32x2{pk.x, pk.y}; \
     }
-    /* (Round 4, measured and removed: BOTH register sets holding loads of the next tile through its MFMA phase -- its stages 0 and 1 requested at
-       the end of the current tile, 237 VGPRs, no scratch: 138.9-143.9 against 138.6-140.3 us per step at 20 000 items, 151.7-154.1 against
-       153.1-155.6 at 25 024, 766-800 against 781-785 at 200 000: noise.  Beside the chain the update is not short of bytes in flight.) */
+    // THREE register sets rotate over the six stages (A B C A B C: the next tile starts on A again), so two stages of loads are in flight
+    // behind the one being consumed and the next tile's first two stages through its MFMA phase: 248 VGPRs, no scratch.  Against two
+    // sets (round 4, interleaved, two boxes): 200 000 items 741-774 against 755-806 us per step, 20 000 and 25 024 items equal
+    // (138.0-142.6 / 137.5-139.2, 151.8-153.7 / 151.4-155.0).  (Two sets that only keep BOTH loaded through the MFMA phase: equal everywhere.)
+#define DW_SB __builtin_amdgcn_sched_barrier(0);
 #define DW_STAGES() \
-        DW_LD(B, t, 2, 2, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(A, t, 2, 0, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(A, t, 2, 4, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(B, t, 2, 2, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(B, t, 2, 6, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(A, t, 2, 4, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(A, t, 1, 8, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(B, t, 2, 6, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(B, t, 1, 9, lo9)                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(A, t, 1, 8, lo)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_LD(A, tn, 2, 0, lo) /* first stage of the next tile (of this one again at the end: unused) */             \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        DW_AP(B, t, 1, 9, lo9)                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);
-#define DW_FIRST(tt) DW_LD(A, tt, 2, 0, lo)
-    // one tile: set A holds the first stage of tile t (requested one stage earlier); six stages alternate A, B so the
-    // next tile starts on A again -- one loop body, no register-set swap (a swap would have to wait for loads in flight)
+        DW_LD(C, t, 2, 4, lo) DW_SB   DW_AP(A, t, 2, 0, lo) DW_SB \
+        DW_LD(A, t, 2, 6, lo) DW_SB   DW_AP(B, t, 2, 2, lo) DW_SB \
+        DW_LD(B, t, 1, 8, lo) DW_SB   DW_AP(C, t, 2, 4, lo) DW_SB \
+        DW_LD(C, t, 1, 9, lo9) DW_SB  DW_AP(A, t, 2, 6, lo) DW_SB \
+        DW_LD(A, tn, 2, 0, lo) DW_SB  DW_AP(B, t, 1, 8, lo) DW_SB   /* the next tile's first two stages (of this one again at the end: unused) */ \
+        DW_LD(B, tn, 2, 2, lo) DW_SB  DW_AP(C, t, 1, 9, lo9) DW_SB
+#define DW_FIRST(tt) DW_LD(A, tt, 2, 0, lo) DW_LD(B, tt, 2, 2, lo)
+    // one tile: sets A and B hold its first two stages (requested at the end of the previous tile) -- one loop body, no register-set swap
+    // (a swap would have to wait for loads in flight)
 #define DW_BODY()                                                                                              \
     {                                                                                                                \
         const bool more = t + G < ntiles;                                                                            \
@@ -886,6 +870,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, in
     if (t < ntiles) { DW_FIRST(t) }
     for (; t < ntiles; t += G) DW_BODY()
 #undef DW_STAGES
+#undef DW_SB
 #undef DW_FIRST
 #undef DW_LDG
 #undef DW_STG
