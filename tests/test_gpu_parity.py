@@ -1033,19 +1033,23 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
             from ltgan.engine import Pipe
             assert eng.sharded_step_ok(B)
             pipe = Pipe(eng, B, flags=pipe_flags[variant] | int(os.environ.get("LTGAN_TEST_PIPE_FLAGS", "0")))
-        for s in range(2 * n_batches):
-            X = Xs[s % n_batches]
-            rows, gen, pop = fakes[s % n_batches]
+        batches = []
+        for X in Xs:
             slot, uptr, rowidx, pos, nu = Hh.csc_view(X)
             uitem = None if variant.endswith("no-uitem") else t(np.flatnonzero(slot >= 0).astype(np.int32))
-            batch = CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, uptr=t(uptr), rowidx=t(rowidx), csr_pos=t(pos), n_unique=nu,
-                            uitem=uitem, uitem_off=0)
+            batches.append(CsrRows(t(X.indptr.astype(np.int32)), t(X.indices.astype(np.int32)), 0, B, uptr=t(uptr), rowidx=t(rowidx), csr_pos=t(pos),
+                                   n_unique=nu, uitem=uitem, uitem_off=0))
+        for s in range(2 * n_batches):
+            batch = batches[s % n_batches]
+            rows, gen, pop = fakes[s % n_batches]
             fake = Pairs(t(pop), t(gen), t(rows))
             cnt = torch.tensor([int(((gen >= 0) & (pop >= 0)).sum())], dtype=torch.int32, device=dev)
             eng.adam_t += s % 3                                           # the shared counter also moves between G steps (D steps)
             if pipe is not None:
                 go = eng.g_opts(cnt, 0.05, rng_step=10 + s, d_rng_step=200 + s)
-                losses.append(eng.g_step_sharded(batch, fake, acts, go, pipe).clone())
+                # the NEXT batch announced: its rows of W_q0 are caught up during this call and the next call launches no catch-up (ABI v13) --
+                # also across the mid-phase forward below, which moves no ordinal
+                losses.append(eng.g_step_sharded(batch, fake, acts, go, pipe, next_batch=batches[(s + 1) % n_batches]).clone())
             else:
                 losses.append(eng.g_step(batch, fake, acts, cnt, 0.05, rng_step=10 + s, d_rng_step=200 + s).clone())
             if s == n_batches + 2:                                        # mid-phase forward: rows are caught up as they are read
@@ -1058,6 +1062,8 @@ def test_lazy_adam_clock_of_the_first_encoder_layer_is_bit_identical_to_the_dens
         if pipe is not None:
             eng.pipe_join(pipe)
             assert pipe.expired_waits() == 0, variant
+            ahead_served = variant not in ("one-call-events", "one-call-slice-in-touch", "one-call-no-uitem") and pipe.handover != "events"
+            assert pipe.ahead_calls == (2 * n_batches - 1 if ahead_served else 0), (variant, pipe.handover, pipe.ahead_calls)
         if lazy:
             torch.cuda.synchronize()
             assert eng.gen_c.q0_ord == 2 * n_batches
