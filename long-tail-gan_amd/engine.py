@@ -287,6 +287,17 @@ class Engine:
                     for i, t in enumerate(self.g_p)]
         self.g_v = [torch.zeros_like(t) if v is None else torch.as_tensor(np.ascontiguousarray(v[i]), dtype=torch.float32).to(dev)
                     for i, t in enumerate(self.g_p)]
+        if self.I >= 8192 and os.environ.get("LTGAN_ONE_BLOCK", "1") != "0":
+            # theta / m / v of W_p1t in ONE allocation (each table on a 2-MiB boundary): the weight update streams the three in lock step, and
+            # a sweep over three separate allocations measured 2-6 % below the same sweep over one block (scripts/micro/stagger.hip: 5.56-5.79
+            # against 5.90 TB/s at 200 000 items; which of the two a process got showed as the two modes of profiles/r4_c4_two_modes.txt)
+            n = self.g_p[3].numel()
+            per = ((n * 4 + (2 << 20) - 1) // (2 << 20)) * (2 << 20) // 4
+            self._p1_block = torch.empty(3 * per, dtype=torch.float32, device=dev)
+            for k, lst in enumerate((self.g_p, self.g_m, self.g_v)):
+                view = self._p1_block[k * per:k * per + n].view_as(lst[3])
+                view.copy_(lst[3])
+                lst[3] = view
         arr = lambda ts: (cabi.vp * 8)(*[_ptr(t) for t in ts])
         # bf16 shadow of W_p1t for the streaming decoder kernels (large item slabs only)
         self.g_shadow = None
