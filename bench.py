@@ -406,6 +406,15 @@ def self_launch(a):
     raise SystemExit(0)
 
 
+def pipe_facts(pipe):
+    """what the one-call G step did beside its kernels (include/ltg.h, ABI v13): steps that found their rows of W_q0 caught up by the step
+    before (no catch-up launch of their own) out of all steps, and whether the weight update wrote a second shadow buffer"""
+    if pipe is None:
+        return None
+    return {"steps": int(pipe.c.seq), "steps_caught_up_ahead": int(pipe.ahead_calls), "second_shadow_buffer": pipe.shadow is not None,
+            "tail_stream": pipe.tail_stream is not None}
+
+
 def warm_moments(eng):
     """--warm-moments: Adam moments of W_q0 as after long training (every item seen at some point)"""
     import torch
@@ -453,6 +462,7 @@ def other_workloads(a, device, users=6400):
                     "warm_moments": bool(warm),
                     "lazy_q0": bool(eng.lazy_q0),
                     "handover": getattr(getattr(tr, "pipe", None), "handover", None),     # how the one-call G step's streams meet (engine.py: _pipe_ready)
+                    "pipe": pipe_facts(getattr(tr, "pipe", None)),
                     **step_fracs(idx, data, eng, a.sub_epochs, tr.active, dt, 1),
                     "dominant_kernel": None if r is None else {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}}
         del tr, prof, eng, data, idx
@@ -593,6 +603,7 @@ def main():
         res["sharded_step"] = {
             "one_call": bool(one_call),                          # ltg_g_step_sharded: every launch and the three exchanges from one C call
             "handover": getattr(getattr(tr, "pipe", None), "handover", None),   # fork / join of the weight update: "device-words" | "events"
+            "pipe": pipe_facts(getattr(tr, "pipe", None)),
             "transport": getattr(comm, "kind", "torch.distributed (%s), step cut at its exchange points" % backend),
             "rccl_ranks": getattr(comm, "count", None) if getattr(comm, "kind", "") == "rccl-direct" else None,   # ncclCommCount
             "ranks": ranks_info,
