@@ -1739,11 +1739,20 @@ __global__ __launch_bounds__(NT) void fks_d_l2(int n, int h12, int h3, const flo
 // workgroup's stage used to last one L2 / HBM round trip (~1.2 us against 0.1 us of MFMA), 16 of them per 2048-deep tile.  The loop is
 // unrolled by two with static set names, fetches are clamped instead of guarded and a block past the end is stashed as zeros (adds
 // nothing), so the loop has no branch and every s_waitcnt is an exact count.  -DLTG_SG8_SHALLOW builds the one-block-ahead loop.
+constexpr int SG8_LDK = 128;   // bytes per LDS row of the staged e4m3 block (s8[2 * (BM + BN) * SG8_LDK] per workgroup)
 template <int BM, int BN, class ARow, class BRow>
 __device__ __forceinline__ void ltg_sgemm8_core(int K, ARow a_row, BRow b_row, ltg_f32x4 (&acc)[BM / 32][BN / 32], uint8_t* __restrict__ lds) {
-    constexpr int BK = 128, LDK = BK + 16, TM = BM / 32, TN = BN / 32, RA = BM / 32, RB = BN / 32;
+    // LDS image (round 4): rows of 128 bytes WITHOUT padding, the sixteen 8-byte k-chunks of row r stored at chunk position c ^ (r & 15).
+    // A fragment read is 16 lanes x 8 bytes of ONE logical chunk over 16 consecutive rows: with the 144-byte padded rows of before, rows r
+    // and r + 8 met in the same banks (36 r mod 32 dwords repeats after 8 rows: SQ_LDS_BANK_CONFLICT 39 % of the LDS-active cycles, 23 % of
+    // the wave cycles of fk8t_d_l1 waiting on LDS); swizzled, the 16 rows hit 16 different chunk positions = every bank once.  The loader's
+    // 16-byte piece (two chunks of one row) stays one aligned 16-byte store, its halves exchanged in odd rows.
+    constexpr int BK = 128, LDK = SG8_LDK, TM = BM / 32, TN = BN / 32, RA = BM / 32, RB = BN / 32;
+    static_assert(LDK == BK, "unpadded rows: the swizzle replaces the pad");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4, wm = w >> 1, wn = w & 1;
     const int lrow = tid >> 3, lkc = (tid & 7) * 16;        // loader: rows lrow + 32 j, byte column lkc of the K block
+    const int wcol = 16 * ((tid & 7) ^ ((lrow & 15) >> 1)); // ... stored at this byte column (rows lrow + 32 j share lrow & 15)
+    const bool wodd = (lrow & 1) != 0;
     const uint8_t* ap[RA];
     const uint8_t* bp[RB];
     unsigned am[RA], bm[RB];
@@ -1777,26 +1786,32 @@ __device__ __forceinline__ void ltg_sgemm8_core(int K, ARow a_row, BRow b_row, l
     {                                                                                                      \
         const unsigned in_ = (kk) < K ? 0xFFFFFFFFu : 0u;                                                  \
         _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                                   \
-            ltg_u32x4 v = XA[j];                                                                           \
+            const ltg_u32x4 x = XA[j];                                                                     \
             const unsigned mk = am[j] & in_;                                                               \
-            v[0] &= mk; v[1] &= mk; v[2] &= mk; v[3] &= mk;                                                \
-            *reinterpret_cast<ltg_u32x4*>(As + (size_t)((buf) * BM + lrow + 32 * j) * LDK + lkc) = v;      \
+            ltg_u32x4 v;                                                                                   \
+            v[0] = (wodd ? x[2] : x[0]) & mk; v[1] = (wodd ? x[3] : x[1]) & mk;                            \
+            v[2] = (wodd ? x[0] : x[2]) & mk; v[3] = (wodd ? x[1] : x[3]) & mk;                            \
+            *reinterpret_cast<ltg_u32x4*>(As + (size_t)((buf) * BM + lrow + 32 * j) * LDK + wcol) = v;     \
         }                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                   \
-            ltg_u32x4 v = XB[j];                                                                           \
+            const ltg_u32x4 x = XB[j];                                                                     \
             const unsigned mk = bm[j] & in_;                                                               \
-            v[0] &= mk; v[1] &= mk; v[2] &= mk; v[3] &= mk;                                                \
-            *reinterpret_cast<ltg_u32x4*>(Bs + (size_t)((buf) * BN + lrow + 32 * j) * LDK + lkc) = v;      \
+            ltg_u32x4 v;                                                                                   \
+            v[0] = (wodd ? x[2] : x[0]) & mk; v[1] = (wodd ? x[3] : x[1]) & mk;                            \
+            v[2] = (wodd ? x[0] : x[2]) & mk; v[3] = (wodd ? x[1] : x[3]) & mk;                            \
+            *reinterpret_cast<ltg_u32x4*>(Bs + (size_t)((buf) * BN + lrow + 32 * j) * LDK + wcol) = v;     \
         }                                                                                                  \
     }
 #define SG8_MFMA(buf)                                                                                      \
     {                                                                                                      \
-        const uint8_t* Aw = As + (size_t)((buf) * BM + wm * (BM / 2) + lr) * LDK + 8 * lq;                 \
-        const uint8_t* Bw = Bs + (size_t)((buf) * BN + wn * (BN / 2) + lr) * LDK + 8 * lq;                 \
+        /* rows wm * (BM / 2) + 16 i + lr: r & 15 == lr; logical chunk ks / 8 + lq at chunk position (ks / 8 + lq) ^ lr */ \
+        const uint8_t* Aw = As + (size_t)((buf) * BM + wm * (BM / 2) + lr) * LDK;                          \
+        const uint8_t* Bw = Bs + (size_t)((buf) * BN + wn * (BN / 2) + lr) * LDK;                          \
         _Pragma("unroll") for (int ks = 0; ks < BK; ks += 32) {                                            \
             long af[TM], bf[TN];                                                                           \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(Aw + (size_t)(i * 16) * LDK + ks); \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const long*>(Bw + (size_t)(j * 16) * LDK + ks); \
+            const int cx = 8 * (((ks >> 3) + lq) ^ lr);                                                    \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(Aw + (size_t)(i * 16) * LDK + cx); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const long*>(Bw + (size_t)(j * 16) * LDK + cx); \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i], bf[j], acc[i][j], 0, 0, 0); \
@@ -1854,7 +1869,7 @@ __global__ __launch_bounds__(NT) void fk8s_d_l1(PairView pv, int h0, int h1, int
                                                 const uint8_t* __restrict__ w1t8, const float* __restrict__ b1,
                                                 const uint8_t* __restrict__ w2t8, const float* __restrict__ b2, DropView dA, DropView dB,
                                                 float keep, uint64_t seed, uint64_t step, float* __restrict__ A1, uint8_t* __restrict__ A1_8) {
-    __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * 144];
+    __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * SG8_LDK];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const int tn1 = (h1 + BN - 1) / BN;
     const int ct = blockIdx.x, rt = blockIdx.y;
@@ -1890,7 +1905,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(NT) void fk8s_d_l2(int n, int h12, int h3, const uint8_t* __restrict__ A1_8, const uint8_t* __restrict__ w3t8,
                                                 const float* __restrict__ b3, DropView dC, float keep, uint64_t seed, uint64_t step,
                                                 float* __restrict__ A3) {
-    __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * 144];
+    __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * SG8_LDK];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     auto a_row = [=] __device__(int r) -> const uint8_t* { return (r < 0 || m0 + r >= n) ? (r < 0 ? A1_8 : nullptr) : A1_8 + (size_t)(m0 + r) * h12; };
     auto b_row = [=] __device__(int c) -> const uint8_t* { return (c < 0 || n0 + c >= h3) ? (c < 0 ? w3t8 : nullptr) : w3t8 + (size_t)(n0 + c) * h12; };
