@@ -30,6 +30,7 @@ def _librccl():
     lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
     lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    lib.ncclCommAbort.argtypes = [C.c_void_p]
     lib.ncclGetErrorString.restype = C.c_char_p
     lib.ncclGetErrorString.argtypes = [C.c_int]
     lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -43,7 +44,9 @@ class RcclComm:
     def __init__(self, group=None, device=None, warm_counts=(128 * 600, 640)):
         """warm_counts: floats of the step's all-reduce message and of one rank's all-gather block (ltg_pipe.h1pre, rowpart_all / R).
         ncclCommInitRank is a COLLECTIVE: every step before it that can fail on one rank alone (loading librccl, the unique id, its
-        broadcast) is followed by an agreement over the existing group, so a rank that failed never leaves the others blocked inside it."""
+        broadcast) is followed by an agreement over the existing group, so a rank that failed BEFORE it never leaves the others blocked inside
+        it; a rank whose ncclCommInitRank itself returns an error is caught by one more agreement behind it (the others abort their
+        communicator instead of entering the warm-up collectives)."""
         self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.comm = C.c_void_p()
         self.group = group
@@ -68,7 +71,20 @@ class RcclComm:
         C.memmove(C.byref(uid), box[0], 128)
         if device is not None:
             torch.cuda.set_device(device)
-        self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.n_ranks, uid, self.rank), "ncclCommInitRank")
+        err = None
+        try:
+            self._check(self.lib.ncclCommInitRank(C.byref(self.comm), self.n_ranks, uid, self.rank), "ncclCommInitRank")
+        except Exception as e:
+            err = "ncclCommInitRank: %r" % (e,)
+        # (a rank whose init FAILED returns from it; the others have returned too -- the call is collective -- and would otherwise wait in
+        # _warm_up's collectives for ever.  A rank that never returns from ncclCommInitRank is beyond this agreement: RCCL's own timeout.)
+        try:
+            self._agree(err, device)
+        except Exception:
+            if self.comm:
+                self.lib.ncclCommAbort(self.comm)
+                self.comm = C.c_void_p()
+            raise
         self._warm_counts = (int(warm_counts[0]), int(warm_counts[1]))
         n = C.c_int()
         self._check(self.lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
@@ -105,6 +121,8 @@ class RcclComm:
             raise cabi.LtgError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
 
     def close(self):
+        """ncclCommDestroy: blocks on outstanding operations, so it is called explicitly (ShardedTrainer.close) while the process group and
+        the HIP runtime are alive -- never from a destructor (interpreter teardown, a one-rank exception path)"""
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)
             self.comm = C.c_void_p()

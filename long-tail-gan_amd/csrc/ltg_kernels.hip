@@ -2929,18 +2929,21 @@ int ltg_sample_pairs(const ltg_config* cfg, const ltg_sample_inputs* in, const f
 
 // One Adam sweep of the discriminator from `ks` gradient slabs of stride `stride` (lrow: the per-row loss terms of the
 // round-1 kernels, else the loss sits in slot P of the slabs)
-static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLayout& L, int ks, int stride, const float* slab, int n,
-                    const float* lrow, const AdamC& ad, float* loss_out, const Probe& pr, hipStream_t st, const unsigned* poison = nullptr) {
-    const int P = L.off[8];
-    // one flat float4 sweep when the eight tensors (and moments) lie back to back -- and no operand-format shadows have to follow
-    // the weights (fp8 mode: k_d_adam rewrites the e4m3 copies of the three matrices it updates)
+// one flat float4 sweep (fk_d_adam) when the eight tensors (and moments) lie back to back -- and no operand-format shadows have to follow
+// the weights (fp8 mode: k_d_adam rewrites the e4m3 copies of the three matrices it updates)
+static bool d_adam_flat(const ltg_config* cfg, const ltg_disc_state* disc, const DLayout& L, int stride, const float* slab, const float* lrow) {
     bool flat = lrow == nullptr && (stride % 4) == 0 && !(cfg->d_precision == LTG_PREC_FP8 && disc->w1t_fp8);
     for (int i = 0; i < 7; ++i) {
         const size_t sz = (size_t)(L.off[i + 1] - L.off[i]);
         flat = flat && disc->p[i + 1] == disc->p[i] + sz && disc->m[i + 1] == disc->m[i] + sz && disc->v[i + 1] == disc->v[i] + sz;
     }
-    flat = flat && ((uintptr_t)disc->p[0] % 16) == 0 && ((uintptr_t)disc->m[0] % 16) == 0 && ((uintptr_t)disc->v[0] % 16) == 0 &&
+    return flat && ((uintptr_t)disc->p[0] % 16) == 0 && ((uintptr_t)disc->m[0] % 16) == 0 && ((uintptr_t)disc->v[0] % 16) == 0 &&
            ((uintptr_t)slab % 16) == 0;
+}
+static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLayout& L, int ks, int stride, const float* slab, int n,
+                    const float* lrow, const AdamC& ad, float* loss_out, const Probe& pr, hipStream_t st, const unsigned* poison = nullptr) {
+    const int P = L.off[8];
+    const bool flat = d_adam_flat(cfg, disc, L, stride, slab, lrow);
     int ga = ((flat ? P / 4 : P) + NT - 1) / NT;
     if (ga > 1024) ga = 1024;
     if (ga < 1) ga = 1;
@@ -2982,7 +2985,10 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         // gave up = poison, the sweep then returns at once).  (Measured and not kept, same round: the same jobs riding in stage 2's OWN
         // launch instead of beside job A: 59.5-59.6 -> 61.3-61.6 us per step; profiles/r4_d_step_floor.txt, which also has the step's
         // launch structure: the five grids returning at once take 18 us.)
-        const bool fork = o->aux_stream && o->sync && !grad_out && (cfg->reserved0 & 64) == 0;      // (tuning-knob bit 6: no fork)
+        // (only with the FLAT tensor layout: the poison word reaches fk_d_adam alone -- separate tensors take k_d_adam, which has no early
+        // return, so a direct C-ABI caller with that layout keeps the whole step on one stream)
+        const bool fork = o->aux_stream && o->sync && !grad_out && (cfg->reserved0 & 64) == 0 &&      // (tuning-knob bit 6: no fork)
+                          d_adam_flat(cfg, disc, L, SP, w.slab, nullptr);
         const unsigned* poison = fork ? o->sync + 2 : nullptr;
         LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(fork ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
                                                         w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab,

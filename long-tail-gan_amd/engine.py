@@ -308,6 +308,7 @@ class Engine:
             self.q0_last = torch.zeros(self.I, dtype=torch.int32, device=dev)
             self.q0_lr_hist = torch.zeros(cabi.LTG_Q0_HIST, dtype=torch.float32, device=dev)
         self._q0_dirty = False
+        self._forget_ahead()                                         # (new weights, ordinal 0: no catch-up announced against the old clock stays valid)
         self.gen_c = cabi.ltg_gen_state(arr(self.g_p), arr(self.g_m), arr(self.g_v), _ptr(self.g_shadow),
                                         _ptr(self.q0_last), _ptr(self.q0_lr_hist), 0, self.q0_period if self.lazy_q0 else 0)
         if self.g_shadow is not None:
@@ -524,17 +525,27 @@ class Engine:
             # memset behind the flush kernel)
             self.q0_last.zero_()
             self.gen_c.q0_ord = 0
+            self._forget_ahead()       # (an announcement made against the old ordinals must not match a later call's key)
+
+    def _forget_ahead(self):
+        """the clock's ordinals restart (flush, new weights): no pipe's catch-up-ahead announcement is valid any more"""
+        for pipe in list(self._pipes):
+            pipe.ahead = None
+            pipe.c.next_uitem, pipe.c.next_nu, pipe.c.caught_up = None, 0, 0
 
     def check_pipes(self):
         """raises if a device-side wait of a one-call G step gave up (ltg_pipe.sync[2]).  The kernels behind such a wait have skipped
-        their work, so the model is the one from before that step -- but the run is not the run that was asked for.  Synchronises."""
-        for pipe in list(self._pipes) + ([self._dfork] if self._dfork is not None else []):
-            n = pipe.expired_waits()
-            if n:
-                torch.cuda.synchronize(self.device)
-                self.refresh_shadow()      # (a skipped weight update did not write the shadow buffer the host has switched to since)
-                raise cabi.LtgError("%d device-side wait(s) of a step's hand-overs gave up: the steps behind them were skipped, "
-                                    "the results of that phase are not trustworthy" % n)
+        their work, so the model is the one from before that step -- but the run is not the run that was asked for.  ONE device-to-host
+        copy and one synchronisation however many pipes the engine has."""
+        words = [pipe.sync[2:3] for pipe in list(self._pipes) + ([self._dfork] if self._dfork is not None else [])]
+        if not words:
+            return
+        n = int((words[0] if len(words) == 1 else torch.cat(words)).sum().item())
+        if n:
+            torch.cuda.synchronize(self.device)
+            self.refresh_shadow()      # (a skipped weight update did not write the shadow buffer the host has switched to since)
+            raise cabi.LtgError("%d device-side wait(s) of a step's hand-overs gave up: the steps behind them were skipped, "
+                                "the results of that phase are not trustworthy" % n)
 
     # ------------------------------------------------------------------ the G step cut at its exchange points
     def fwd_opts(self, keep_prob=0.75, is_training=0.0, rng_step=0, drop_keep=None, eps=None, probe=None):
@@ -570,7 +581,8 @@ class Engine:
         pipe.ahead_calls += pipe.c.caught_up
         pipe.ahead = None
         pipe.c.next_uitem, pipe.c.next_nu = None, 0
-        plan = self.lib.ltg_g_step_sharded_plan(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(pipe.c))
+        plan = (self.lib.ltg_g_step_sharded_plan(C.byref(self.cfg), C.byref(self.gen_c), C.byref(batch.c), C.byref(pipe.c))
+                if hasattr(self.lib, "ltg_g_step_sharded_plan") else 0)      # (an ABI 11 / 12 build under LTG_AB_COMPAT: no catch-up ahead, one shadow buffer)
         if next_batch is not None and next_batch.c.uitem and self.q0_defer and (plan & cabi.LTG_PLAN_AHEAD):
             pipe.c.next_uitem, pipe.c.next_nu = next_batch.c.uitem, int(next_batch.c.n_unique)
             pipe.ahead = (next_batch.c.uitem, int(next_batch.c.n_unique), int(self.gen_c.q0_ord) + 1, (int(pipe.c.seq) + 1) & 0xFFFFFFFF)

@@ -111,13 +111,6 @@ class ShardedTrainer(Trainer):
             self.comm.close()
             self.comm = None
 
-    def __del__(self):
-        try:
-            if getattr(self, "comm", None) is not None:
-                self.comm.close()
-        except Exception:
-            pass
-
     # -- collectives -------------------------------------------------------------------------------
     def _allreduce(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -20,7 +20,7 @@ def main():
     from oracle import ltg_oracle as O
     dist.init_process_group("gloo")
     rank, R = dist.get_rank(), dist.get_world_size()
-    I, B = 300, 24
+    I, B = (300 if R <= 2 else 64 * R - 12), 24         # world size 8: seven slabs of 64 items and an uneven last one (52)
     rng = np.random.default_rng(0)                      # same problem on every rank
     X = Hh.random_history(rng, B, I, mean_nnz=9).toarray().astype(np.float64)
     P = {k: np.asarray(v, np.float64) for k, v in O.init_generator(I, seed=1).items()}

@@ -45,7 +45,9 @@ def main():
     data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
     tr = ShardedTrainer(eng, data, num_sub_epochs=S, shuffle_seed=1, d_split=d_split)
     assert tr.d_split == d_split
-    one_call = precision == "bf16" and hi - lo >= 8192 and mode != "cutpoints"
+    # (every rank takes the same path: one slab below the one-call step's 8 192 items sends ALL ranks onto the cut-point sequence)
+    smallest = min(b - a for a, b in (item_slab(I, r, world) for r in range(world)))
+    one_call = precision == "bf16" and smallest >= 8192 and mode != "cutpoints"
     assert (tr.pipe is not None) == one_call and (tr.comm is not None) == one_call, (tr.pipe, tr.comm)
     if backend == "nccl" and one_call:
         assert tr.comm.kind == "rccl-direct" and tr.comm.count == world, (tr.comm.kind, tr.comm.count)     # ncclCommCount of the step's own communicator
@@ -128,8 +130,9 @@ def main():
     tr.close()
     dist.barrier()
     if rank == 0:
-        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s d_precision=%s backend=%s transport=%s handover=%s" % (
-            world, workload, precision, d_split, dq, backend, transport, getattr(tr.pipe, "handover", None)))
+        print("SHARDED_OK world=%d workload=%s precision=%s d_split=%s d_precision=%s backend=%s transport=%s handover=%s path=%s slabs=%s" % (
+            world, workload, precision, d_split, dq, backend, transport, getattr(tr.pipe, "handover", None),
+            "one-call" if one_call else "cut-points", sorted({b - a for a, b in (item_slab(I, r, world) for r in range(world))})))
     dist.destroy_process_group()
 
 

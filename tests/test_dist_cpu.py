@@ -10,10 +10,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_gloo_world2_exchange_algebra():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(ROOT, "tests", "dist_cpu_worker.py")]
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_exchange_algebra(world):
+    """world 8 = the node the item sharding is built for: eight slabs with an uneven last one, rowpart_all [8][B][5]"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29611 + world), os.path.join(ROOT, "tests", "dist_cpu_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "DIST_CPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 

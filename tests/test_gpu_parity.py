@@ -81,6 +81,40 @@ def test_forward_parity(precision, tol, I, B):
         assert np.max(np.abs(p - F32["probs"]) / F32["probs"]) < 2e-2
 
 
+@pytest.mark.parametrize("I,rows", [(20000, (100, 100, 50)), (1000, (100, 100, 100, 1))])
+def test_forward_parity_over_a_span_of_batches(I, rows):
+    """Phase C's forward as the trainer issues it (train.py:192-200 over consecutive batches; `ltg_fwd_opts.rows_per_step`): ONE launch
+    sequence over several batches, batch k drawing its input dropout with counter rng_step + k and its LOCAL row numbers -- against the
+    oracle batch by batch (is_training = 0: no epsilon, as train.py:200 feeds it).  I = 20 000: BASELINE config 3's item count."""
+    import scipy.sparse as sp
+    import torch
+    R, bs = sum(rows), rows[0]
+    rng, X, P = _problem(I, R, seed=3 * I + R)
+    eng = _engine(I, "bf16")
+    eng.set_generator(Hh.gen_to_engine(P))
+    acts = eng.new_acts(R)
+    batch = _upload_batch(eng, X)
+    probs = torch.empty(R, I, dtype=torch.float32, device=eng.device)
+    step, keep = 21, 0.75
+    eng.forward(batch, acts, keep_prob=keep, is_training=0.0, rng_step=step, probs_out=probs, rows_per_step=bs)
+    torch.cuda.synchronize()
+    got = {k: getattr(acts, k).cpu().numpy() for k in ("h1", "h2", "logits", "lse")}
+    p = probs.cpu().numpy()
+    r0 = 0
+    for k, n in enumerate(rows):
+        Xk = X[r0:r0 + n].toarray()
+        mask = Hh.dropout_mask_dense(SEED, step + k, n, I, keep)
+        F = O.vae_forward(P, Xk, mask, keep, np.zeros((n, eng.Z)), 0.0, 1.0, np.float64, quant=True)
+        sl = slice(r0, r0 + n)
+        assert Hh.rel_err(got["h1"][sl], F["h1"]) < 2e-5, k
+        assert Hh.rel_err(got["h2"][sl], F["h2"]) < 1e-4, k
+        assert Hh.rel_err(got["logits"][sl], F["logits"]) < 1e-3, k
+        assert np.abs(got["lse"][sl] - F["lse"]).max() < 1e-3, k
+        perr = np.max(np.abs(p[sl] - F["probs"]) / F["probs"])
+        assert perr < 1e-3, (k, perr)
+        r0 += n
+
+
 def _check_adam_move(move_got, move_want, m_want, lr_t, tag):
     """First-step Adam moves are lr_t*0.1g/(0.0316|g|+1e-8): a sign-like function of g, so rounding
     noise on a near-cancelling gradient (|g| << its terms) is amplified without bound.  Elements
@@ -276,7 +310,10 @@ def test_g_step_parity(precision, I, B, path):
 
 @pytest.mark.parametrize("precision,I,B,path", [("fp32", 1000, 100, "step"), ("bf16", 1000, 100, "step"), ("fp32", 6000, 100, "step"),
                                                 ("bf16", 8200, 100, "step"), ("bf16", 20000, 100, "step"), ("bf16", 25024, 100, "one-call"),
-                                                ("bf16", 25032, 100, "one-call")])
+                                                ("bf16", 25032, 100, "one-call"),
+                                                # BASELINE config 4's item count: the combination the driver's C4 bench leg runs (one call, warm
+                                                # moments, 200 000 items), and the ragged slab through the five-launch step
+                                                ("bf16", 200000, 100, "one-call"), ("bf16", 200008, 100, "step")])
 def test_g_step_adam_quotient_from_warm_moments(precision, I, B, path):
     """The G step from injected NON-ZERO Adam moments at shared step t = 138 against oracle.SharedAdam (train.py:160-164): every
     theta move, m and v element-wise -- dense tile epilogues, the streaming weight update, the lazy clock's kernels (rows of W_q0
@@ -501,6 +538,17 @@ def test_sampler_matches_oracle_at_200000_items():
     prob = (idx.cand_ptr.astype(np.int32), idx.cand_idx.astype(np.int32), idx.pop_ptr.astype(np.int32), idx.pop_idx.astype(np.int32),
             idx.n_sample.astype(np.int32), idx.valid_item.astype(np.uint8))
     assert int(np.diff(prob[0]).max()) > 20
+    _sampler_case(rng, idx.n_items, 100, prob, False)
+
+
+def test_sampler_matches_oracle_at_20000_items():
+    """BASELINE config 3's item count with the candidate statistics of the ML-20M-shaped synthetic (ltgan.synthetic)."""
+    from ltgan.synthetic import synthetic_index
+    idx, _ = synthetic_index("ml20m", users=100, seed=33)
+    rng = np.random.default_rng(43)
+    prob = (idx.cand_ptr.astype(np.int32), idx.cand_idx.astype(np.int32), idx.pop_ptr.astype(np.int32), idx.pop_idx.astype(np.int32),
+            idx.n_sample.astype(np.int32), idx.valid_item.astype(np.uint8))
+    assert idx.n_items == 20000 and int(np.diff(prob[0]).max()) > 20
     _sampler_case(rng, idx.n_items, 100, prob, False)
 
 

@@ -33,6 +33,22 @@ def test_two_rank_item_sharding_matches_unsharded(workload, users, precision, mo
     assert out.returncode == 0 and "SHARDED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
 
 
+@pytest.mark.parametrize("workload,users,precision,mode", [("c4", 200, "bf16", ""), ("ml20m", 200, "bf16", ""), ("c4", 200, "bf16", "wide_fp8_full"),
+                                                           ("custom:65600", 200, "bf16", "")])
+def test_eight_rank_item_sharding_matches_unsharded(workload, users, precision, mode):
+    """World size 8 -- the node the split is built for -- on the rig a 1-GPU box allows: eight gloo ranks sharing cuda:0, every rank also
+    running the unsharded trainer it is compared with.  c4: 200 000 items = seven slabs of 25 024 and one of 24 832 (the uneven last
+    slab), `rowpart_all [8][B][5]`, the one-call step on every rank; with "wide_fp8_full" config 5's discriminator pair-split over 8
+    ranks.  ml20m: 20 000 items = 2 560-item slabs, below the one-call step's 8 192 -- every rank agrees on the cut-point sequence
+    (the worker asserts which path ran).  custom:65600: slabs of 8 256 items and a last one of 7 808 < 8 192 -- ONE rank's slab is too
+    small for the one-call step, so all eight must agree on the cut-point sequence (`ShardedTrainer._init_sharded_step`)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", os.path.join(ROOT, "tests", "dist_shard_worker.py"), workload, str(users), precision] + ([mode] if mode else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=2400)      # fresh children only
+    assert out.returncode == 0 and "SHARDED_OK world=8" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
+
+
 def test_direct_rccl_transport_of_the_one_call_step_at_world_size_one():
     """The transport a GPU node uses: RCCL bound directly, its entry points called by the library in-stream (tests/dist_rccl_worker.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
