@@ -526,6 +526,188 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
     }
 }
 
+// ---- The streaming decoder forward, second form (round 5): WHO OWNS WHAT is turned round.  Above, the eight waves of a workgroup split the
+// BATCH rows, so every wave needs every W tile: the tile goes through LDS, each wave reads all 39 KB of it (311 KB of LDS reads per 32
+// items and CU), and one barrier per tile keeps the eight waves in lock step -- loads, product and stores add up (56 + 13 + 16 us at
+// 200 000 items).  Here h2 -- the SMALL operand, 100 x 608 bf16 -- is resident in LDS for the whole kernel, laid out in fragment order
+// (every fragment read is one contiguous, conflict-free 1-KiB ds_read_b128), and each WAVE owns its own 32-item tiles:
+//   * items are the M dimension of v_mfma_f32_16x16x32_bf16 (A = W_p1t shadow rows, B = h2^T): a lane's A fragment is 16 contiguous
+//     bytes of ONE shadow row, loaded global -> VGPR in fragment order (16 rows x 64 B per wave instruction: every byte of a 128-B
+//     line is used by two consecutive K steps) -- no LDS staging of W, no barrier in the loop, the waves drift apart and one wave's
+//     loads overlap another's MFMAs and stores;
+//   * two 16-item sub-tiles per wave tile share every B fragment read: 133 KB of LDS reads per 32 items and wave (NTB = 7) instead of
+//     311 KB per 32 items and workgroup -- 2.3x fewer LDS bytes per item;
+//   * W travels through a RING of 19 load units (one unit = one wave instruction = 16 B per lane = one (K step, sub-tile) fragment;
+//     a tile is 38 units): the unit consumed by K step ks is re-requested for 19 units ahead -- the same tile's second half, then the
+//     NEXT tile's first half -- so 19 KB per wave = 152 KB per CU of HBM loads are in flight at every moment, through the epilogue's
+//     stores and across tile boundaries, with no register-set swap (19 is odd: unit u and u + 19 sit in the same registers);
+//   * the accumulator of a lane is four CONSECUTIVE items of one batch row: logits leave as 16-B stores, 64 B contiguous per row and
+//     instruction (128 B per row over the two sub-tiles), and the softmax statistics stay per lane (one (max, sum exp) pair per batch
+//     tile), merged over the four lane groups and the eight waves once at the end -- same stat[workgroup][row] = (max, sum) output.
+// No branch in the loop: indices are clamped (a wave's last tile re-requests one 64-B line instead of a next tile: no HBM traffic),
+// rows >= M mirror row M - 1, items >= I mirror the slab's last four items, so every s_waitcnt is an exact count.  Summation order over
+// K differs from the first form's (there: per 32-wide K step across four lane groups as well -- here the same; tiles and lanes differ
+// in which items they hold, not in how a logit is added up), so the logits are the same sums; bit-identity is not relied upon.
+// NTB: 16-row batch tiles (7 for <= 112 rows: the 100-row batches of config.ini; 8 up to 128 rows).
+constexpr int ST2_UNITS = 2 * ST_KS;   // 38 load units per 32-item tile
+constexpr int ST2_RING = ST_KS;        // 19 units in flight per wave
+template <bool STATS, int NTB>
+__global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H, const float* __restrict__ h2,
+                                                            const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
+                                                            float* __restrict__ logits, float* __restrict__ stat) {
+    __shared__ __attribute__((aligned(16))) ltg_u32x4 Hs[ST_KS * NTB * 64];   // h2 in B-fragment order: [K step][batch tile][lane] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int ntiles = (I + 31) >> 5, G = gridDim.x, GW = 8 * G;
+    // tiles are dealt to waves CU-first (wave w of workgroup g is wave number w * G + g): a slab with fewer tiles than waves spreads over
+    // all CUs, a few waves each, instead of filling some CUs with eight waves
+    int t = w * G + (int)blockIdx.x;
+    const bool any = t < ntiles;
+    const ltg_gchar* Wg = ltg_uniform_ptr(Wb);
+    // byte offset of this lane's A-fragment row in the shadow: item row (tile, sub-tile s, lr), chunk lq of the K step (the K step's
+    // 64 B are added as an immediate).  Items past the end mirror the slab's last four (I % 4 == 0: a lane's four output items are all
+    // inside or all outside): the product of a mirrored row group is the last group's, and it is stored to the last group's address.
+    auto rowoff = [&](int tt, int ss) -> unsigned {
+        int it = tt * 32 + 16 * ss + lr;
+        it = it < I ? it : I - 4 + (it & 3);
+        return (unsigned)it * (unsigned)(ST_KP * 2) + 16u * (unsigned)lq;
+    };
+    ltg_u32x4 Wr[ST2_RING];
+    typedef const ltg_u32x4 __attribute__((address_space(1))) * st2_gp;
+#define ST2_LOAD(u, OFF0, OFF1) Wr[(u) % ST2_RING] = *(st2_gp)(Wg + (((u) & 1) ? (OFF1) : (OFF0)) + 64u * (unsigned)((u) >> 1));
+    unsigned c0 = any ? rowoff(t, 0) : 0u, c1 = any ? rowoff(t, 1) : 0u;
+    // the ring's first 19 units BEFORE the prologue: the first HBM round trip runs under the construction of the h2 image
+#pragma unroll
+    for (int u = 0; u < ST2_RING; ++u) { ST2_LOAD(u, c0, c1) }
+    {   // h2 (fp32, [M][H]) -> bf16 fragments in LDS; rows >= M mirror row M - 1, columns >= H are zero (K padding)
+        const int H4 = H >> 2;
+        constexpr int NE = ST_KS * NTB * 64, PER = (NE + ST_NT - 1) / ST_NT, CH = 6;
+#pragma unroll 1
+        for (int j0 = 0; j0 < PER; j0 += CH) {
+            float4 x0[CH], x1[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int e = min(tid + (j0 + j) * ST_NT, NE - 1), ln = e & 63, fr = e >> 6, nt = fr % NTB, ks = fr / NTB;
+                const int row = min(16 * nt + (ln & 15), M - 1), c4 = ks * 8 + 2 * (ln >> 4);
+                const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)row * H);
+                x0[j] = hr[min(c4, H4 - 1)];
+                x1[j] = hr[min(c4 + 1, H4 - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int e = tid + (j0 + j) * ST_NT, fr = min(e, NE - 1) >> 6, ks = fr / NTB, c4 = ks * 8 + 2 * ((e & 63) >> 4);
+                const uint2 p0 = ltg_pack4(x0[j]), p1 = ltg_pack4(x1[j]);
+                const unsigned k0 = c4 < H4 ? 0xFFFFFFFFu : 0u, k1 = c4 + 1 < H4 ? 0xFFFFFFFFu : 0u;
+                ltg_u32x4 v;
+                v[0] = p0.x & k0; v[1] = p0.y & k0; v[2] = p1.x & k1; v[3] = p1.y & k1;
+                if (e < NE && j0 + j < PER) Hs[e] = v;
+            }
+        }
+    }
+    __syncthreads();
+    float rm[NTB], rs[NTB];
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) {
+        rm[nt] = -INFINITY;
+        rs[nt] = 0.f;
+    }
+    if (any) {
+        const ltg_u32x4* Hl = Hs + lane;
+#pragma unroll 1
+        for (; t < ntiles; t += GW) {
+            const bool more = t + GW < ntiles;
+            // the next tile's row offsets; on the wave's last tile every lane re-requests ONE line (offset 0 + the K step): no branch, no traffic
+            const unsigned n0 = more ? rowoff(t + GW, 0) : 0u, n1 = more ? rowoff(t + GW, 1) : 0u;
+            // bias of the lane's 2 x 4 output items (requested before anything waits in this tile)
+            const int i0 = t * 32 + 4 * lq, i1 = i0 + 16;
+            const int g0 = i0 < I ? i0 : I - 4, g1 = i1 < I ? i1 : I - 4;
+            const float4 bias0 = *reinterpret_cast<const float4*>(bp1 + g0), bias1 = *reinterpret_cast<const float4*>(bp1 + g1);
+            ltg_f32x4 acc[2][NTB];
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) {
+                acc[0][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[1][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < ST_KS; ++ks) {
+                ltg_u32x4 bfr[NTB];
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt) bfr[nt] = Hl[(ks * NTB + nt) * 64];
+                const ltg_bf16x8 a0 = __builtin_bit_cast(ltg_bf16x8, Wr[(2 * ks) % ST2_RING]);
+                const ltg_bf16x8 a1 = __builtin_bit_cast(ltg_bf16x8, Wr[(2 * ks + 1) % ST2_RING]);
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt) {
+                    const ltg_bf16x8 b = __builtin_bit_cast(ltg_bf16x8, bfr[nt]);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // refill: units 2 ks + 19 and 2 ks + 20 (this tile's second half, then the next tile's first half) into the registers just consumed
+                if (2 * ks + ST2_RING < ST2_UNITS) { ST2_LOAD(2 * ks + ST2_RING, c0, c1) } else { ST2_LOAD(2 * ks + ST2_RING - ST2_UNITS, n0, n1) }
+                if (2 * ks + 1 + ST2_RING < ST2_UNITS) { ST2_LOAD(2 * ks + 1 + ST2_RING, c0, c1) } else { ST2_LOAD(2 * ks + 1 + ST2_RING - ST2_UNITS, n0, n1) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue: + bias, 16-B stores (row 16 nt + lr, items g .. g + 3), running softmax statistics of the row over this lane's items
+            const bool in0 = i0 < I, in1 = i1 < I;
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) {
+                const size_t ro = (size_t)min(16 * nt + lr, M - 1) * (size_t)I;
+                const float4 v0 = make_float4(acc[0][nt][0] + bias0.x, acc[0][nt][1] + bias0.y, acc[0][nt][2] + bias0.z, acc[0][nt][3] + bias0.w);
+                const float4 v1 = make_float4(acc[1][nt][0] + bias1.x, acc[1][nt][1] + bias1.y, acc[1][nt][2] + bias1.z, acc[1][nt][3] + bias1.w);
+                *reinterpret_cast<float4*>(logits + ro + g0) = v0;
+                *reinterpret_cast<float4*>(logits + ro + g1) = v1;
+                if constexpr (STATS) {
+                    const float m0 = in0 ? fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)) : -INFINITY;
+                    const float m1 = in1 ? fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)) : -INFINITY;
+                    const float mn = fmaxf(rm[nt], fmaxf(m0, m1)), mr = fmaxf(mn, -1e30f);
+                    float e = rs[nt] * __expf(rm[nt] - mr);
+                    const float e0 = (__expf(v0.x - mr) + __expf(v0.y - mr)) + (__expf(v0.z - mr) + __expf(v0.w - mr));
+                    const float e1 = (__expf(v1.x - mr) + __expf(v1.y - mr)) + (__expf(v1.z - mr) + __expf(v1.w - mr));
+                    e += in0 ? e0 : 0.f;
+                    e += in1 ? e1 : 0.f;
+                    rs[nt] = e;
+                    rm[nt] = mn;
+                }
+            }
+            c0 = n0;
+            c1 = n1;
+        }
+    }
+#undef ST2_LOAD
+    if constexpr (STATS) {
+        // the four lane groups of a row, then the eight waves through LDS (the h2 image is dead: one barrier in front)
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) {
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                const float m2 = __shfl_xor(rm[nt], o), s2 = __shfl_xor(rs[nt], o);
+                const float mn = fmaxf(rm[nt], m2), mr = fmaxf(mn, -1e30f);
+                rs[nt] = rs[nt] * __expf(rm[nt] - mr) + s2 * __expf(m2 - mr);
+                rm[nt] = mn;
+            }
+        }
+        __syncthreads();
+        float2* red = reinterpret_cast<float2*>(Hs);   // [8 waves][NTB * 16 rows]
+        if (lq == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) red[w * (NTB * 16) + 16 * nt + lr] = make_float2(rm[nt], rs[nt]);
+        }
+        __syncthreads();
+        if (tid < M) {
+            float m = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const float2 q = red[ww * (NTB * 16) + tid];
+                const float mn = fmaxf(m, q.x), mr = fmaxf(mn, -1e30f);
+                sum = sum * __expf(m - mr) + q.y * __expf(q.x - mr);
+                m = mn;
+            }
+            float* o2 = stat + ((size_t)blockIdx.x * M + tid) * 2;
+            o2[0] = m;
+            o2[1] = sum;
+        }
+    }
+}
+
 // part[blockIdx.x][b][h]: this workgroup's share of dh2 (k_da2 sums the slabs)
 // NH = 2: blockIdx.y = which HALF of the 608 columns this workgroup produces, over a chunk of twice the items -- the same number of
 // workgroups and the same W bytes per workgroup, but half the partial slabs (at 25 024 items 98 x 240 KB instead of 196: the slab sum
@@ -2684,6 +2866,14 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 // at 200 000 items on one box, min 81.8 vs 78.6; whole step 968-970 vs 965-968 us.  The serialisation is not inside the workgroup.)
 int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int R, const ltg_gen_acts* acts, float* stat, hipStream_t st) {
     const int I = cfg->n_items, H = cfg->h_enc;
+    if ((cfg->reserved0 & (1 << 26)) == 0) {   // (tuning-knob bit 26: the first form, W tiles through LDS)
+        const int nt2 = (I + 31) / 32, G2 = nt2 < 256 ? nt2 : 256;
+#define LTG_ST2(STATS, NTB) hipLaunchKernelGGL((k_dec1_fwd_stream2<STATS, NTB>), dim3(G2), dim3(ST_NT), 0, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat)
+        if (stat) { if (R <= 112) LTG_ST2(true, 7); else LTG_ST2(true, 8); }
+        else { if (R <= 112) LTG_ST2(false, 7); else LTG_ST2(false, 8); }
+#undef LTG_ST2
+        return G2;
+    }
     const int ntiles = (I + ST_BN - 1) / ST_BN, G = ntiles < 256 ? ntiles : 256;
     const size_t lds = (size_t)2 * ST_BN * ST_LDW * 2;
     if (stat) hipLaunchKernelGGL(k_dec1_fwd_stream<true>, dim3(G), dim3(ST_NT), lds, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat);
