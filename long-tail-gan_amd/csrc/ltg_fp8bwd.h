@@ -6,8 +6,9 @@
 // orientation a consumer needs, by the kernel that produces it (pair rows padded with zeros to NP = a multiple of 128):
 //
 //   producer                      writes (e4m3, the mode's static scales)                       consumed by
-//   fk8s_d_l1<.., true>           A1_8   [n][h12]      (k = h12 contiguous)                     fc layer forward (as before)
+//   fk8t_d_l1                     A1_8   [n][h12]      (k = h12 contiguous)                     fc layer forward (as before)
 //                                 A1T_8  [h12 + 1][NP] (k = pair rows; row h12 = ones)          dw3 / db3 = A1^T . dpre3
+//                                 dA1T_16 [h12][NP]    (bf16: d A1 / d pre, transposed)         job A's epilogue: dpre1 = dA1 * it (no fp32 A1)
 //   k8_d_out                      dpre3_8  [n][h3]     (k = h3)                                 dpre1 = dpre3 . w3^T
 //                                 dpre3T_8 [h3][NP]    (k = pair rows)                          dw3 / db3
 //   k8_d_bwd1 job A epilogue      dpre1T_8 [h12][NP]   (k = pair rows)                          dw1 / dw2 = E^T . dpre1
@@ -61,7 +62,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(NT) void fk8t_d_l1(PairView pv, int h0, int h1, int h2, int NP, const uint8_t* __restrict__ emb8,
                                                 const uint8_t* __restrict__ w1t8, const float* __restrict__ b1,
                                                 const uint8_t* __restrict__ w2t8, const float* __restrict__ b2, DropView dA, DropView dB,
-                                                float keep, uint64_t seed, uint64_t step, float* __restrict__ A1, uint8_t* __restrict__ A1_8,
+                                                float keep, uint64_t seed, uint64_t step, unsigned short* __restrict__ dA1T, uint8_t* __restrict__ A1_8,
                                                 uint8_t* __restrict__ A1T_8) {
     __shared__ __attribute__((aligned(16))) uint8_t s8[2 * (BM + BN) * SG8_LDK];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
@@ -121,11 +122,6 @@ __global__ __launch_bounds__(NT) void fk8t_d_l1(PairView pv, int h0, int h1, int
     const int tid = threadIdx.x;
     const float s_act = (float)(1 << FP8_S_ACT);
     if (n0 + BN <= N) {   // (every layer size is a multiple of 64 in this mode: whole column tiles)
-#pragma unroll
-        for (int q = 0; q < BM * BN / 4 / NT; ++q) {                  // A1: float4 pieces, 16 per row
-            const int e = q * NT + tid, r = e >> 4, c4 = e & 15;
-            if (m0 + r < n) *reinterpret_cast<float4*>(A1 + (size_t)(m0 + r) * h12 + coff + n0 + 4 * c4) = *reinterpret_cast<const float4*>(T + r * LT + 4 * c4);
-        }
         {                                                              // A1_8: 16-byte pieces, 4 per row
             const int r = tid >> 2, p = tid & 3;
             if (m0 + r < n) {
@@ -143,15 +139,23 @@ __global__ __launch_bounds__(NT) void fk8t_d_l1(PairView pv, int h0, int h1, int
         {                                                              // A1T_8: column c, rows 16 p .. 16 p + 15 (a wave = one p: lanes walk the columns)
             const int c = tid & 63, p = tid >> 6;
             if (m0 + 16 * p < NP) {
-                ltg_u32x4 o;
+                ltg_u32x4 o, d0, d1;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
                     for (int x = 0; x < 4; ++x) v[x] = T[(16 * p + 4 * g + x) * LT + c];
                     o[g] = ltg_pack4_fp8(v, s_act);
+                    // ... and the factor the backward multiplies dA1 with, d A1 / d pre = dropout' tanh' (0 for dropped elements and the padded
+                    // rows), as bf16 in the SAME transposed layout: 32 bytes per thread instead of the 64 of an fp32 copy of A1 (round 5)
+                    const unsigned q0 = (unsigned)ltg_f2bf(dact(v[0], keep)) | ((unsigned)ltg_f2bf(dact(v[1], keep)) << 16);
+                    const unsigned q1 = (unsigned)ltg_f2bf(dact(v[2], keep)) | ((unsigned)ltg_f2bf(dact(v[3], keep)) << 16);
+                    if (g < 2) { d0[2 * g] = q0; d0[2 * g + 1] = q1; } else { d1[2 * (g - 2)] = q0; d1[2 * (g - 2) + 1] = q1; }
                 }
                 *reinterpret_cast<ltg_u32x4*>(A1T_8 + (size_t)(coff + n0 + c) * NP + m0 + 16 * p) = o;
+                ltg_u32x4* dd = reinterpret_cast<ltg_u32x4*>(dA1T + (size_t)(coff + n0 + c) * NP + m0 + 16 * p);
+                dd[0] = d0;
+                dd[1] = d1;
             }
         }
     } else {              // a ragged column tile: element by element
@@ -159,11 +163,9 @@ __global__ __launch_bounds__(NT) void fk8t_d_l1(PairView pv, int h0, int h1, int
             const int r = e / BN, c = e % BN, m = m0 + r, nn = n0 + c;
             if (nn >= N || m >= NP) continue;
             const float a = T[r * LT + c];
-            if (m < n) {
-                A1[(size_t)m * h12 + coff + nn] = a;
-                A1_8[(size_t)m * h12 + coff + nn] = ltg_f2fp8(a * s_act);
-            }
+            if (m < n) A1_8[(size_t)m * h12 + coff + nn] = ltg_f2fp8(a * s_act);
             A1T_8[(size_t)(coff + nn) * NP + m] = ltg_f2fp8(a * s_act);
+            dA1T[(size_t)(coff + nn) * NP + m] = ltg_f2bf(dact(a, keep));
         }
     }
 }
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(NT) void k8_gather_t(PairView pv, int h0, int NP, c
 //   job A  dpre1 = (dpre3 . w3^T) * dact(A1)  -> dpre1T_8 [h12][NP] (e4m3, transposed; rows >= n zero)      64 x 64 tiles over (NP, h12)
 //   job B  slab[z] = A1^T . dpre3 (+ ones row -> db3) over the pair rows of chunk z                          64 x 64 tiles over (h12 + 1, h3)
 //   job C  slab[z]: dw4 = A3^T . ds, db4 = sum ds                                                            fp32 column sums
-__global__ __launch_bounds__(NT) void k8_d_bwd1(int n, int NP, int h12, int h3, int nA, int nB, DLayout L, int SP, const float* __restrict__ A1,
+__global__ __launch_bounds__(NT) void k8_d_bwd1(int n, int NP, int h12, int h3, int nA, int nB, DLayout L, int SP, const unsigned short* __restrict__ dA1T,
                                                 const float* __restrict__ A3, const float* __restrict__ ds,
                                                 const uint8_t* __restrict__ dpre3_8, const uint8_t* __restrict__ dpre3T_8,
                                                 const uint8_t* __restrict__ A1T_8, const uint8_t* __restrict__ w3_8, float keep,
@@ -281,12 +283,12 @@ __global__ __launch_bounds__(NT) void k8_d_bwd1(int n, int NP, int h12, int h3, 
         auto epiq = [=] __device__(int r0, int c, const float* v) {
             const int nn = n0 + c;
             if (nn >= h12 || m0 + r0 >= NP) return;
+            // d A1 / d pre of rows m0 + r0 .. + 3 of column nn: four bf16 = one 8-byte load from the transposed copy the forward left (rows >= n: zeros)
+            const uint2 dq = *reinterpret_cast<const uint2*>(dA1T + (size_t)nn * NP + m0 + r0);
+            const float da[4] = {__uint_as_float(dq.x << 16), __uint_as_float(dq.x & 0xFFFF0000u), __uint_as_float(dq.y << 16), __uint_as_float(dq.y & 0xFFFF0000u)};
             float g[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int m = m0 + r0 + x;
-                g[x] = m < n ? v[x] * dact(A1[(size_t)m * h12 + nn], keep) : 0.f;
-            }
+            for (int x = 0; x < 4; ++x) g[x] = m0 + r0 + x < n ? v[x] * da[x] : 0.f;
             *reinterpret_cast<unsigned*>(dpre1T_8 + (size_t)nn * NP + m0 + r0) = ltg_pack4_fp8(g, (float)(1 << FP8_S_G1));
         };
         ltg_sgemm8q<64, 64>(h3, a_row, b_row, 1.f / (float)(1 << (FP8_S_G3 + FP8_S_W)), epi, epiq, s8);

@@ -526,11 +526,12 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
     }
 }
 
-// ---- The streaming decoder forward, second form (round 5): WHO OWNS WHAT is turned round.  Above, the eight waves of a workgroup split the
-// BATCH rows, so every wave needs every W tile: the tile goes through LDS, each wave reads all 39 KB of it (311 KB of LDS reads per 32
-// items and CU), and one barrier per tile keeps the eight waves in lock step -- loads, product and stores add up (56 + 13 + 16 us at
-// 200 000 items).  Here h2 -- the SMALL operand, 100 x 608 bf16 -- is resident in LDS for the whole kernel, laid out in fragment order
-// (every fragment read is one contiguous, conflict-free 1-KiB ds_read_b128), and each WAVE owns its own 32-item tiles:
+// ---- The streaming decoder forward, second form (round 5; slabs of 65 536 items or more): WHO OWNS WHAT is turned round.  Above, the
+// eight waves of a workgroup split the BATCH rows, so every wave needs every W tile: the tile goes through LDS, each wave reads all 39 KB
+// of it (311 KB of LDS reads per 32 items and CU), and one barrier per tile keeps the eight waves in lock step -- loads, product and
+// stores add up (56 + 13 + 16 us at 200 000 items).  Here h2 -- the SMALL operand, 100 x 608 bf16 -- is resident in LDS for the whole
+// kernel, laid out in fragment order (every fragment read is one contiguous, conflict-free 1-KiB ds_read_b128), and each WAVE owns its
+// own 32-item tiles:
 //   * items are the M dimension of v_mfma_f32_16x16x32_bf16 (A = W_p1t shadow rows, B = h2^T): a lane's A fragment is 16 contiguous
 //     bytes of ONE shadow row, loaded global -> VGPR in fragment order (16 rows x 64 B per wave instruction: every byte of a 128-B
 //     line is used by two consecutive K steps) -- no LDS staging of W, no barrier in the loop, the waves drift apart and one wave's
@@ -543,19 +544,27 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
 //     stores and across tile boundaries, with no register-set swap (19 is odd: unit u and u + 19 sit in the same registers);
 //   * the accumulator of a lane is four CONSECUTIVE items of one batch row: logits leave as 16-B stores, 64 B contiguous per row and
 //     instruction (128 B per row over the two sub-tiles), and the softmax statistics stay per lane (one (max, sum exp) pair per batch
-//     tile), merged over the four lane groups and the eight waves once at the end -- same stat[workgroup][row] = (max, sum) output.
-// No branch in the loop: indices are clamped (a wave's last tile re-requests one 64-B line instead of a next tile: no HBM traffic),
-// rows >= M mirror row M - 1, items >= I mirror the slab's last four items, so every s_waitcnt is an exact count.  Summation order over
-// K differs from the first form's (there: per 32-wide K step across four lane groups as well -- here the same; tiles and lanes differ
-// in which items they hold, not in how a logit is added up), so the logits are the same sums; bit-identity is not relied upon.
+//     tile), merged over the four lane groups and the eight waves once at the end -- same stat[workgroup][row] = (max, sum) output;
+//   * the bias of a tile goes through the SCALAR unit (one s_load of the tile's 32 values, the lane picks its two groups of four with
+//     bit masks): as a vector load it joins the in-order vmcnt queue wherever the compiler sinks it -- K step 14 -- and the wait for it
+//     in front of the stores then drains 15 of the ring's 19 units.
+// No branch in the loop: indices are clamped (a wave's last tile re-requests the tile it has just read instead of a next one: L2 hits),
+// rows >= M mirror row M - 1, items >= I mirror the slab's last four, so every s_waitcnt is an exact count.
+// Where it is used, and why not everywhere (round 5, profiles/README.md): ALONE on the chip it runs 74.7 us at 200 000 items against the
+// first form's 79.2 (4.33 TB/s of a box that copies at 5.2) and 17.9 against 19.9 us at 25 024; INSIDE the one-call step of a 20 000- /
+// 25 024-item slab the step got 1-3 / 4 us LONGER with it: its two waves per SIMD take all 512 registers (256 each), so the side
+// stream's clock kernels (26-30 VGPRs), which the first form (2 x 224) leaves room for, wait for whole CUs to drain.  A 16-item-tile
+// variant held to 168 VGPRs co-resides again but reads twice the LDS bytes per item: 85 us alone at 200 000 items, no gain in any step.
+// So: this form for the HBM-bound slabs, the first form below 65 536 items.
 // NTB: 16-row batch tiles (7 for <= 112 rows: the 100-row batches of config.ini; 8 up to 128 rows).
 constexpr int ST2_UNITS = 2 * ST_KS;   // 38 load units per 32-item tile
 constexpr int ST2_RING = ST_KS;        // 19 units in flight per wave
+constexpr int ST2_MIN_ITEMS = 65536;
 template <bool STATS, int NTB>
 __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H, const float* __restrict__ h2,
                                                             const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
                                                             float* __restrict__ logits, float* __restrict__ stat) {
-    __shared__ __attribute__((aligned(16))) ltg_u32x4 Hs[ST_KS * NTB * 64];   // h2 in B-fragment order: [K step][batch tile][lane] x 16 B
+    extern __shared__ __attribute__((aligned(16))) ltg_u32x4 Hs[];   // h2 in B-fragment order: [K step][batch tile][lane] x 16 B = 19 NTB KiB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int ntiles = (I + 31) >> 5, G = gridDim.x, GW = 8 * G;
     // tiles are dealt to waves CU-first (wave w of workgroup g is wave number w * G + g): a slab with fewer tiles than waves spreads over
@@ -563,6 +572,7 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H,
     int t = w * G + (int)blockIdx.x;
     const bool any = t < ntiles;
     const ltg_gchar* Wg = ltg_uniform_ptr(Wb);
+    ltg_gchar* Lg = ltg_uniform_ptr(logits);      // (32-bit byte offsets: the host sends launches of 2^30 logits or more to the first form)
     // byte offset of this lane's A-fragment row in the shadow: item row (tile, sub-tile s, lr), chunk lq of the K step (the K step's
     // 64 B are added as an immediate).  Items past the end mirror the slab's last four (I % 4 == 0: a lane's four output items are all
     // inside or all outside): the product of a mirrored row group is the last group's, and it is stored to the last group's address.
@@ -615,12 +625,33 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H,
 #pragma unroll 1
         for (; t < ntiles; t += GW) {
             const bool more = t + GW < ntiles;
-            // the next tile's row offsets; on the wave's last tile every lane re-requests ONE line (offset 0 + the K step): no branch, no traffic
-            const unsigned n0 = more ? rowoff(t + GW, 0) : 0u, n1 = more ? rowoff(t + GW, 1) : 0u;
-            // bias of the lane's 2 x 4 output items (requested before anything waits in this tile)
+            // the next tile's row offsets; on the wave's last tile the ring re-requests the tile it has just read (a uniform select, no branch:
+            // a join of divergent paths would cost every wait its exact count): served by the L2, no HBM traffic
+            const int tnx = more ? t + GW : t;
+            const unsigned n0 = rowoff(tnx, 0), n1 = rowoff(tnx, 1);
             const int i0 = t * 32 + 4 * lq, i1 = i0 + 16;
             const int g0 = i0 < I ? i0 : I - 4, g1 = i1 < I ? i1 : I - 4;
-            const float4 bias0 = *reinterpret_cast<const float4*>(bp1 + g0), bias1 = *reinterpret_cast<const float4*>(bp1 + g1);
+            // bias of the lane's 2 x 4 output items: the tile's 32 values through the scalar unit (I % 8 == 0: 32-B aligned), picked by bit masks
+            // (?: on scalar-loaded values is turned into branches)
+            const int bbase = __builtin_amdgcn_readfirstlane(min(t * 32, I - 32));
+            typedef float st2_f8 __attribute__((ext_vector_type(8)));
+            const st2_f8* __restrict__ bs = reinterpret_cast<const st2_f8*>(bp1 + bbase);
+            const st2_f8 bq0 = bs[0], bq1 = bs[1], bq2 = bs[2], bq3 = bs[3];
+            auto pick4 = [&](int g) -> float4 {
+                const int sel = (g - bbase) >> 2;      // 0 .. 7: which group of four
+                unsigned km[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) km[k] = 0u - (unsigned)(sel == k);
+                float4 r;
+                float* rp = &r.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rp[j] = __uint_as_float((__float_as_uint(bq0[j]) & km[0]) | (__float_as_uint(bq0[4 + j]) & km[1]) | (__float_as_uint(bq1[j]) & km[2]) |
+                                            (__float_as_uint(bq1[4 + j]) & km[3]) | (__float_as_uint(bq2[j]) & km[4]) | (__float_as_uint(bq2[4 + j]) & km[5]) |
+                                            (__float_as_uint(bq3[j]) & km[6]) | (__float_as_uint(bq3[4 + j]) & km[7]));
+                return r;
+            };
+            const float4 bias0 = pick4(g0), bias1 = pick4(g1);
             ltg_f32x4 acc[2][NTB];
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt) {
@@ -648,20 +679,22 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H,
             }
             // epilogue: + bias, 16-B stores (row 16 nt + lr, items g .. g + 3), running softmax statistics of the row over this lane's items
             const bool in0 = i0 < I, in1 = i1 < I;
+            int lr_v = lr;      // (opaque: hoisted out of the loop the NTB row offsets cost registers the ring needs)
+            asm volatile("" : "+v"(lr_v));
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt) {
-                const size_t ro = (size_t)min(16 * nt + lr, M - 1) * (size_t)I;
-                const float4 v0 = make_float4(acc[0][nt][0] + bias0.x, acc[0][nt][1] + bias0.y, acc[0][nt][2] + bias0.z, acc[0][nt][3] + bias0.w);
-                const float4 v1 = make_float4(acc[1][nt][0] + bias1.x, acc[1][nt][1] + bias1.y, acc[1][nt][2] + bias1.z, acc[1][nt][3] + bias1.w);
-                *reinterpret_cast<float4*>(logits + ro + g0) = v0;
-                *reinterpret_cast<float4*>(logits + ro + g1) = v1;
+                const unsigned ro = (unsigned)min(16 * nt + lr_v, M - 1) * (unsigned)I;
+                const ltg_f32x4 v0{acc[0][nt][0] + bias0.x, acc[0][nt][1] + bias0.y, acc[0][nt][2] + bias0.z, acc[0][nt][3] + bias0.w};
+                const ltg_f32x4 v1{acc[1][nt][0] + bias1.x, acc[1][nt][1] + bias1.y, acc[1][nt][2] + bias1.z, acc[1][nt][3] + bias1.w};
+                *(ltg_f32x4 __attribute__((address_space(1)))*)(Lg + (ro + (unsigned)g0) * 4u) = v0;
+                *(ltg_f32x4 __attribute__((address_space(1)))*)(Lg + (ro + (unsigned)g1) * 4u) = v1;
                 if constexpr (STATS) {
-                    const float m0 = in0 ? fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)) : -INFINITY;
-                    const float m1 = in1 ? fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)) : -INFINITY;
+                    const float m0 = in0 ? fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v0[2], v0[3])) : -INFINITY;
+                    const float m1 = in1 ? fmaxf(fmaxf(v1[0], v1[1]), fmaxf(v1[2], v1[3])) : -INFINITY;
                     const float mn = fmaxf(rm[nt], fmaxf(m0, m1)), mr = fmaxf(mn, -1e30f);
                     float e = rs[nt] * __expf(rm[nt] - mr);
-                    const float e0 = (__expf(v0.x - mr) + __expf(v0.y - mr)) + (__expf(v0.z - mr) + __expf(v0.w - mr));
-                    const float e1 = (__expf(v1.x - mr) + __expf(v1.y - mr)) + (__expf(v1.z - mr) + __expf(v1.w - mr));
+                    const float e0 = (__expf(v0[0] - mr) + __expf(v0[1] - mr)) + (__expf(v0[2] - mr) + __expf(v0[3] - mr));
+                    const float e1 = (__expf(v1[0] - mr) + __expf(v1[1] - mr)) + (__expf(v1[2] - mr) + __expf(v1[3] - mr));
                     e += in0 ? e0 : 0.f;
                     e += in1 ? e1 : 0.f;
                     rs[nt] = e;
@@ -1287,7 +1320,10 @@ __global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, i
         auto a = [=] __device__(int m, int k) -> float { return dpre3[(size_t)m * h3 + k]; };
         auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)nn * h3 + k]; };
         auto epi = [=] __device__(int m, int nn, float acc) {
-            dpre1[(size_t)m * h12 + nn] = acc * dact(A1[(size_t)m * h12 + nn], keep);
+            // (MODE 2, e4m3 operands: the derivative rounded to bf16 -- the form the operand-format backward stores it in (ltg_fp8bwd.h:
+            // dA1T_16), so that both fp8 paths feed the e4m3 conversion of dpre1 the same values)
+            const float da = dact(A1[(size_t)m * h12 + nn], keep);
+            dpre1[(size_t)m * h12 + nn] = acc * (MODE == 2 ? __uint_as_float((unsigned)ltg_f2bf(da) << 16) : da);
         };
         if constexpr (V) {
             auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dpre3 + (size_t)min(m, n - 1) * h3, k, h3, m < n); };
@@ -2682,6 +2718,7 @@ struct Workspace {
     uint8_t* A1_8;      // the branch layers' output in e4m3 (fp8 operand storage of the wide discriminator)
     // operand-format storage of the fp8 backward (ltg_fp8bwd.h): transposed / row-major e4m3 copies, pair rows padded to np8
     uint8_t *A1T_8, *dpre3_8, *dpre3T_8, *dpre1T_8, *ET_8;
+    unsigned short* dA1T_16;
     int np8;
     size_t bytes;
 };
@@ -2740,6 +2777,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
         auto take8 = [&](size_t nbytes) { return reinterpret_cast<uint8_t*>(take(f8 ? (nbytes + 3) / 4 : 1)); };
         w.np8 = (int)np;
         w.A1T_8 = take8((h12 + 1) * np);
+        w.dA1T_16 = reinterpret_cast<unsigned short*>(take8(2 * h12 * np));   // dA1 / dpre1 of the branch layers, bf16, transposed (ltg_fp8bwd.h)
         w.dpre3_8 = take8(P * h3);
         w.dpre3T_8 = take8(h3 * np);
         w.dpre1T_8 = take8(h12 * np);
@@ -2866,9 +2904,12 @@ void fwd_stage_enc(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
 // at 200 000 items on one box, min 81.8 vs 78.6; whole step 968-970 vs 965-968 us.  The serialisation is not inside the workgroup.)
 int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int R, const ltg_gen_acts* acts, float* stat, hipStream_t st) {
     const int I = cfg->n_items, H = cfg->h_enc;
-    if ((cfg->reserved0 & (1 << 26)) == 0) {   // (tuning-knob bit 26: the first form, W tiles through LDS)
+    // the second form for the HBM-bound slabs (see k_dec1_fwd_stream2); tuning-knob bit 26: the first form at every size, bit 17: the second
+    // form from 8 192 items (A/B measurements)
+    const int st2_min = (cfg->reserved0 & (1 << 17)) ? 8192 : ST2_MIN_ITEMS;
+    if ((cfg->reserved0 & (1 << 26)) == 0 && I >= st2_min && (size_t)R * (size_t)I < ((size_t)1 << 30)) {
         const int nt2 = (I + 31) / 32, G2 = nt2 < 256 ? nt2 : 256;
-#define LTG_ST2(STATS, NTB) hipLaunchKernelGGL((k_dec1_fwd_stream2<STATS, NTB>), dim3(G2), dim3(ST_NT), 0, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat)
+#define LTG_ST2(STATS, NTB) hipLaunchKernelGGL((k_dec1_fwd_stream2<STATS, NTB>), dim3(G2), dim3(ST_NT), (size_t)ST_KS * NTB * 64 * 16, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat)
         if (stat) { if (R <= 112) LTG_ST2(true, 7); else LTG_ST2(true, 8); }
         else { if (R <= 112) LTG_ST2(false, 7); else LTG_ST2(false, 8); }
 #undef LTG_ST2
@@ -3039,7 +3080,7 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
             const int NP = d8_np(n);
             hipLaunchKernelGGL(k8_gather_t, dim3(h0 / 64, NP / 64, 2), dim3(NT), 0, st, pv, h0, NP, d->emb_fp8, w.ET_8);
             LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL((fk8t_d_l1<64, 64>), dim3((h1 + 63) / 64 + (h2 + 63) / 64, NP / 64), dim3(NT), 0, st, pv, h0, h1, h2, NP,
-                                                          d->emb_fp8, d->w1t_fp8, d->p[1], d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.A1, w.A1_8, w.A1T_8));
+                                                          d->emb_fp8, d->w1t_fp8, d->p[1], d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.dA1T_16, w.A1_8, w.A1T_8));
             LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL((fk8s_d_l2<64, 64>), grid2(h3, n, 64, 64), dim3(NT), 0, st, n, h12, h3, w.A1_8, d->w3t_fp8, d->p[5], dC, keep,
                                                           cfg->seed, step, w.A3));
             hipLaunchKernelGGL(k8_d_out, dim3(NP / 16), dim3(NT), 0, st, pv, h3, NP, w.A3, d->p[6], d->p[7], keep, w.y, w.ds, w.lrow, w.dpre3_8, w.dpre3T_8);
@@ -3203,7 +3244,7 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         const int nA = (NP / 64) * ((h12 + 63) / 64);
         const int nB = ks8 * ((h12 + 1 + 63) / 64) * ((h3 + 63) / 64);
         const int nC = ks8 * ((h3 + 1 + 31) / 32);
-        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(k8_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, NP, h12, h3, nA, nB, L, SP, w.A1, w.A3, w.ds, w.dpre3_8, w.dpre3T_8,
+        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(k8_d_bwd1, dim3(nA + nB + nC), dim3(NT), 0, st, n, NP, h12, h3, nA, nB, L, SP, w.dA1T_16, w.A3, w.ds, w.dpre3_8, w.dpre3T_8,
                                                         w.A1T_8, disc->w3_fp8, o->keep_prob, w.dpre1T_8, w.slab));
         const int n2 = ks8 * ((h0 + 1 + 63) / 64) * (h1 / 64 + h2 / 64);
         LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(k8_d_bwd2, dim3(n2), dim3(NT), 0, st, NP, h0, h1, h2, L, SP, w.ET_8, w.dpre1T_8, w.slab));
@@ -3990,6 +4031,10 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // less.  profiles/r4_ab_c4_two_launch_split.txt, r4_c4_timeline_two_launch_split.txt.)
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
                                                   acts->h2, gates ? LtgGate{pp->sync + 7, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE, poison));
+    // (Round 5, measured and removed: with ONE rank no exchange sits between the row statistics and dlogits, so k_row_stats_merge was folded
+    // into k_dlogits_combine -- every (segment, row) workgroup re-folding the 256 (max, sum exp) pairs and the sparse terms of its row, the
+    // step's scalars from the last of B tickets; bit-identical.  The fused kernel took 16.9 us against 10.0 + 5.6 for the two launches:
+    // 143 against 139.5 us per step at 20 000 items, 102 against 101 at 25 024 -- the redundancy costs what the launch saved.)
     {
         int G = 0;
         LTG_PROBED(pr, LTG_K_DEC1_FWD, G = launch_dec1_fwd_stream(cfg, gen, B, acts, w.segpart, st));

@@ -242,8 +242,11 @@ def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64, dq=None):
     g["b3"] = qC.sum(0)
     dhin = qC @ _dq(f(D["w3"]), dq, "w").T
     h1 = mA.shape[1]
-    dpA = dhin[:, :h1] * mA / dtype(keep) * (1 - T["tA"] ** 2)
-    dpB = dhin[:, h1:] * mB / dtype(keep) * (1 - T["tB"] ** 2)
+    fA, fB = mA / dtype(keep) * (1 - T["tA"] ** 2), mB / dtype(keep) * (1 - T["tB"] ** 2)
+    if dq == "fp8":     # the fp8 mode keeps d a / d pre of the branch layers as bf16 (csrc/ltg_fp8bwd.h: dA1T_16), not an fp32 copy of a
+        fA, fB = bf16_round(fA.astype(np.float32)).astype(dtype), bf16_round(fB.astype(np.float32)).astype(dtype)
+    dpA = dhin[:, :h1] * fA
+    dpB = dhin[:, h1:] * fB
     if dq is not None:
         dpA, dpB = dpA.astype(np.float32).astype(dtype), dpB.astype(np.float32).astype(dtype)
     qA, qB = _dq(dpA, dq, "g1"), _dq(dpB, dq, "g1")

@@ -115,6 +115,36 @@ def test_forward_parity_over_a_span_of_batches(I, rows):
         r0 += n
 
 
+@pytest.mark.parametrize("I,B", [(8200, 100), (25032, 128), (20000, 1), (65536, 100), (65544, 113)])
+def test_forward_parity_of_the_second_streaming_form(I, B):
+    """k_dec1_fwd_stream2 (h2 resident in LDS, every wave its own 32-item tiles; the library uses it from 65 536 items) forced at every
+    streaming size through tuning-knob bit 17: ragged slabs (I % 32 = 8), 8 batch tiles (B > 112), a single row, fewer tiles than waves --
+    logits, lse and probabilities against the oracle exactly as test_forward_parity states them, and against the first form (bit 26)."""
+    import torch
+    rng, X, P = _problem(I, B, seed=I + B)
+    outs = {}
+    for knob in (1 << 17, 1 << 26):
+        eng = _engine(I, "bf16")
+        eng.cfg.reserved0 = knob
+        eng.set_generator(Hh.gen_to_engine(P))
+        acts = eng.new_acts(B)
+        batch = _upload_batch(eng, X)
+        probs = torch.empty(B, I, dtype=torch.float32, device=eng.device)
+        eng.forward(batch, acts, keep_prob=0.75, is_training=1.0, rng_step=7, probs_out=probs)
+        torch.cuda.synchronize()
+        outs[knob] = (acts.logits[:B].cpu().numpy().copy(), acts.lse[:B].cpu().numpy().copy(), probs.cpu().numpy())
+        del eng
+    mask = Hh.dropout_mask_dense(SEED, 7, B, I, 0.75)
+    eps = Hh.eps_dense(SEED, 7, B, 200)
+    F = O.vae_forward(P, X.toarray(), mask, 0.75, eps, 1.0, 1.0, np.float64, quant=True)
+    lg, lse, p = outs[1 << 17]
+    assert Hh.rel_err(lg, F["logits"]) < 1e-3
+    assert np.abs(lse - F["lse"]).max() < 1e-3
+    assert np.max(np.abs(p - F["probs"]) / F["probs"]) < 1e-3
+    lg1, lse1, p1 = outs[1 << 26]
+    assert Hh.rel_err(lg, lg1) < 1e-5 and np.abs(lse - lse1).max() < 1e-5      # (same K order per logit; other tiles, other lanes)
+
+
 def _check_adam_move(move_got, move_want, m_want, lr_t, tag):
     """First-step Adam moves are lr_t*0.1g/(0.0316|g|+1e-8): a sign-like function of g, so rounding
     noise on a near-cancelling gradient (|g| << its terms) is amplified without bound.  Elements
