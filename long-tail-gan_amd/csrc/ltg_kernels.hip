@@ -3079,6 +3079,9 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
             // orientation its GEMM contracts over (ltg_fp8bwd.h)
             const int NP = d8_np(n);
             hipLaunchKernelGGL(k8_gather_t, dim3(h0 / 64, NP / 64, 2), dim3(NT), 0, st, pv, h0, NP, d->emb_fp8, w.ET_8);
+            // (Round 5, measured and removed: the branch layers' product on 128 x 64 / 128 x 128 tiles -- half the operand bytes through the L1s per
+            // output -- ran 38.3 / 72.1 us against the 64 x 64 tiles' 30.1 us on the same box: the loop is bound by the latency of its staged K
+            // blocks, which 720 small workgroups hide better than 360 / 180 large ones, not by L2 bandwidth.)
             LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL((fk8t_d_l1<64, 64>), dim3((h1 + 63) / 64 + (h2 + 63) / 64, NP / 64), dim3(NT), 0, st, pv, h0, h1, h2, NP,
                                                           d->emb_fp8, d->w1t_fp8, d->p[1], d->w2t_fp8, d->p[3], dA, dB, keep, cfg->seed, step, w.dA1T_16, w.A1_8, w.A1T_8));
             LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL((fk8s_d_l2<64, 64>), grid2(h3, n, 64, 64), dim3(NT), 0, st, n, h12, h3, w.A1_8, d->w3t_fp8, d->p[5], dC, keep,
@@ -4030,7 +4033,14 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
     // 290 us instead of 44 and the update 30 us longer: the step is HBM-bound, overlapping two bandwidth-bound kernels moves no byte
     // less.  profiles/r4_ab_c4_two_launch_split.txt, r4_c4_timeline_two_launch_split.txt.)
     LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6], acts->kl_rows,
-                                                  acts->h2, gates ? LtgGate{pp->sync + 7, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE, poison));
+                                                  acts->h2,
+#ifdef LTG_X_NO_W7   // MEASUREMENT BUILD ONLY (results wrong): the streaming forward does not wait for the end of the previous weight update -- the
+                     // upper bound of what ANY earlier hand-over of the shadow (tile by tile, word 7 sooner) could gain
+                                                  LTG_NO_GATE,
+#else
+                                                  gates ? LtgGate{pp->sync + 7, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE,
+#endif
+                                                  poison));
     // (Round 5, measured and removed: with ONE rank no exchange sits between the row statistics and dlogits, so k_row_stats_merge was folded
     // into k_dlogits_combine -- every (segment, row) workgroup re-folding the 256 (max, sum exp) pairs and the sparse terms of its row, the
     // step's scalars from the last of B tickets; bit-identical.  The fused kernel took 16.9 us against 10.0 + 5.6 for the two launches:

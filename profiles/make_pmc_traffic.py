@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-ALIAS = {"dh2_partial": "dh2", "dh2_stream": "dh2", "dec1_fwd_stream": "dec1_fwd", "dec1_bwd_adam_stream": "dec1_bwd_adam",
+ALIAS = {"dh2_partial": "dh2", "dh2_stream": "dh2", "dec1_fwd_stream": "dec1_fwd", "dec1_fwd_stream2": "dec1_fwd", "dec1_bwd_adam_stream": "dec1_bwd_adam",
          "dense_fwd<0>": "enc1", "dense_fwd<1>": "dec0", "row_partial_seg": "row_partial", "dec1": "dec1_fwd", "enc0_grad_rows": "enc0_grad", "q0_touch_slice": "q0_touch_unique"}
 
 

@@ -235,7 +235,10 @@ G_CASES = [(1000, 100, "step"), (333, 17, "step"), (6000, 100, "step"), (6000, 1
            (8200, 150, "step"), (8200, 100, "one-call"), (20000, 100, "step"), (25024, 100, "step"),
            (25024, 100, "one-call-config-d"), (200000, 100, "step"), (200000, 100, "one-call"),
            # ragged slabs (I % 32 != 0): the last I % 32 item rows go through the streaming kernels' tail path
-           (25032, 100, "one-call"), (200008, 100, "step")]
+           (25032, 100, "one-call"), (200008, 100, "step"),
+           # tuning-knob bit 18: the generic (round-1) kernels -- what sizes the latency path does not serve fall back to (z_dim % 4 != 0,
+           # more than 256 rows, discriminator layers that are not multiples of 4) -- over the same oracle, small and streaming-sized slabs
+           (1000, 100, "step-generic"), (333, 17, "step-generic"), (8200, 100, "step-generic")]
 
 
 def _g_step_case(precision, I, B, path, warm):
@@ -273,6 +276,8 @@ def _g_step_case(precision, I, B, path, warm):
     # ---- device
     eng = _engine(I, precision, hs=hs, lr=1e-3)
     assert eng.Z == 200
+    if path.endswith("-generic"):
+        eng.cfg.reserved0 = 1 << 18
     if warm:
         eng.set_generator(Hh.gen_to_engine(P), m=Hh.gen_to_engine(m0), v=Hh.gen_to_engine(v0))
     else:
@@ -356,6 +361,12 @@ def test_d_step_parity(nr, nf):
     _d_step_case(nr, nf, warm=False)
 
 
+@pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7)])
+def test_d_step_parity_of_the_generic_kernels(nr, nf):
+    """tuning-knob bit 18: the discriminator step through the generic (round-1) kernels, same oracle and bounds"""
+    _d_step_case(nr, nf, warm=False, knob=1 << 18)
+
+
 @pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (260, 250)])
 def test_d_step_adam_quotient_from_warm_moments(nr, nf):
     """The D step from injected non-zero Adam moments at shared step t = 212 (train.py:160-163): the flat Adam sweep's theta move,
@@ -363,7 +374,7 @@ def test_d_step_adam_quotient_from_warm_moments(nr, nf):
     _d_step_case(nr, nf, warm=True)
 
 
-def _d_step_case(nr, nf, warm):
+def _d_step_case(nr, nf, warm, knob=0):
     import torch
     from ltgan.engine import Pairs
     I = 500
@@ -410,6 +421,7 @@ def _d_step_case(nr, nf, warm):
     ad.apply(D64, g, O.D_KEYS)
     # device
     eng = _engine(I, "fp32", hs=hs, lr=1e-3)
+    eng.cfg.reserved0 = knob
     emb, darr = Hh.disc_to_engine(D)
     if warm:
         eng.set_discriminator(emb, darr, m=[m0[k] for k in O.D_KEYS], v=[v0[k] for k in O.D_KEYS])
