@@ -62,7 +62,8 @@ typedef struct ltg_config {
      *   bit 14 column-blocked sparse W_q0 gradient; bit 18 the round-1 kernels instead of csrc/ltg_fast.h; bit 19 / 24 fp8 discriminator:
      *   backward converts on the fly / register-resident forward tiles; bits 21 / 22 softmax statistics from a second pass / fp32 dlogits;
      *   bit 23 register-resident forward-only towers; bit 25 sparse gradient and Adam as two launches; bits 27-30 = k: the streaming
-     *   weight update with 256 - 8 k workgroups */
+     *   weight update with 256 - 8 k workgroups; bit 26 / 17: the streaming decoder forward's first form at every size / its second form
+     *   (h2 resident in LDS, per-wave item tiles; default from 65 536 items) from 8 192 items */
     int32_t reserved0;
     /* item shard of this rank: it owns global items [item_lo, item_lo + n_items); n_items_global = 0 means
      * unsharded (n_items_global = n_items, item_lo = 0).  W_q0 / W_p1t / b_p1 and their Adam moments hold
