@@ -20,6 +20,19 @@ __device__ __forceinline__ int xcd_chunk(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// The same for a 2-D grid of (column tile, row tile) workgroups: blockIdx -> tile ids with the ROW tiles of one column tile -- which share
+// the column block of the weight matrix, the large operand of these latency-bound products -- consecutive, so that they meet in one XCD's L2.
+// Dealt round-robin every row tile of a column fetched that block into another L2: fk_dec1 moved 21 MB per launch for 3 MB of operands,
+// fk_enc1 10 MB for 1.2 (profiles/r4_pmc_traffic.json).  Round 5, Askubuntu_Sample G step with this order in fk_g_tail, fk_dec1, fk_dh2:
+// 81.8 -> 78.9 ms per epoch on one box.
+struct LtgTile2 {
+    int x, y;   // column tile, row tile
+};
+__device__ __forceinline__ LtgTile2 xcd_tile2() {
+    const int t = xcd_chunk((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    return LtgTile2{t / (int)gridDim.y, t % (int)gridDim.y};
+}
+
 // a * b rounded to fp32 on its own: never contracted into an fma with a following addition (HIP compiles with
 // -ffp-contract=fast-honor-pragmas; __fmul_rn is a plain product there)
 __device__ __forceinline__ float ltg_mul_rounded(float a, float b) {
@@ -56,13 +69,14 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
     // end_wait (one-call step): the kernel behind this one, dec-0, overwrites h2, which the previous step's weight update reads in its
     // prologue on the side stream -- ONE thread of this launch polls for the update's word as the last thing it does
     __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, Z2 = 2 * Z;
+    const LtgTile2 tl = xcd_tile2();
+    const int m0 = tl.y * 16, n0 = tl.x * 16, Z2 = 2 * Z;
     auto col = [=] __device__(int c) { return min(n0 + (c & 15), Z - 1) + (c >> 4) * Z; };   // logical tile column -> column of mulv
     auto a_ld = [=] __device__(int, int m, int k) {
         if constexpr (PRE) return LtgRaw2{ltg_ld4(h1 + (size_t)m * H + k), ltg_ld4(bq0 + k)};
         else return ltg_ld4(h1 + (size_t)m * H + k);
     };
-    const bool keep_h1 = PRE && blockIdx.x == 0;
+    const bool keep_h1 = PRE && tl.x == 0;
     auto a_xf = [=] __device__(auto raw, int, int m, int k) {
         if constexpr (PRE) {
             const ltg_f32x4 t{tanhf(raw.x[0] + raw.y[0]), tanhf(raw.x[1] + raw.y[1]), tanhf(raw.x[2] + raw.y[2]), tanhf(raw.x[3] + raw.y[3])};
@@ -109,9 +123,10 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     // shadow of W_p1t, which that update rewrites until it ends: one thread of this launch polls for its end as the last thing it does.
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
     if (ltg_poisoned(poison)) return;
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const LtgTile2 tl = xcd_tile2();
+    const int m0 = tl.y * 16, n0 = tl.x * 16;
     float kl = 0.f;
-    if (blockIdx.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns
+    if (tl.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns
         const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
         const float* mrow = mulv + (size_t)min(m0 + rr, B - 1) * 2 * Z;
         for (int j = cc; j < Z; j += 16) {
@@ -126,12 +141,12 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
         if (ok) h2[(size_t)m * H + n] = tanhf(v + biasv);
     };
     ltg_rgemm<1, 1, 1, 1, 4, 4>(B, H, Z, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
-    if (blockIdx.x == 0) {
+    if (tl.x == 0) {
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) kl += __shfl_xor(kl, o);    // the 16 lanes of a row are consecutive
         if ((threadIdx.x & 15) == 0 && m0 + (threadIdx.x >> 4) < B) kl_rows[m0 + (threadIdx.x >> 4)] = kl;
     }
-    if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);   // (block column 1: not one that adds up the KL)
+    if (tl.x == 1 && tl.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);   // (tile column 1: not one that adds up the KL)
 }
 
 // dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)          [B][2Z]
@@ -187,20 +202,22 @@ __global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __
                                             const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
                                             float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    dz_tile(B, Z, H, da2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, blockIdx.y * 16, blockIdx.x * 16, lds);
+    const LtgTile2 tl = xcd_tile2();
+    dz_tile(B, Z, H, da2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, tl.y * 16, tl.x * 16, lds);
 }
 __global__ __launch_bounds__(NT) void fk_dz_dh2(int B, int Z, int H, const float* __restrict__ dh2, const float* __restrict__ h2,
                                                 const float* __restrict__ Wp0, const float* __restrict__ mulv, const float* __restrict__ eps_in,
                                                 float is_training, float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv,
                                                 float* __restrict__ da2_out) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    dz_tile<true>(B, Z, H, dh2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, blockIdx.y * 16, blockIdx.x * 16, lds, h2, da2_out,
-                  blockIdx.x == 0);
+    const LtgTile2 tl = xcd_tile2();
+    dz_tile<true>(B, Z, H, dh2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, tl.y * 16, tl.x * 16, lds, h2, da2_out, tl.x == 0);
 }
 __global__ __launch_bounds__(NT) void fk_dh1(int B, int H, int Z2, const float* __restrict__ dmlv, const float* __restrict__ Wq1,
                                              const float* __restrict__ h1, float* __restrict__ da1) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    dh1_tile(B, H, Z2, dmlv, Wq1, h1, da1, blockIdx.y * 16, blockIdx.x * 16, lds);
+    const LtgTile2 tl = xcd_tile2();
+    dh1_tile(B, H, Z2, dmlv, Wq1, h1, da1, tl.y * 16, tl.x * 16, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -879,6 +896,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
     const int tm = (h0 + 1 + 15) / 16;
     const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
     const int per_z = tm * (tn1 + tn2);
+    // (Round 5, measured and removed: the tiles of one row chunk z in contiguous runs per XCD -- D step 57.7-58.2 against 57.2-57.4 us.)
     const int z = blockIdx.x / per_z, t = blockIdx.x % per_z;
     const int m0 = (t / (tn1 + tn2)) * 16;
     const int tcol = t % (tn1 + tn2);
@@ -980,7 +998,10 @@ template <bool BF>
 __global__ __launch_bounds__(NT) void fk_dec1(int B, int I, int H, const float* __restrict__ h2, const float* __restrict__ Wp1t,
                                               const float* __restrict__ bp1, float* __restrict__ logits) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    // the row tiles of one column tile (= the same 16 rows of W_p1t) meet in ONE XCD's L2: contiguous runs of the tile ids per XCD, column
+    // tile major (round 5: dealt round-robin every row tile of a column fetched those rows into another L2 -- 21 MB of traffic for 3 MB)
+    const LtgTile2 tl = xcd_tile2();
+    const int m0 = tl.y * 16, n0 = tl.x * 16;
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(h2 + (size_t)m * H + k); };
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4(Wp1t + (size_t)n * H + k); };
     auto xf = [=] __device__(ltg_f32x4 v, int, int, int) { return BF ? ltg_bf16r4(v) : v; };
@@ -1106,7 +1127,8 @@ template <bool BF>
 __global__ __launch_bounds__(NT) void fk_dh2(int B, int I, int H, const float* __restrict__ dlog, const float* __restrict__ Wp1t,
                                              const float* __restrict__ h2, float* __restrict__ da2) {
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const LtgTile2 tl = xcd_tile2();     // (as fk_dec1: a column block of W_p1t per XCD)
+    const int m0 = tl.y * 16, n0 = tl.x * 16;
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dlog + (size_t)m * I + k); };
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wp1t + (size_t)k * H + n, H); };
     auto xf = [=] __device__(ltg_f32x4 v, int, int, int) { return BF ? ltg_bf16r4(v) : v; };
@@ -1259,7 +1281,12 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     const int B = a.B, I = a.I, H = a.H, Z = a.Z;
     // (The dz / dh1 tiles once rode in front of the jobs -- three launches of this kernel per step, measured +23 us; the variant
     // is gone: its 80 operand registers set the register count of the whole kernel and with it the tiles' occupancy.)
+    // Every job's tiles are dealt to the XCDs in CONTIGUOUS runs (xcd_chunk on the job's own block index: blocks whose index agrees mod 8
+    // share an XCD whatever the job's offset in the grid): an XCD then meets an eighth of the row tiles' operand columns (dlog, z, h1, xd) and
+    // every column of the other operand, instead of all of both from all eight L2s (round 5; PMC traffic of the launch 67.3 MB against 39.25
+    // algorithmic before).  Speed only: any placement computes the same values.
     if (bid < a.n1) {
+        bid = xcd_chunk(bid, a.n1);
         const int tn = (H + 1 + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[3], st.m[3], st.v[3], st.p[7], st.m[7], st.v[7]};
         wgrad_adam_tile<BF, false>(B, I, H, a.dlog, I, a.h2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
@@ -1267,6 +1294,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     }
     bid -= a.n1;
     if (bid < a.n2) {
+        bid = xcd_chunk(bid, a.n2);
         const int tn = (H + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[2], st.m[2], st.v[2], st.p[6], st.m[6], st.v[6]};
         wgrad_adam_tile<false, true>(B, Z, H, a.z, Z, a.da2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
@@ -1274,6 +1302,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     }
     bid -= a.n2;
     if (bid < a.n3) {
+        bid = xcd_chunk(bid, a.n3);
         const int tn = (2 * Z + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[1], st.m[1], st.v[1], st.p[5], st.m[5], st.v[5]};
         wgrad_adam_tile<false, true>(B, H, 2 * Z, a.h1, H, a.dmlv, 2 * Z, T, 2 * Z, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
@@ -1281,6 +1310,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     }
     bid -= a.n3;
     if (bid < a.n4 && a.xd) {
+        bid = xcd_chunk(bid, a.n4);
         const int tn = (H + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[0], st.m[0], st.v[0], st.p[4], st.m[4], st.v[4]};
         wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
