@@ -637,7 +637,7 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const bool br = blockIdx.z != 0;
     const int N = br ? h2 : h1;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;      // (round 5: the column tiles of a row tile in one XCD's L2 -- no difference: 57.2-57.5 us either way)
     if (n0 >= N) return;
     const float* W = br ? w2 : w1;
     const float* bias = br ? b2 : b1;
@@ -1009,7 +1009,9 @@ __global__ __launch_bounds__(NT) void fk_dec1(int B, int I, int H, const float* 
     auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
         if (ok) logits[(size_t)m * I + n] = v + biasv;
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, I, H, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+    // (BF: both operands are bf16-rounded -- the product runs on the bf16 matrix pipe, 5 blocks of 32 per K slice instead of 10 of 16)
+    if constexpr (BF) ltg_rgemm<1, 1, 1, 1, 4, 5, true>(B, I, H, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+    else ltg_rgemm<1, 1, 1, 1, 4, 10>(B, I, H, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
 }
 
 // One workgroup per user row: log-softmax statistics, the row's loss terms and dlogits in ONE pass (the row lives in
@@ -1136,7 +1138,8 @@ __global__ __launch_bounds__(NT) void fk_dh2(int B, int I, int H, const float* _
     auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
         if (ok) da2[(size_t)m * H + n] = v * (1.f - t * t);
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 16>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+    if constexpr (BF) ltg_rgemm<1, 1, 1, 1, 4, 8, true>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+    else ltg_rgemm<1, 1, 1, 1, 4, 16>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
 }
 
 // "weight gradient + Adam" tile: G[m][n] = sum_k Lm(k, m) * Rm(k, n) over the K batch rows, fused with the TF-Adam update
@@ -1235,7 +1238,9 @@ __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const f
     // 32 x 32 tile, every wave the whole tile over a QUARTER of K (two 16-deep blocks at 100 batch rows): 32 operand registers per
     // lane instead of 56 (one 16 x 16 product over all of K per wave), so that six workgroups fit a CU and the ~1 600 tiles of an
     // Askubuntu-sized tail are resident in (almost) one round instead of two
-    ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 2>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
+    // (RND = the decoder's weight gradient under LTG_PREC_BF16: bf16-rounded operands on the bf16 matrix pipe, one 32-deep block per K slice)
+    if constexpr (RND) ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 1, true>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
+    else ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 2>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
 }
 
 // The Adam updates of the generator step as jobs riding with the backward chain (train.py:164; each is independent once

@@ -152,10 +152,112 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
     __syncthreads();
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
+// The same product on the bf16 matrix pipe, for the three decoder GEMMs whose operands the loaders round to bf16 anyway (round 5): the
+// products bf16 x bf16 are exact in fp32 either way, so v_mfma_f32_16x16x32_bf16 on the PACKED operands adds up the same terms as
+// v_mfma_f32_16x16x4_f32 on the rounded fp32 values (in another order) -- at 16 cycles per 32-deep block instead of 8 x 32.  At Askubuntu's
+// sizes the fp32 form kept the matrix pipe busy for 1-1.2 us of each of these 8-us kernels.
+// K is cut into blocks of 32: lane (r, q) fetches k = 32 jb + 8 q .. + 7 of its row / column as TWO requests of four (the functors' unit).
+// a_xf / b_xf must return values that are exactly representable in bf16 (ltg_bf16r4) or zero; NBLK counts 32-deep blocks.
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
+__device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
+                                                       MID mid = MID()) {
+    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+    typedef LtgRg<TM, TN, WM, WN, WK> G;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wk = w % WK, wn = (w / WK) % WN, wm = w / (WK * WN);
+    const int nblk = (K + 31) >> 5;
+    const int per = (nblk + WK - 1) / WK;
+    const int Kc = K >= 4 ? ((K - 1) & ~3) : 0;   // start of the last (possibly partial) group of 4
+    int am[TM], bn[TN];
+    bool aok[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + (wm * TM + tm) * 16 + r;
+        aok[tm] = m < M;
+        am[tm] = min(m, M - 1);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bn[tn] = min(n0 + (wn * TN + tn) * 16 + r, N - 1);
+    ltg_f32x4 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto pack8 = [] __device__(ltg_f32x4 lo, ltg_f32x4 hi) -> ltg_bf16x8 {
+        typedef unsigned ltg_rg_u32x4 __attribute__((ext_vector_type(4)));
+        ltg_rg_u32x4 p;     // (the values are bf16-representable: the upper halves ARE the bf16 bits)
+        p[0] = (__float_as_uint(lo[0]) >> 16) | (__float_as_uint(lo[1]) & 0xFFFF0000u);
+        p[1] = (__float_as_uint(lo[2]) >> 16) | (__float_as_uint(lo[3]) & 0xFFFF0000u);
+        p[2] = (__float_as_uint(hi[0]) >> 16) | (__float_as_uint(hi[1]) & 0xFFFF0000u);
+        p[3] = (__float_as_uint(hi[2]) >> 16) | (__float_as_uint(hi[3]) & 0xFFFF0000u);
+        return __builtin_bit_cast(ltg_bf16x8, p);
+    };
+    for (int base = 0; base < per; base += NBLK) {
+        decltype(a_ld(0, 0, 0)) ra[NBLK][TM][2];
+        decltype(b_ld(0, 0, 0)) rb[NBLK][TN][2];
+        // phase 1: requests only
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kc = min(32 * (wk * per + base + i) + 8 * q + 4 * h, Kc);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) ra[i][tm][h] = a_ld(2 * i + h, am[tm], kc);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) rb[i][tn][h] = b_ld(2 * i + h, kc, bn[tn]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (base == 0) mid();
+        // phase 2: transforms and MFMAs, block by block as the data lands
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            if (base + i >= per || 32 * (wk * per + base + i) >= K) continue;   // wave-uniform: nothing of this block is in range
+            ltg_f32x4 av[TM][2], bv[TN][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 32 * (wk * per + base + i) + 8 * q + 4 * h;
+                const bool ok = k < K;
+                const int kc = min(k, Kc);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const ltg_f32x4 v = a_xf(ra[i][tm][h], 2 * i + h, am[tm], kc);
+                    const bool o = ok && aok[tm];
+                    av[tm][h] = ltg_f32x4{o ? v[0] : 0.f, o ? v[1] : 0.f, o ? v[2] : 0.f, o ? v[3] : 0.f};
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bv[tn][h] = b_xf(rb[i][tn][h], 2 * i + h, kc, bn[tn]);
+            }
+            ltg_bf16x8 ap[TM], bp[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) ap[tm] = pack8(av[tm][0], av[tm][1]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bp[tn] = pack8(bv[tn][0], bv[tn][1]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[tm], bp[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    float* mine = lds + wk * (G::BM * G::LDC);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                mine[((wm * TM + tm) * 16 + 4 * q + x) * G::LDC + (wn * TN + tn) * 16 + r] = acc[tm][tn][x];
+    __syncthreads();
+}
+
+// BFM: the product on the bf16 matrix pipe (ltg_rgemm_product_bf16; NBLK then counts 32-deep blocks)
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds,
                                           MID mid = MID()) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
+    if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
+    else
     ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
@@ -176,7 +278,7 @@ __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, A
 // ragged last group -- N % 4 != 0 -- is the caller's business).  pre = prefetch(m, n, in_range) is evaluated for the same
 // (m, n) BEFORE the product: the epilogue's own operands (theta / m / v of an Adam update) are requested first, so the
 // whole workgroup costs one memory round trip.
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class PF, class EF>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, class ALD, class AXF, class BLD, class BXF, class PF, class EF>
 __device__ __forceinline__ void ltg_rgemm_v4(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, PF prefetch, EF epi4,
                                              float* __restrict__ lds) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
@@ -191,6 +293,8 @@ __device__ __forceinline__ void ltg_rgemm_v4(int M, int N, int K, int m0, int n0
         const int mm = id / (G::BN / 4), nn = (id % (G::BN / 4)) * 4;
         pre[e] = prefetch(m0 + mm, n0 + nn, m0 + mm < M && n0 + nn < N);
     }
+    if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
+    else
     ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
