@@ -335,7 +335,8 @@ def copy_ceiling(device, nbytes=1 << 30, reps=5):
         torch.cuda.synchronize()
         best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del src, dst
-    return {"value": best, "unit": "GB/s", "what": "torch D2D copy of 1 GiB, read + write bytes, best of %d" % reps}
+    return {"value": best, "unit": "GB/s", "what": "torch D2D copy of 1 GiB, read + write bytes, best of %d (a practical reference, not a hard ceiling: "
+                                                   "a kernel with more bytes in flight per CU than torch's copy can read a few percent above it)" % reps}
 
 
 def visible_gpus():
