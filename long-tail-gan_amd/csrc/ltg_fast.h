@@ -1274,6 +1274,9 @@ struct TailArgs {
     int n_wait;
     LtgGate end_wait;
 };
+// (Round 5, measured: the launch holds 96 VGPRs + 16 AGPRs = four workgroups per CU, 1 024 slots for Askubuntu's 1 597 tiles.  Held to 5 / 6 / 7
+// waves per SIMD with __launch_bounds__(NT, w) -- 92 VGPRs, 80 + 40 B of scratch, 72 + 100 B -- the G phase ran 77.2 / 78.5 / 83.0 against 76.6 ms
+// per epoch: more resident tiles do not pay for fewer registers per tile.)
 template <bool BF>
 __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, AdamC ad) {
     __shared__ __attribute__((aligned(16))) float lds[LtgRg<2, LTG_TAIL_BN / 16, 1, 1, 4>::LDS_FLOATS];
@@ -1774,6 +1777,8 @@ __global__ __launch_bounds__(NT) void fks_d_l2(int n, int h12, int h3, const flo
 // workgroup's stage used to last one L2 / HBM round trip (~1.2 us against 0.1 us of MFMA), 16 of them per 2048-deep tile.  The loop is
 // unrolled by two with static set names, fetches are clamped instead of guarded and a block past the end is stashed as zeros (adds
 // nothing), so the loop has no branch and every s_waitcnt is an exact count.  -DLTG_SG8_SHALLOW builds the one-block-ahead loop.
+// (Round 5, measured and removed: THREE blocks in flight -- three register sets, the loop unrolled by six -- D step of config 5
+// 128.1-128.5 against 115.2-115.5 us: more loads in flight make it slower, as larger tiles did; the block is not short of bytes in flight.)
 constexpr int SG8_LDK = 128;   // bytes per LDS row of the staged e4m3 block (s8[2 * (BM + BN) * SG8_LDK] per workgroup)
 template <int BM, int BN, class ARow, class BRow>
 __device__ __forceinline__ void ltg_sgemm8_core(int K, ARow a_row, BRow b_row, ltg_f32x4 (&acc)[BM / 32][BN / 32], uint8_t* __restrict__ lds) {
