@@ -129,7 +129,21 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     if (tl.x == 0) {   // uniform: 16 threads per row, each a strided share of the row's Z columns
         const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
         const float* mrow = mulv + (size_t)min(m0 + rr, B - 1) * 2 * Z;
-        for (int j = cc; j < Z; j += 16) {
+        // Round 5: the thread's Z / 16 (mu, logvar) pairs requested AT ONCE (clamped, masked), added in the same order.  As a plain loop with a
+        // runtime bound every pair was a round trip of its own (load, wait, add: 13 dependent trips at Z = 200), in the seven workgroups the
+        // whole launch then waited for: 7.6 us for a 24-MFLOP product.
+        constexpr int KLU = 16;
+        float kmu[KLU], klv[KLU];
+#pragma unroll
+        for (int u = 0; u < KLU; ++u) {
+            const int j = min(cc + 16 * u, Z - 1);
+            kmu[u] = mrow[j];
+            klv[u] = mrow[Z + j];
+        }
+#pragma unroll
+        for (int u = 0; u < KLU; ++u)
+            if (cc + 16 * u < Z) kl += 0.5f * (-klv[u] + expf(klv[u]) + kmu[u] * kmu[u] - 1.f);
+        for (int j = cc + 16 * KLU; j < Z; j += 16) {      // (z_dim > 256)
             const float mu = mrow[j], lv = mrow[Z + j];
             kl += 0.5f * (-lv + expf(lv) + mu * mu - 1.f);
         }
@@ -960,10 +974,20 @@ __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const flo
     if (ks >= 0) return;
 #endif
     const int P4 = P >> 2;
+    constexpr int DA_U = 8;
     for (int e = blockIdx.x * NT + threadIdx.x; e < P4; e += gridDim.x * NT) {
-        ltg_f32x4 g = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < ks; ++z) g += *reinterpret_cast<const ltg_f32x4*>(slab + (size_t)z * SP + 4 * e);
+        // (round 5: theta / m / v and the first eight slabs requested together, the slabs added in ascending order as before -- the plain
+        // loop over a runtime slab count made every slab a round trip of its own: eight of them in a 5.7-us launch)
         ltg_f32x4 pp = ltg_ld4(p + 4 * e), mm = ltg_ld4(m + 4 * e), vv = ltg_ld4(v + 4 * e);
+        ltg_f32x4 g = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z0 = 0; z0 < ks; z0 += DA_U) {
+            ltg_f32x4 gs[DA_U];
+#pragma unroll
+            for (int u = 0; u < DA_U; ++u) gs[u] = *reinterpret_cast<const ltg_f32x4*>(slab + (size_t)min(z0 + u, ks - 1) * SP + 4 * e);
+#pragma unroll
+            for (int u = 0; u < DA_U; ++u)
+                if (z0 + u < ks) g += gs[u];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float pj = pp[j], mj = mm[j], vj = vv[j];
@@ -976,16 +1000,24 @@ __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const flo
     }
     if (blockIdx.x == 0) {
         const int e = 4 * P4 + threadIdx.x;
+        // (the same batching for the ragged tail and the loss slot: this workgroup's serial walk over the slabs bounded the whole launch)
+        auto slab_sum = [&](int col) -> float {
+            float t = 0.f;
+            for (int z0 = 0; z0 < ks; z0 += DA_U) {
+                float xs[DA_U];
+#pragma unroll
+                for (int u = 0; u < DA_U; ++u) xs[u] = slab[(size_t)min(z0 + u, ks - 1) * SP + col];
+#pragma unroll
+                for (int u = 0; u < DA_U; ++u)
+                    if (z0 + u < ks) t += xs[u];
+            }
+            return t;
+        };
         if (e < P) {   // ragged tail (P % 4 elements)
-            float g = 0.f;
-            for (int z = 0; z < ks; ++z) g += slab[(size_t)z * SP + e];
+            const float g = slab_sum(e);
             adam_update(p, m, v, (size_t)e, g, ad);
         }
-        if (threadIdx.x == 0) {
-            float s = 0.f;
-            for (int z = 0; z < ks; ++z) s += slab[(size_t)z * SP + P];
-            loss_out[0] = s;
-        }
+        if (threadIdx.x == 0) loss_out[0] = slab_sum(P);
     }
 }
 
@@ -1065,8 +1097,18 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
         const int i = tid + NT * j;
         v[j] = row[min(i, I - 1)];
     }
+    // (round 5: the y's and the fake-pair triples of this thread in batches of RD_U requests, clamped and masked, consumed in the loop's
+    // order -- as plain loops with a runtime bound every element was a round trip of its own: load, wait, use)
+    constexpr int RD_U = 4;
     float sy = 0.f;
-    for (int q = tid; q < nf; q += NT) sy += y[q];
+    for (int q0 = tid; q0 < nf; q0 += RD_U * NT) {
+        float ty[RD_U];
+#pragma unroll
+        for (int u = 0; u < RD_U; ++u) ty[u] = y[min(q0 + u * NT, nf - 1)];
+#pragma unroll
+        for (int u = 0; u < RD_U; ++u)
+            if (q0 + u * NT < nf) sy += ty[u];
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -1087,9 +1129,18 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
         xl += x * s_l[it];
         nx += x;
     }
-    for (int q = tid; q < nf; q += NT) {
-        const int it = f_gen[q];
-        if (f_row[q] == b && it >= 0 && it < I && f_pop[q] >= 0) s_s[it] = 1;
+    for (int q0 = tid; q0 < nf; q0 += RD_U * NT) {
+        int tg[RD_U], tr[RD_U], tp[RD_U];
+#pragma unroll
+        for (int u = 0; u < RD_U; ++u) {
+            const int q = min(q0 + u * NT, nf - 1);
+            tg[u] = f_gen[q];
+            tr[u] = f_row[q];
+            tp[u] = f_pop[q];
+        }
+#pragma unroll
+        for (int u = 0; u < RD_U; ++u)
+            if (q0 + u * NT < nf && tr[u] == b && tg[u] >= 0 && tg[u] < I && tp[u] >= 0) s_s[tg[u]] = 1;
     }
     block_red4(xl, nx, sy, mx, red);           // (its barrier also publishes s_x / s_s)
     float s = 0.f, psu = 0.f, zero = 0.f, m2 = 0.f;

@@ -1648,9 +1648,29 @@ __global__ __launch_bounds__(NT) void k_row_stats_merge(int B, int G, int I, int
         xl += x * row[indices[e]];
         nx += x;
     }
-    for (int q = threadIdx.x; q < nf; q += NT) {
-        const int it = f_gen[q] - item_lo;
-        if (f_row[q] == b && f_gen[q] >= 0 && f_pop[q] >= 0 && it >= 0 && it < I) ps += expf(row[it] - mx);
+    // (round 5: the thread's fake pairs in batches of four -- the triples requested together, then the logits of the pairs that count,
+    // added in the loop's order; as a plain loop every pair was two dependent round trips of its own)
+    constexpr int FU = 4;
+    for (int q0 = threadIdx.x; q0 < nf; q0 += FU * NT) {
+        int tg[FU], tr[FU], tp[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = min(q0 + u * NT, nf - 1);
+            tg[u] = f_gen[q];
+            tr[u] = f_row[q];
+            tp[u] = f_pop[q];
+        }
+        float lg[FU];
+        bool ok[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int it = tg[u] - item_lo;
+            ok[u] = q0 + u * NT < nf && tr[u] == b && tg[u] >= 0 && tp[u] >= 0 && it >= 0 && it < I;
+            lg[u] = row[ok[u] ? it : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (ok[u]) ps += expf(lg[u] - mx);
     }
     s = block_sum(s, red);
     xl = block_sum(xl, red);
@@ -1669,6 +1689,70 @@ __global__ __launch_bounds__(NT) void k_row_stats_merge(int B, int G, int I, int
     }
 }
 
+// The R shards' partials of row rb folded into (lse, n_b, P_b, sum x logit): max over the ranks, then the sums in ascending rank order
+// (k_g_combine's arithmetic and order).  Round 5: for R <= 8 the R x 5 floats are requested AT ONCE (clamped, masked) -- as three plain loops
+// over a runtime rank count every partial was a round trip of its own, 3 R of them in front of the first logit k_dlogits_combine reads
+// (24 at eight ranks).
+__device__ __forceinline__ void ltg_rank_terms(const float* __restrict__ rowpart_all, int R, int B, int rb, float& l, float& nx, float& pb, float& xl) {
+    constexpr int RU = 8;
+    if (R == 1) {      // one rank: the five floats, the same operations in the same order as the general form
+        const float* q = rowpart_all + (size_t)rb * RP;
+        const float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+        const float M = fmaxf(-INFINITY, a0);
+        const float se = 0.f + a1 * expf(a0 - M);
+        xl = 0.f + a2;
+        nx = 0.f + a4;
+        l = M + logf(se);
+        pb = 0.f + a3 * expf(a0 - l);
+        return;
+    }
+    if (R <= RU) {
+        float q0[RU], q1[RU], q2[RU], q3[RU], q4[RU];
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {
+            const float* q = rowpart_all + ((size_t)min(r, R - 1) * B + rb) * RP;
+            q0[r] = q[0]; q1[r] = q[1]; q2[r] = q[2]; q3[r] = q[3]; q4[r] = q[4];
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < RU; ++r)
+            if (r < R) M = fmaxf(M, q0[r]);
+        float se = 0.f;
+        xl = 0.f;
+        nx = 0.f;
+#pragma unroll
+        for (int r = 0; r < RU; ++r)
+            if (r < R) {
+                se += q1[r] * expf(q0[r] - M);
+                xl += q2[r];
+                nx += q4[r];
+            }
+        l = M + logf(se);
+        pb = 0.f;
+#pragma unroll
+        for (int r = 0; r < RU; ++r)
+            if (r < R) pb += q3[r] * expf(q0[r] - l);
+        return;
+    }
+    float M = -INFINITY;
+    for (int r = 0; r < R; ++r) M = fmaxf(M, rowpart_all[((size_t)r * B + rb) * RP]);
+    float se = 0.f;
+    xl = 0.f;
+    nx = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
+        se += q[1] * expf(q[0] - M);
+        xl += q[2];
+        nx += q[4];
+    }
+    l = M + logf(se);
+    pb = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
+        pb += q[3] * expf(q[0] - l);
+    }
+}
+
 // Combine the R shards' row partials: lse, n_b, P_b per row, then the step scalars (train.py:145-157):
 // out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
 __global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __restrict__ rowpart_all, int nf,
@@ -1679,21 +1763,8 @@ __global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __r
     __shared__ float red[NT / 64];
     float a = 0.f, k = 0.f, p = 0.f, sy = 0.f;
     for (int b = threadIdx.x; b < B; b += NT) {
-        float M = -INFINITY;
-        for (int r = 0; r < R; ++r) M = fmaxf(M, rowpart_all[((size_t)r * B + b) * RP]);
-        float se = 0.f, xl = 0.f, nx = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float* q = rowpart_all + ((size_t)r * B + b) * RP;
-            se += q[1] * expf(q[0] - M);
-            xl += q[2];
-            nx += q[4];
-        }
-        const float l = M + logf(se);
-        float pb = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float* q = rowpart_all + ((size_t)r * B + b) * RP;
-            pb += q[3] * expf(q[0] - l);
-        }
+        float l, nx, pb, xl;
+        ltg_rank_terms(rowpart_all, R, B, b, l, nx, pb, xl);
         lse[b] = l;
         nb[b] = nx;
         Pb[b] = pb;
@@ -1791,38 +1862,41 @@ __global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, con
         s_x[j] = 0.f;
         s_s[j] = 0;
     }
+    // (round 5: y and the fake-pair triples in batches of four requests, consumed in the loops' order: as plain loops with a runtime bound
+    // every element was a round trip of its own -- about eight of them in front of the first logit this launch reads)
+    constexpr int FU = 4;
     float sy = 0.f;
     if (y)
-        for (int q = threadIdx.x; q < nf; q += NT) sy += y[q];
+        for (int q0 = threadIdx.x; q0 < nf; q0 += FU * NT) {
+            float ty[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) ty[u] = y[min(q0 + u * NT, nf - 1)];
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+                if (q0 + u * NT < nf) sy += ty[u];
+        }
     __syncthreads();
     for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
         const int it = indices[e];
         if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
     }
-    for (int q = threadIdx.x; q < nf; q += NT) {
-        const int it = f_gen[q] - item_lo;  // fake pairs carry global item ids
-        if (f_row[q] == b && f_gen[q] >= 0 && it >= i0 && it < i1 && f_pop[q] >= 0) s_s[it - i0] = 1;
+    for (int q0 = threadIdx.x; q0 < nf; q0 += FU * NT) {
+        int tg[FU], tr[FU], tp[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = min(q0 + u * NT, nf - 1);
+            tg[u] = f_gen[q];
+            tr[u] = f_row[q];
+            tp[u] = f_pop[q];
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int it = tg[u] - item_lo;  // fake pairs carry global item ids
+            if (q0 + u * NT < nf && tr[u] == b && tg[u] >= 0 && it >= i0 && it < i1 && tp[u] >= 0) s_s[it - i0] = 1;
+        }
     }
     sy = block_sum(sy, red);   // (its barriers also publish s_x / s_s)
-    auto row_terms = [=] __device__(int rb, float& l, float& nx, float& pb, float& xl) {
-        float M = -INFINITY;
-        for (int r = 0; r < R; ++r) M = fmaxf(M, rowpart_all[((size_t)r * B + rb) * RP]);
-        float se = 0.f;
-        xl = 0.f;
-        nx = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
-            se += q[1] * expf(q[0] - M);
-            xl += q[2];
-            nx += q[4];
-        }
-        l = M + logf(se);
-        pb = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
-            pb += q[3] * expf(q[0] - l);
-        }
-    };
+    auto row_terms = [=] __device__(int rb, float& l, float& nx, float& pb, float& xl) { ltg_rank_terms(rowpart_all, R, B, rb, l, nx, pb, xl); };
     float l, nx, pb, xl;
     row_terms(b, l, nx, pb, xl);
     const float invB = 1.f / (float)B;
@@ -1898,16 +1972,18 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
     // one output per thread (B H = 60 000 outputs -> 235 workgroups instead of 59 with float4), 16 slabs in flight; the slabs
     // are added in ascending order whatever the unroll: bitwise the same sum as a serial walk
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        // (round 5: 32 slabs in flight and the remainder as ONE clamped, masked batch -- with 16 and a serial remainder the 98 slabs of a
+        // 25 024-item step were eight dependent round trips in a 6-us launch on the caller's stream)
         float s = 0.f;
-        int z = 0;
-        for (; z + 16 <= nsplit; z += 16) {
-            float x[16];
+        constexpr int DU = 32;
+        for (int z = 0; z < nsplit; z += DU) {
+            float x[DU];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = part[(size_t)(z + u) * n + i];
+            for (int u = 0; u < DU; ++u) x[u] = part[(size_t)min(z + u, nsplit - 1) * n + i];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) s += x[u];
+            for (int u = 0; u < DU; ++u)
+                if (z + u < nsplit) s += x[u];
         }
-        for (; z < nsplit; ++z) s += part[(size_t)z * n + i];
         const float t = h2 ? h2[i] : 0.f;
         da2[i] = s * __builtin_fmaf(-t, t, 1.f);   // (rounding pinned: fk_dz_dh2's operand loader computes the same expression)
     }
