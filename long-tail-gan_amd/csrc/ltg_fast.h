@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     // of this one waited for that (fk_enc1's end_wait; poison: the wait gave up).  end_wait: the kernel BEHIND this one streams the bf16
     // shadow of W_p1t, which that update rewrites until it ends: one thread of this launch polls for its end as the last thing it does.
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
-    if (ltg_poisoned(poison)) return;
+    const unsigned dead = ltg_poison_word(poison);   // (requested first, looked at in front of the stores: not a round trip of its own)
     const LtgTile2 tl = xcd_tile2();
     const int m0 = tl.y * 16, n0 = tl.x * 16;
     float kl = 0.f;
@@ -152,9 +152,10 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     auto b_ld = [=] __device__(int, int k, int n) { return ltg_ld4s(Wp0 + (size_t)k * H + n, H); };
     const float biasv = bp0[min(n0 + (int)(threadIdx.x & 15), H - 1)];
     auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
-        if (ok) h2[(size_t)m * H + n] = tanhf(v + biasv);
+        if (ok && !ltg_word_set(dead)) h2[(size_t)m * H + n] = tanhf(v + biasv);
     };
     ltg_rgemm<1, 1, 1, 1, 4, 4>(B, H, Z, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    if (ltg_word_set(dead)) return;
     if (tl.x == 0) {
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) kl += __shfl_xor(kl, o);    // the 16 lanes of a row are consecutive
@@ -267,6 +268,9 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
     const uint64_t kb = rps > 0 ? (uint64_t)(b % rps) : (uint64_t)b;
     step += rps > 0 ? (uint64_t)(b / rps) : 0;
     const int beg = indptr[b], end = indptr[b + 1];
+    // (round 5: the bias chunk this thread adds at the very end is requested here -- behind the last barrier it was one more round trip)
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!pre_only && tid < 64 && 64 * cb + tid < (H >> 2)) bb = *reinterpret_cast<const float4*>(bq0 + 4 * (64 * cb + tid));
     float ss = 0.f;
     for (int e = beg + tid; e < end; e += ENC_NT) {
         const float v = values ? values[e] : 1.f;
@@ -307,11 +311,19 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
             float4 x[E0_U];
 #pragma unroll
             for (int u = 0; u < E0_U; ++u) {
-                const int ju = j + u * ENC_NW;
-                const bool ok = ju < cnt;
-                v[u] = ok ? s_val[ju] : 0.f;
-                x[u] = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[ok ? ju : j] * H)[c4];
+                const int ju = j + u * ENC_NW;       // (wave-uniform: a slot beyond the chunk is skipped by a scalar branch, no request at all)
+                v[u] = 0.f;
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                // (round 5: written as "row ju, or row j again with weight 0" the compiler loaded row j, WAITED for it, and requested the other
+                // seven only under their masks with row j's value as the default -- two dependent trips per group instead of one; clamped to the
+                // chunk's last entry instead, a 25-item row made 128 requests for the same row: +1.2 us per launch)
+                if (ju < cnt) {
+                    v[u] = s_val[ju];
+                    x[u] = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[ju] * H)[c4];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);      // (all eight requests before the first sum: the scheduler otherwise holds the last one back
+                                                    // behind the first two arrivals to save registers)
 #pragma unroll
             for (int u = 0; u < E0_U; ++u) {
                 acc.x += v[u] * x[u].x;
@@ -334,7 +346,6 @@ __global__ __launch_bounds__(ENC_NT) void fk_enc0_fwd(int H, int I, const int32_
         float4 o;
         if (pre_only) o = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
         else {
-            const float4 bb = *reinterpret_cast<const float4*>(bq0 + c);
             // (product ROUNDED before the bias is added -- no fma: it is the value an item-sharded run all-reduces, so that the one-call
             // sharded step, which applies bias + tanh in the next layer's loader, and this kernel yield the same bits)
             o = make_float4(tanhf(ltg_mul_rounded(t.x, scale) + bb.x), tanhf(ltg_mul_rounded(t.y, scale) + bb.y), tanhf(ltg_mul_rounded(t.z, scale) + bb.z),
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
         const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + coff + nn] = kp ? t / keep : 0.f;
     };
-    ltg_rgemm<1, 1, 2, 2, 1, 7>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 2, 2, 1, 7, false, true>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // fully connected layer + the output unit's dot product (discriminator.py:44-45, :54-55): A3 = dropout(tanh(A1 . w3 + b3));
@@ -706,7 +717,7 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
         for (int o = 16; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
         if ((threadIdx.x & 31) == 0 && m < n) spart[(size_t)tile * n + m] = pd;
     };
-    ltg_rgemm<2, 2, 1, 1, 4, 7>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<2, 2, 1, 1, 4, 7, false, true>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
 }
 
 // output unit from the tile partials (discriminator.py:45,55; train.py:142): y, d loss / d s, loss term of one pair row
@@ -799,7 +810,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
         auto epi = [=] __device__(int e, int m, int nn, float v, bool ok) {
             if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(a1v[e], keep);
         };
-        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA, false, true>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
         return;
     }
     d_bwd1_jobs_bc(pv, h12, h3, bid - nA, nB, ntile, L, SP, A1, A3, G3, spart, b4v, slab, lds, s_ds, s_lr);
@@ -866,7 +877,7 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB, false, true>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
         return;
     }
     bid -= nB;
@@ -957,7 +968,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    ltg_rgemm<1, 2, 1, 1, 4, 4>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 4, 4, false, true>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // (Measured and not kept, round 3: this sweep FUSED into fk_d_bwd2 -- every workgroup releases its slab tile with a device-scope fence
@@ -969,13 +980,45 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
 __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const float* __restrict__ slab, float* __restrict__ p,
                                                 float* __restrict__ m, float* __restrict__ v, AdamC ad, float* __restrict__ loss_out,
                                                 const unsigned* __restrict__ poison = nullptr) {
-    if (ltg_poisoned(poison)) return;   // (the wait for the aux stream's jobs gave up: the discriminator is not touched)
+    // (the poison word -- the wait for the aux stream's jobs gave up: the discriminator is not touched -- is REQUESTED first and looked at in
+    // front of the first store: as the guard of an early return it was a round trip of its own in front of every other request of a launch
+    // that is nothing but round trips)
+    const unsigned dead = ltg_poison_word(poison);
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (ks >= 0) return;
 #endif
     const int P4 = P >> 2;
     constexpr int DA_U = 8;
-    for (int e = blockIdx.x * NT + threadIdx.x; e < P4; e += gridDim.x * NT) {
+    // Workgroup 0 (dispatched first) does the ragged tail and d_loss and nothing else; the sweep belongs to workgroups 1 .. gridDim.x - 1.
+    // (Round 5: as the epilogue of workgroup 0's share of the sweep, these two serial walks were a second and a third chain of round trips
+    // that the whole launch waited for.)
+    if (blockIdx.x == 0) {
+        const int e = 4 * P4 + threadIdx.x;
+        const bool tail = e < P, lossl = threadIdx.x == NT - 1;      // (the loss on another wave than the tail elements)
+        const int col = tail ? e : P;
+        if (!tail && !lossl) return;
+        float pe = 0.f, me = 0.f, ve = 0.f;
+        if (tail) { pe = p[e]; me = m[e]; ve = v[e]; }
+        float t = 0.f;
+        auto batch = [&] __device__(const int z0) {       // (first batch peeled: a loop header drains theta / m / v before its first request)
+            float xs[DA_U];
+#pragma unroll
+            for (int u = 0; u < DA_U; ++u) xs[u] = slab[(size_t)min(z0 + u, ks - 1) * SP + col];
+#pragma unroll
+            for (int u = 0; u < DA_U; ++u)
+                if (z0 + u < ks) t += xs[u];
+        };
+        if (ks > 0) batch(0);
+        for (int z0 = DA_U; z0 < ks; z0 += DA_U) batch(z0);
+        if (ltg_word_set(dead)) return;
+        if (tail) {
+            adam1(pe, me, ve, t, ad.lr_t, ad);
+            p[e] = pe; m[e] = me; v[e] = ve;
+        } else loss_out[0] = t;
+        return;
+    }
+    const int nb = gridDim.x - 1;
+    for (int e = (blockIdx.x - 1) * NT + threadIdx.x; e < P4; e += nb * NT) {
         // (round 5: theta / m / v and the first eight slabs requested together, the slabs added in ascending order as before -- the plain
         // loop over a runtime slab count made every slab a round trip of its own: eight of them in a 5.7-us launch)
         ltg_f32x4 pp = ltg_ld4(p + 4 * e), mm = ltg_ld4(m + 4 * e), vv = ltg_ld4(v + 4 * e);
@@ -994,30 +1037,10 @@ __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const flo
             adam1(pj, mj, vj, g[j], ad.lr_t, ad);
             pp[j] = pj; mm[j] = mj; vv[j] = vj;
         }
+        if (ltg_word_set(dead)) return;
         *reinterpret_cast<ltg_f32x4*>(p + 4 * e) = pp;
         *reinterpret_cast<ltg_f32x4*>(m + 4 * e) = mm;
         *reinterpret_cast<ltg_f32x4*>(v + 4 * e) = vv;
-    }
-    if (blockIdx.x == 0) {
-        const int e = 4 * P4 + threadIdx.x;
-        // (the same batching for the ragged tail and the loss slot: this workgroup's serial walk over the slabs bounded the whole launch)
-        auto slab_sum = [&](int col) -> float {
-            float t = 0.f;
-            for (int z0 = 0; z0 < ks; z0 += DA_U) {
-                float xs[DA_U];
-#pragma unroll
-                for (int u = 0; u < DA_U; ++u) xs[u] = slab[(size_t)min(z0 + u, ks - 1) * SP + col];
-#pragma unroll
-                for (int u = 0; u < DA_U; ++u)
-                    if (z0 + u < ks) t += xs[u];
-            }
-            return t;
-        };
-        if (e < P) {   // ragged tail (P % 4 elements)
-            const float g = slab_sum(e);
-            adam_update(p, m, v, (size_t)e, g, ad);
-        }
-        if (threadIdx.x == 0) loss_out[0] = slab_sum(P);
     }
 }
 
@@ -1097,9 +1120,31 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
         const int i = tid + NT * j;
         v[j] = row[min(i, I - 1)];
     }
+    // (round 5, second pass: ALSO up front -- the first batch of fake-pair triples, the thread's first sparse entry, cnt[0] and the row's KL
+    // term: behind the barrier / at the end of the kernel each of them was a dependent round trip of its own -- seven in all in a 7.8-us launch)
+    constexpr int RD_U = 4;
+    int tg0[RD_U], tr0[RD_U], tp0[RD_U];
+#pragma unroll
+    for (int u = 0; u < RD_U; ++u) tg0[u] = tr0[u] = tp0[u] = -1;
+    if (nf > 0) {      // (ONE uniform branch around the twelve requests: a select per element made a basic block -- and a wait -- of each)
+#pragma unroll
+        for (int u = 0; u < RD_U; ++u) {
+            const int q = min(tid + u * NT, nf - 1);
+            tg0[u] = f_gen[q];
+            tr0[u] = f_row[q];
+            tp0[u] = f_pop[q];
+        }
+    }
+    const int cntv = cnt[0];
+    const float klb = kl_rows[b];
+    int it0 = -1;
+    float x0 = 1.f;
+    if (e0 + tid < e1) {
+        it0 = indices[e0 + tid];
+        if (values) x0 = values[e0 + tid];
+    }
     // (round 5: the y's and the fake-pair triples of this thread in batches of RD_U requests, clamped and masked, consumed in the loop's
     // order -- as plain loops with a runtime bound every element was a round trip of its own: load, wait, use)
-    constexpr int RD_U = 4;
     float sy = 0.f;
     for (int q0 = tid; q0 < nf; q0 += RD_U * NT) {
         float ty[RD_U];
@@ -1122,14 +1167,22 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
     }
     __syncthreads();
     float xl = 0.f, nx = 0.f;
-    for (int e = e0 + tid; e < e1; e += NT) {
+    if (it0 >= 0) {      // (the entry requested up front, then the rest of a long row)
+        s_x[it0] = x0;
+        xl += x0 * s_l[it0];
+        nx += x0;
+    }
+    for (int e = e0 + tid + NT; e < e1; e += NT) {
         const int it = indices[e];
         const float x = values ? values[e] : 1.f;
         s_x[it] = x;
         xl += x * s_l[it];
         nx += x;
     }
-    for (int q0 = tid; q0 < nf; q0 += RD_U * NT) {
+#pragma unroll
+    for (int u = 0; u < RD_U; ++u)
+        if (tid + u * NT < nf && tr0[u] == b && tg0[u] >= 0 && tg0[u] < I && tp0[u] >= 0) s_s[tg0[u]] = 1;
+    for (int q0 = tid + RD_U * NT; q0 < nf; q0 += RD_U * NT) {
         int tg[RD_U], tr[RD_U], tp[RD_U];
 #pragma unroll
         for (int u = 0; u < RD_U; ++u) {
@@ -1155,7 +1208,7 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
     const float l = mx + logf(s);
     const float ps = psu / s;                  // sum_{S_b} exp(logit - lse)
     const float invB = 1.f / (float)B, invs = 1.f / s;
-    const float c = cnt[0] > 0 ? lam / (float)cnt[0] * sy : 0.f;
+    const float c = cntv > 0 ? lam / (float)cntv * sy : 0.f;
     const float alpha = nx * invB + c * ps;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -1170,7 +1223,7 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
         float* o = rowout + (size_t)b * 4;
         o[0] = -xl + nx * l;
         o[1] = ps;
-        o[2] = kl_rows[b];
+        o[2] = klb;
         o[3] = sy;
     }
 }
@@ -1212,7 +1265,7 @@ struct WgRegs {
 #endif
 template <bool RND, bool ONES_L>
 __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const float* __restrict__ Lm, int ldl, const float* __restrict__ Rm,
-                                                int ldr, WgTensors T, int ldw, AdamC ad, int m0, int n0, float* __restrict__ lds) {
+                                                int ldr, WgTensors T, int ldw, AdamC ad, int m0, int n0, float* __restrict__ lds, unsigned dead = 0u) {
     const int M = ONES_L ? Min + 1 : Min, N = ONES_L ? Nin : Nin + 1;
     auto a_ld = [=] __device__(int, int m, int k) {
         ltg_f32x4 v;
@@ -1268,7 +1321,7 @@ __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const f
         return r;
     };
     auto epi4 = [=] __device__(WgRegs r, int m, int n, ltg_f32x4 g, bool ok) {
-        if (!ok) return;
+        if (!ok || ltg_word_set(dead)) return;      // (dead: the pipe's poison word, requested before anything else and first looked at here)
         const WgWhere x = where(m, n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1336,8 +1389,38 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         if (threadIdx.x == 0) ltg_gate_wait_tail(a.end_wait);
         return;
     }
-    if (ltg_poisoned(a.poison)) return;
+    // (round 5: the poison word is requested here and looked at in front of each job's first store -- as the guard of an early return it was a
+    // round trip in front of every tile's requests)
+    const unsigned dead = ltg_poison_word(a.poison);
     const int B = a.B, I = a.I, H = a.H, Z = a.Z;
+    if (bid < a.n5) {   // job 5 FIRST in the grid (round 5): its chain -- row terms, three block sums, two more scalars, six stores -- started when the
+                        // last tiles did and ended after them
+        float* red = lds;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        const float sy = a.rowout[3];
+        const int cntv = a.cnt[0];
+        for (int b = threadIdx.x; b < B; b += NT) {
+            x0 += a.rowout[(size_t)b * 4];
+            x1 += a.rowout[(size_t)b * 4 + 1];
+            x2 += a.rowout[(size_t)b * 4 + 2];
+        }
+        x0 = block_sum(x0, red);
+        x1 = block_sum(x1, red);
+        x2 = block_sum(x2, red);
+        if (threadIdx.x == 0 && !ltg_word_set(dead)) {
+            const float negll = x0 / (float)B, KL = x2 / (float)B;
+            const float c = cntv > 0 ? a.lam / (float)cntv * sy : 0.f;
+            const float vae = negll + a.anneal * KL, gan = -c * x1;
+            const float r[6] = {vae + gan, vae, gan, x1, sy, c};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                a.loss_out[i] = r[i];
+                if (a.loss_out2) a.loss_out2[i] = r[i];
+            }
+        }
+        return;
+    }
+    bid -= a.n5;
     // (The dz / dh1 tiles once rode in front of the jobs -- three launches of this kernel per step, measured +23 us; the variant
     // is gone: its 80 operand registers set the register count of the whole kernel and with it the tiles' occupancy.)
     // Every job's tiles are dealt to the XCDs in CONTIGUOUS runs (xcd_chunk on the job's own block index: blocks whose index agrees mod 8
@@ -1348,7 +1431,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         bid = xcd_chunk(bid, a.n1);
         const int tn = (H + 1 + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[3], st.m[3], st.v[3], st.p[7], st.m[7], st.v[7]};
-        wgrad_adam_tile<BF, false>(B, I, H, a.dlog, I, a.h2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
+        wgrad_adam_tile<BF, false>(B, I, H, a.dlog, I, a.h2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds, dead);
         return;
     }
     bid -= a.n1;
@@ -1356,7 +1439,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         bid = xcd_chunk(bid, a.n2);
         const int tn = (H + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[2], st.m[2], st.v[2], st.p[6], st.m[6], st.v[6]};
-        wgrad_adam_tile<false, true>(B, Z, H, a.z, Z, a.da2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
+        wgrad_adam_tile<false, true>(B, Z, H, a.z, Z, a.da2, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds, dead);
         return;
     }
     bid -= a.n2;
@@ -1364,7 +1447,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         bid = xcd_chunk(bid, a.n3);
         const int tn = (2 * Z + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[1], st.m[1], st.v[1], st.p[5], st.m[5], st.v[5]};
-        wgrad_adam_tile<false, true>(B, H, 2 * Z, a.h1, H, a.dmlv, 2 * Z, T, 2 * Z, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
+        wgrad_adam_tile<false, true>(B, H, 2 * Z, a.h1, H, a.dmlv, 2 * Z, T, 2 * Z, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds, dead);
         return;
     }
     bid -= a.n3;
@@ -1372,11 +1455,12 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
         bid = xcd_chunk(bid, a.n4);
         const int tn = (H + LTG_TAIL_BN - 1) / LTG_TAIL_BN;
         const WgTensors T{st.p[0], st.m[0], st.v[0], st.p[4], st.m[4], st.v[4]};
-        wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds);
+        wgrad_adam_tile<false, true>(B, I, H, a.xd, I, a.da1, H, T, H, ad, (bid / tn) * 32, (bid % tn) * LTG_TAIL_BN, lds, dead);
         return;
     }
     if (bid < a.n4 && a.q0_bias) {   // b_q0 from the partial bias rows of fk_enc0_grad + this step's learning rate into the clock's ring
         const int H4 = H >> 2;
+        if (ltg_word_set(dead)) return;
         if (threadIdx.x == 0) st.q0_lr_hist[(st.q0_ord + 1) & (LTG_Q0_HIST - 1)] = ad.lr_t;
         float4* b4 = reinterpret_cast<float4*>(st.p[4]);
         float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
@@ -1402,6 +1486,7 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
     }
     if (bid < a.n4) {
         const int H4 = H >> 2;
+        if (ltg_word_set(dead)) return;
         const size_t total = (size_t)(I + 1) * H4;
         float4* W4 = reinterpret_cast<float4*>(st.p[0]);
         float4* m4 = reinterpret_cast<float4*>(st.m[0]);
@@ -1434,30 +1519,6 @@ __global__ __launch_bounds__(NT) void fk_g_tail(TailArgs a, ltg_gen_state st, Ad
             *Vv = vv;
         }
         return;
-    }
-    {
-        float* red = lds;
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-        for (int b = threadIdx.x; b < B; b += NT) {
-            x0 += a.rowout[(size_t)b * 4];
-            x1 += a.rowout[(size_t)b * 4 + 1];
-            x2 += a.rowout[(size_t)b * 4 + 2];
-        }
-        x0 = block_sum(x0, red);
-        x1 = block_sum(x1, red);
-        x2 = block_sum(x2, red);
-        if (threadIdx.x == 0) {
-            const float sy = a.rowout[3];
-            const float negll = x0 / (float)B, KL = x2 / (float)B;
-            const float c = a.cnt[0] > 0 ? a.lam / (float)a.cnt[0] * sy : 0.f;
-            const float vae = negll + a.anneal * KL, gan = -c * x1;
-            const float r[6] = {vae + gan, vae, gan, x1, sy, c};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                a.loss_out[i] = r[i];
-                if (a.loss_out2) a.loss_out2[i] = r[i];
-            }
-        }
     }
 }
 

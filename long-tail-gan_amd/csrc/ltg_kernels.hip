@@ -129,6 +129,14 @@ __device__ __forceinline__ void ltg_gate_wait_tail(LtgGate g) {
 __device__ __forceinline__ bool ltg_poisoned(const unsigned* __restrict__ p) {
     return p && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
+// The word itself, for kernels that REQUEST it first and look at it in front of their first store (round 5): `if (ltg_poisoned(p)) return;`
+// as a kernel's first statement is a vector-memory round trip of its own in front of every other request.  A PLAIN load of a uniform address
+// before the kernel's first store: the compiler issues it on the SCALAR unit (s_load_dword, beside the kernel-argument loads), so nothing in
+// the vector-memory queue waits for it.  Plain is enough here: every poisoner is a wait that sits IN FRONT of the reading kernel on its own
+// stream (a kernel's end releases, a kernel's start acquires); a wait on another stream that gives up while this kernel runs is seen by the
+// next kernel, as with the atomic load.
+__device__ __forceinline__ unsigned ltg_poison_word(const unsigned* __restrict__ p) { return p ? *p : 0u; }
+__device__ __forceinline__ bool ltg_word_set(unsigned w) { return w != 0u; }
 // by ONE thread.  Every producer in this library is a WHOLE KERNEL that ended in front of the kernel that stores the word (the store
 // is the first thing a kernel does when it starts, or a one-wave kernel of its own behind the producer), and the end of a kernel is
 // already the device-wide release of what it wrote; the agent-scope release below is belt and braces -- measured in round 4 against a
@@ -1159,7 +1167,8 @@ struct PairView {
         const int32_t* p = r < nr ? r_nic : f_nic;
         return p[r < nr ? r : r - nr];
     }
-    __device__ __forceinline__ bool valid(int r) const { return pop(r) >= 0 && nic(r) >= 0; }
+    // (both ids requested unconditionally: with `&&` the niche id was loaded only under the popular id's sign -- a dependent round trip)
+    __device__ __forceinline__ bool valid(int r) const { return (pop(r) | nic(r)) >= 0; }
 };
 struct DropView {
     const uint8_t *real, *fake;  // optional injected keep flags [rows][width]
@@ -1633,25 +1642,72 @@ __global__ __launch_bounds__(NT) void k_row_stats_merge(int B, int G, int I, int
                                                         const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
                                                         float* __restrict__ rowpart, float* __restrict__ lse) {
     __shared__ float red[NT / 64];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = logits + (size_t)b * I;
-    float mx = -INFINITY;
-    for (int g = threadIdx.x; g < G; g += NT) mx = fmaxf(mx, stat[((size_t)g * B + b) * 2]);
+    // Round 5, second pass: TWO levels of requests for the common case (G <= NT, a row of at most NT entries, nf <= 4 NT fake pairs) -- level 1:
+    // the thread's (max, sum exp) pair, its first sparse entry and its first batch of fake-pair triples; level 2: the logits those point at.
+    // As written before -- max loop, barrier, the pairs AGAIN, indptr -> indices -> logit, triples -> logit -- the row cost seven dependent trips.
+    // Every sum below adds the same terms in the same order as before.
+    constexpr int FU = 4;
+    const int e0 = indptr[b], e1 = indptr[b + 1];
+    float st0 = -INFINITY, st1 = 0.f;
+    if (tid < G) {
+        const float* q = stat + ((size_t)tid * B + b) * 2;
+        st0 = q[0];
+        st1 = q[1];
+    }
+    int tg0[FU], tr0[FU], tp0[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) tg0[u] = tr0[u] = tp0[u] = -1;
+    if (nf > 0) {      // (ONE uniform branch around the twelve requests: a select per element made a basic block -- and a wait -- of each)
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = min(tid + u * NT, nf - 1);
+            tg0[u] = f_gen[q];
+            tr0[u] = f_row[q];
+            tp0[u] = f_pop[q];
+        }
+    }
+    int idx0 = -1;
+    float x0 = 1.f;
+    if (e0 + tid < e1) {
+        idx0 = indices[e0 + tid];
+        if (values) x0 = values[e0 + tid];
+    }
+    // level 2
+    const float rl0 = row[max(idx0, 0)];
+    float lg0[FU];
+    bool ok0[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        const int it = tg0[u] - item_lo;
+        ok0[u] = tid + u * NT < nf && tr0[u] == b && tg0[u] >= 0 && tp0[u] >= 0 && it >= 0 && it < I;
+        lg0[u] = row[ok0[u] ? it : 0];
+    }
+    float mx = fmaxf(-INFINITY, st0);
+    for (int g = tid + NT; g < G; g += NT) mx = fmaxf(mx, stat[((size_t)g * B + b) * 2]);
     mx = block_max(mx, red);
     float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
-    for (int g = threadIdx.x; g < G; g += NT) {
+    if (tid < G) s += st1 * expf(st0 - mx);
+    for (int g = tid + NT; g < G; g += NT) {
         const float* q = stat + ((size_t)g * B + b) * 2;
         s += q[1] * expf(q[0] - mx);
     }
-    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+    if (idx0 >= 0) {
+        xl += x0 * rl0;
+        nx += x0;
+    }
+    for (int e = e0 + tid + NT; e < e1; e += NT) {
         const float x = values ? values[e] : 1.f;
         xl += x * row[indices[e]];
         nx += x;
     }
-    // (round 5: the thread's fake pairs in batches of four -- the triples requested together, then the logits of the pairs that count,
-    // added in the loop's order; as a plain loop every pair was two dependent round trips of its own)
-    constexpr int FU = 4;
-    for (int q0 = threadIdx.x; q0 < nf; q0 += FU * NT) {
+#pragma unroll
+    for (int u = 0; u < FU; ++u)
+        if (ok0[u]) ps += expf(lg0[u] - mx);
+    // (the thread's further fake pairs in batches of four -- the triples requested together, then the logits of the pairs that count,
+    // added in the loop's order)
+    for (int q0 = tid + FU * NT; q0 < nf; q0 += FU * NT) {
         int tg[FU], tr[FU], tp[FU];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
@@ -1856,18 +1912,64 @@ __global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, con
     __shared__ float s_x[DL_SEG];
     __shared__ uint8_t s_s[DL_SEG];
     __shared__ float red[NT / 64];
-    const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG;
+    const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG, tid = threadIdx.x;
     const int i1 = min(I, i0 + DL_SEG);
-    for (int j = threadIdx.x; j < DL_SEG; j += NT) {
+    const size_t base = (size_t)b * I;
+    // Round 5, second pass: every request that depends on nothing FIRST -- the segment's logits themselves (they were the LAST thing the kernel
+    // asked for, one dependent trip per 512 items behind five others), the first batch of y's and fake-pair triples, the thread's first sparse
+    // entry, the ranks' row partials and cnt[0].  Sums and stores are the same terms in the same order as before.
+    constexpr int FU = 4;
+    constexpr int NL = D16 ? DL_SEG / (2 * NT) : DL_SEG / NT;
+    float2 lg2[D16 ? NL : 1];
+    float lg1[D16 ? 1 : NL];
+    if constexpr (D16) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) lg2[j] = *reinterpret_cast<const float2*>(logits + base + min(i0 + 2 * tid + 2 * NT * j, I - 2));   // (I % 8 == 0)
+    } else {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) lg1[j] = logits[base + min(i0 + tid + NT * j, I - 1)];
+    }
+    float ty0[FU];
+    int tg0[FU], tr0[FU], tp0[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        ty0[u] = 0.f;
+        tg0[u] = tr0[u] = tp0[u] = -1;
+    }
+    if (nf > 0) {      // (ONE uniform branch around the requests: a select per element made a basic block -- and a wait -- of each)
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = min(tid + u * NT, nf - 1);
+            tg0[u] = f_gen[q];
+            tr0[u] = f_row[q];
+            tp0[u] = f_pop[q];
+        }
+        if (y) {
+#pragma unroll
+            for (int u = 0; u < FU; ++u) ty0[u] = y[min(tid + u * NT, nf - 1)];
+        }
+    }
+    const int e0 = indptr[b], e1 = indptr[b + 1];
+    int it0 = -1;
+    float x0 = 1.f;
+    if (e0 + tid < e1) {
+        it0 = indices[e0 + tid];
+        if (values) x0 = values[e0 + tid];
+    }
+    auto row_terms = [=] __device__(int rb, float& l, float& nx, float& pb, float& xl) { ltg_rank_terms(rowpart_all, R, B, rb, l, nx, pb, xl); };
+    float l, nx, pb, xl;
+    row_terms(b, l, nx, pb, xl);
+    const int cntv = cnt ? cnt[0] : 0;
+    for (int j = tid; j < DL_SEG; j += NT) {
         s_x[j] = 0.f;
         s_s[j] = 0;
     }
-    // (round 5: y and the fake-pair triples in batches of four requests, consumed in the loops' order: as plain loops with a runtime bound
-    // every element was a round trip of its own -- about eight of them in front of the first logit this launch reads)
-    constexpr int FU = 4;
     float sy = 0.f;
-    if (y)
-        for (int q0 = threadIdx.x; q0 < nf; q0 += FU * NT) {
+    if (y) {
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (tid + u * NT < nf) sy += ty0[u];
+        for (int q0 = tid + FU * NT; q0 < nf; q0 += FU * NT) {
             float ty[FU];
 #pragma unroll
             for (int u = 0; u < FU; ++u) ty[u] = y[min(q0 + u * NT, nf - 1)];
@@ -1875,12 +1977,19 @@ __global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, con
             for (int u = 0; u < FU; ++u)
                 if (q0 + u * NT < nf) sy += ty[u];
         }
+    }
     __syncthreads();
-    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
+    if (it0 >= i0 && it0 < i1) s_x[it0 - i0] = x0;
+    for (int e = e0 + tid + NT; e < e1; e += NT) {
         const int it = indices[e];
         if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
     }
-    for (int q0 = threadIdx.x; q0 < nf; q0 += FU * NT) {
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        const int it = tg0[u] - item_lo;  // fake pairs carry global item ids
+        if (tid + u * NT < nf && tr0[u] == b && tg0[u] >= 0 && it >= i0 && it < i1 && tp0[u] >= 0) s_s[it - i0] = 1;
+    }
+    for (int q0 = tid + FU * NT; q0 < nf; q0 += FU * NT) {
         int tg[FU], tr[FU], tp[FU];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
@@ -1891,30 +2000,34 @@ __global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, con
         }
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
-            const int it = tg[u] - item_lo;  // fake pairs carry global item ids
+            const int it = tg[u] - item_lo;
             if (q0 + u * NT < nf && tr[u] == b && tg[u] >= 0 && it >= i0 && it < i1 && tp[u] >= 0) s_s[it - i0] = 1;
         }
     }
     sy = block_sum(sy, red);   // (its barriers also publish s_x / s_s)
-    auto row_terms = [=] __device__(int rb, float& l, float& nx, float& pb, float& xl) { ltg_rank_terms(rowpart_all, R, B, rb, l, nx, pb, xl); };
-    float l, nx, pb, xl;
-    row_terms(b, l, nx, pb, xl);
     const float invB = 1.f / (float)B;
-    const float c = (cnt && cnt[0] > 0) ? lam / (float)cnt[0] * sy : 0.f;
+    const float c = cntv > 0 ? lam / (float)cntv * sy : 0.f;
     const float alpha = nx * invB + c * pb;
-    const size_t base = (size_t)b * I;
     if constexpr (D16) {   // I % 8 == 0 (stream_ok): pairs of items, one 8-B load and one 4-B store per lane
-        for (int i = i0 + 2 * threadIdx.x; i < i1; i += 2 * NT) {
-            const float2 lg = *reinterpret_cast<const float2*>(logits + base + i);
-            const float p0 = expf(lg.x - l), p1 = expf(lg.y - l);
-            const float d0 = p0 * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p0 : 0.f);
-            const float d1 = p1 * alpha - s_x[i + 1 - i0] * invB - (s_s[i + 1 - i0] ? c * p1 : 0.f);
-            reinterpret_cast<unsigned*>(dlog)[(base + i) >> 1] = (unsigned)ltg_f2bf(d0) | ((unsigned)ltg_f2bf(d1) << 16);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = i0 + 2 * tid + 2 * NT * j;
+            if (i < i1) {
+                const float2 lg = lg2[j];
+                const float p0 = expf(lg.x - l), p1 = expf(lg.y - l);
+                const float d0 = p0 * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p0 : 0.f);
+                const float d1 = p1 * alpha - s_x[i + 1 - i0] * invB - (s_s[i + 1 - i0] ? c * p1 : 0.f);
+                reinterpret_cast<unsigned*>(dlog)[(base + i) >> 1] = (unsigned)ltg_f2bf(d0) | ((unsigned)ltg_f2bf(d1) << 16);
+            }
         }
     } else {
-        for (int i = i0 + threadIdx.x; i < i1; i += NT) {
-            const float p = expf(logits[base + i] - l);
-            dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = i0 + tid + NT * j;
+            if (i < i1) {
+                const float p = expf(lg1[j] - l);
+                dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) lse[b] = l;
@@ -1976,6 +2089,7 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
         // 25 024-item step were eight dependent round trips in a 6-us launch on the caller's stream)
         float s = 0.f;
         constexpr int DU = 32;
+        const float t = h2 ? h2[i] : 0.f;      // (requested with the first slabs, not behind them)
         for (int z = 0; z < nsplit; z += DU) {
             float x[DU];
 #pragma unroll
@@ -1984,7 +2098,6 @@ __global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __re
             for (int u = 0; u < DU; ++u)
                 if (z + u < nsplit) s += x[u];
         }
-        const float t = h2 ? h2[i] : 0.f;
         da2[i] = s * __builtin_fmaf(-t, t, 1.f);   // (rounding pinned: fk_dz_dh2's operand loader computes the same expression)
     }
 }
@@ -3267,7 +3380,7 @@ static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLa
         return;
     }
     pr.before(LTG_K_D_ADAM);
-    if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga), dim3(NT), 0, st, ks, P, stride, slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out, poison);
+    if (flat) hipLaunchKernelGGL(fk_d_adam, dim3(ga + 1), dim3(NT), 0, st, ks, P, stride, slab, disc->p[0], disc->m[0], disc->v[0], ad, loss_out, poison);
     else hipLaunchKernelGGL(k_d_adam, dim3(ga), dim3(NT), 0, st, ks, L, stride, slab, *disc, ad, n, lrow, loss_out);
     pr.after(LTG_K_D_ADAM);
 }

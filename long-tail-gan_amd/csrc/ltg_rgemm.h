@@ -76,7 +76,7 @@ struct LtgXfId {
 
 // mid(): called once, after the requests of the first pass have been issued and before anything consumes them -- the place
 // for work that needs an earlier load of the caller's (e.g. row factors into LDS + a barrier) without costing a round trip.
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
                                                   MID mid = MID()) {
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
@@ -102,7 +102,12 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < per; base += NBLK) {
+    // (round 5, PEEL: the first pass peeled off the loop.  As the header of a loop, the pass begins with the waits the back edge needs -- the
+    // registers the requests land in are the targets of the previous pass's loads -- and those waits also drain whatever the CALLER has in flight on
+    // first entry (pair ids, tile partials, activations of the epilogue).  Measured same-box on Askubuntu_Sample: peeled everywhere D phase 54.85 ->
+    // 53.6 ms per epoch but G phase 69.1 -> 70.5 (twice the code for launches that last 5-9 us): the discriminator's kernels peel, the
+    // generator's do not.)
+    auto pass = [&] __device__(const int base) {
         decltype(a_ld(0, 0, 0)) ra[NBLK][TM];   // RAW operand requests: a float4, or a small struct of them (a_xf folds it)
         decltype(b_ld(0, 0, 0)) rb[NBLK][TN];
         // phase 1: requests only
@@ -140,6 +145,12 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
         }
+    };
+    if constexpr (PEEL) {
+        pass(0);
+        for (int base = NBLK; base < per; base += NBLK) pass(base);
+    } else {
+        for (int base = 0; base < per; base += NBLK) pass(base);
     }
     float* mine = lds + wk * (G::BM * G::LDC);
 #pragma unroll
@@ -158,7 +169,7 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
 // sizes the fp32 form kept the matrix pipe busy for 1-1.2 us of each of these 8-us kernels.
 // K is cut into blocks of 32: lane (r, q) fetches k = 32 jb + 8 q .. + 7 of its row / column as TWO requests of four (the functors' unit).
 // a_xf / b_xf must return values that are exactly representable in bf16 (ltg_bf16r4) or zero; NBLK counts 32-deep blocks.
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
                                                        MID mid = MID()) {
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
@@ -193,7 +204,7 @@ __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int 
         p[3] = (__float_as_uint(hi[2]) >> 16) | (__float_as_uint(hi[3]) & 0xFFFF0000u);
         return __builtin_bit_cast(ltg_bf16x8, p);
     };
-    for (int base = 0; base < per; base += NBLK) {
+    auto pass = [&] __device__(const int base) {      // (first pass peeled: see ltg_rgemm_product)
         decltype(a_ld(0, 0, 0)) ra[NBLK][TM][2];
         decltype(b_ld(0, 0, 0)) rb[NBLK][TN][2];
         // phase 1: requests only
@@ -239,6 +250,12 @@ __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int 
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[tm], bp[tn], acc[tm][tn], 0, 0, 0);
         }
+    };
+    if constexpr (PEEL) {
+        pass(0);
+        for (int base = NBLK; base < per; base += NBLK) pass(base);
+    } else {
+        for (int base = 0; base < per; base += NBLK) pass(base);
     }
     float* mine = lds + wk * (G::BM * G::LDC);
 #pragma unroll
@@ -252,13 +269,13 @@ __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int 
 }
 
 // BFM: the product on the bf16 matrix pipe (ltg_rgemm_product_bf16; NBLK then counts 32-deep blocks)
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, bool PEEL = false, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds,
                                           MID mid = MID()) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
-    if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
+    if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK, PEEL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     else
-    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, PEEL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
     static_assert(NE % 256 == 0, "tile must divide over 256 threads");
@@ -287,15 +304,20 @@ __device__ __forceinline__ void ltg_rgemm_v4(int M, int N, int K, int m0, int n0
     constexpr int NP = (NE4 + 255) / 256;
     static_assert(NE4 % 256 == 0, "tile must divide over 256 threads in float4");
     decltype(prefetch(0, 0, false)) pre[NP];
+    // (round 5: the epilogue's operands are requested in the product's mid hook -- BEHIND the first pass's operand requests, in front of anything
+    // that consumes them -- and no longer in front of the product: the compiler drained them (s_waitcnt vmcnt(0)) before the first operand request
+    // of some instantiations, a round trip of its own per tile.  In the queue behind the operands they cost nothing: the MFMAs wait with counts.)
+    auto pre_mid = [&] __device__() {
 #pragma unroll
-    for (int e = 0; e < NP; ++e) {
-        const int id = tid + 256 * e;
-        const int mm = id / (G::BN / 4), nn = (id % (G::BN / 4)) * 4;
-        pre[e] = prefetch(m0 + mm, n0 + nn, m0 + mm < M && n0 + nn < N);
-    }
-    if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
+        for (int e = 0; e < NP; ++e) {
+            const int id = tid + 256 * e;
+            const int mm = id / (G::BN / 4), nn = (id % (G::BN / 4)) * 4;
+            pre[e] = prefetch(m0 + mm, n0 + nn, m0 + mm < M && n0 + nn < N);
+        }
+    };
+    if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, pre_mid);
     else
-    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds);
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, pre_mid);
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
         const int id = tid + 256 * e;
