@@ -126,9 +126,9 @@ __device__ __forceinline__ void ltg_gate_wait_tail(LtgGate g) {
     if (!open && !dead && g.expired) atomicAdd(g.expired, 1u);
 }
 // word 2 of ltg_pipe.sync: a device-side wait of this pipe has given up -- nothing that follows may touch the model
-__device__ __forceinline__ bool ltg_poisoned(const unsigned* __restrict__ p) {
-    return p && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-}
+// (round 5: a PLAIN load -- the scalar unit's, see ltg_poison_word below for why that is enough -- instead of an agent-scope atomic one: the
+// guard is the first statement of its kernels, and as a vector load it was a ~1-us round trip in front of every other request)
+__device__ __forceinline__ bool ltg_poisoned(const unsigned* __restrict__ p) { return p && *p != 0u; }
 // The word itself, for kernels that REQUEST it first and look at it in front of their first store (round 5): `if (ltg_poisoned(p)) return;`
 // as a kernel's first statement is a vector-memory round trip of its own in front of every other request.  A PLAIN load of a uniform address
 // before the kernel's first store: the compiler issues it on the SCALAR unit (s_load_dword, beside the kernel-argument loads), so nothing in
@@ -434,32 +434,55 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, 
     // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup).  Rows >= M MIRROR row M - 1:
     // their products equal row M - 1's and are stored to row M - 1's addresses (same value twice) -- no row predicate
     // anywhere in the loop, so every s_waitcnt is an exact count and the prefetch is never drained.
-    ltg_bf16x8 af[ST_KS];
-    {
-        const int row = min(16 * w + lr, M - 1);
-        const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)row * H);
-        const int H4 = H >> 2;
-#pragma unroll
-        for (int ks = 0; ks < ST_KS; ++ks) {
-            const int c4 = ks * 8 + 2 * lq;
-            const float4 x0 = hr[min(c4, H4 - 1)], x1 = hr[min(c4 + 1, H4 - 1)];
-            const uint2 p0 = ltg_pack4(x0), p1 = ltg_pack4(x1);
-            const unsigned k0 = c4 < H4 ? 0xFFFFFFFFu : 0u, k1 = c4 + 1 < H4 ? 0xFFFFFFFFu : 0u;   // K padding -> 0
-            ltg_u32x4 t;
-            t[0] = p0.x & k0; t[1] = p0.y & k0; t[2] = p1.x & k1; t[3] = p1.y & k1;
-            af[ks] = __builtin_bit_cast(ltg_bf16x8, t);
-        }
-    }
+    // (round 5: the first two / three W tiles are requested BEFORE the h2 fragments, the first one goes to LDS behind them -- h2, then the first
+    // tile, then the others was three dependent round trips in front of the first product of workgroups that own two or three tiles in all)
     const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
-    float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rs[4] = {0.f, 0.f, 0.f, 0.f};
     StW r0, r1, r2;
     int t = blockIdx.x, cur = 0;
     if (t < ntiles) {
         st_fetch_w(Wb, I, t * ST_BN, r0);
-        st_stash_w(st_lds, r0);
         st_fetch_w(Wb, I, min(t + G, last) * ST_BN, r1);
         if constexpr (PF == 3) st_fetch_w(Wb, I, min(t + 2 * G, last) * ST_BN, r2);
     }
+    ltg_bf16x8 af[ST_KS];
+    {
+        // (the fragments in TWO batches of requests: all 38 at once beside the W tiles took 248 registers, and two such waves per SIMD leave the
+        // side stream's clock kernels no room -- see DESIGN 5.3)
+        const int row = min(16 * w + lr, M - 1);
+        const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)row * H);
+        const int H4 = H >> 2;
+        constexpr int KSA = (ST_KS + 1) / 2;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            float4 x0[KSA], x1[KSA];
+#pragma unroll
+            for (int j = 0; j < KSA; ++j) {
+                const int ks = hb * KSA + j;
+                if (ks < ST_KS) {
+                    const int c4 = ks * 8 + 2 * lq;
+                    x0[j] = hr[min(c4, H4 - 1)];
+                    x1[j] = hr[min(c4 + 1, H4 - 1)];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < KSA; ++j) {
+                const int ks = hb * KSA + j;
+                if (ks < ST_KS) {
+                    const int c4 = ks * 8 + 2 * lq;
+                    const uint2 p0 = ltg_pack4(x0[j]), p1 = ltg_pack4(x1[j]);
+                    const unsigned k0 = c4 < H4 ? 0xFFFFFFFFu : 0u, k1 = c4 + 1 < H4 ? 0xFFFFFFFFu : 0u;   // K padding -> 0
+                    ltg_u32x4 tt;
+                    tt[0] = p0.x & k0; tt[1] = p0.y & k0; tt[2] = p1.x & k1; tt[3] = p1.y & k1;
+                    if (hb == 0) asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));   // (packed HERE: the compiler otherwise sinks the packing behind the second batch)
+                    af[ks] = __builtin_bit_cast(ltg_bf16x8, tt);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < ntiles) st_stash_w(st_lds, r0);
     __syncthreads();
     // ST_STEP(RL, RS): LDS[cur] holds tile tc = min(t, last), RS holds tile min(t + G, last) (in flight since the previous
     // step); tile min(t + 2G, last) is requested into RL, so two tiles of HBM loads are always outstanding per workgroup.
@@ -795,11 +818,14 @@ __global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int c
     }
     StW r0, r1;
     float4 e0, e1, o0, o1;     // A fragments of the even / odd steps
+    // (round 5: all four requests of the prologue first, THEN the first tile's way into LDS -- stashed right behind its own request it made
+    // the prologue two dependent round trips, in workgroups whose whole chunk is five or six steps)
     fetch_w(ibeg, r0);
-    stash_w(st_lds, r0);
     DH_LOAD_A(ibeg, e0, e1)
     fetch_w(min(ibeg + ST_BN, ilast), r1);
     DH_LOAD_A(ibeg + ST_BN, o0, o1)
+    __builtin_amdgcn_sched_barrier(0);
+    stash_w(st_lds, r0);
     __syncthreads();
     int cur = 0;
     const int tq = lr >> 2, tp = lr & 3;
