@@ -658,6 +658,7 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (pv.nr >= 0) return;
 #endif
+    LTG_STAMP_AT(1, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg32::LDS_FLOATS];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const bool br = blockIdx.z != 0;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
         const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + coff + nn] = kp ? t / keep : 0.f;
     };
-    ltg_rgemm<1, 1, 2, 2, 1, 7, false, true>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 2, 2, 1, 7, false, true, 1>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // fully connected layer + the output unit's dot product (discriminator.py:44-45, :54-55): A3 = dropout(tanh(A1 . w3 + b3));
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (n >= 0) return;
 #endif
+    LTG_STAMP_AT(2, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
     const int tn = (h3 + 31) / 32;
     const int tid_ = xcd_chunk(blockIdx.x, gridDim.x);
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
         for (int o = 16; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
         if ((threadIdx.x & 31) == 0 && m < n) spart[(size_t)tile * n + m] = pd;
     };
-    ltg_rgemm<2, 2, 1, 1, 4, 7, false, true>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<2, 2, 1, 1, 4, 7, false, true, 2>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
 }
 
 // output unit from the tile partials (discriminator.py:45,55; train.py:142): y, d loss / d s, loss term of one pair row
@@ -770,6 +772,8 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (pv.nr >= 0) return;
 #endif
+    LTG_STAMP_AT(3, 0);
+    LTG_STAMP_AT(4, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
     __shared__ float s_ds[D_KCHUNK], s_lr[D_KCHUNK];
     const int n = pv.nr + pv.nf, tid = threadIdx.x;
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
         auto epi = [=] __device__(int e, int m, int nn, float v, bool ok) {
             if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(a1v[e], keep);
         };
-        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA, false, true>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA, false, true, 3>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
         return;
     }
     d_bwd1_jobs_bc(pv, h12, h3, bid - nA, nB, ntile, L, SP, A1, A3, G3, spart, b4v, slab, lds, s_ds, s_lr);
@@ -877,7 +881,7 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB, false, true>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB, false, true, 4>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
         return;
     }
     bid -= nB;
@@ -916,6 +920,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
 #ifdef LTG_D_EMPTY   // MEASUREMENT BUILD ONLY (results wrong): the grid, registers and LDS of this launch, no work -- the D step's launch structure
     if (pv.nr >= 0) return;
 #endif
+    LTG_STAMP_AT(5, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const int tm = (h0 + 1 + 15) / 16;
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    ltg_rgemm<1, 2, 1, 1, 4, 4, false, true>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 4, 4, false, true, 5>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // (Measured and not kept, round 3: this sweep FUSED into fk_d_bwd2 -- every workgroup releases its slab tile with a device-scope fence

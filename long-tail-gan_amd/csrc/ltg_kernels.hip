@@ -4450,4 +4450,10 @@ int ltg_rank_finish(const ltg_batch* te, const int32_t* counts, int32_t k_ndcg, 
     return check_launch();
 }
 
+#ifdef LTG_STAMP
+// MEASUREMENT BUILD ONLY: copies the phase stamps of the stamped kernel's last launch (ltg_rgemm.h) to the host
+int ltg_debug_stamps(void* dst, int n_words) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ltg_stamp_buf), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // extern "C"

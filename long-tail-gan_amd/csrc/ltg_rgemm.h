@@ -42,6 +42,26 @@ __device__ __forceinline__ ltg_f32x4 ltg_ld4s(const float* __restrict__ p, size_
 __device__ __forceinline__ float ltg_bf16r(float x) { return __uint_as_float((unsigned)ltg_f2bf(x) << 16); }
 __device__ __forceinline__ ltg_f32x4 ltg_bf16r4(ltg_f32x4 v) { return ltg_f32x4{ltg_bf16r(v[0]), ltg_bf16r(v[1]), ltg_bf16r(v[2]), ltg_bf16r(v[3])}; }
 
+// MEASUREMENT BUILD ONLY (-DLTG_STAMP=<id>): the workgroups of ONE kernel (the one that instantiates the block with SID == LTG_STAMP) leave
+// 100-MHz wall-clock stamps of their phases in ltg_stamp_buf[workgroup][8] (scripts/stamp_probe.py reads them through ltg_debug_stamps):
+// 0 kernel entry (the kernel's own first statement), 1 operand requests issued, 2 mid hook done, 3 last MFMA issued, 4 K slices met in LDS,
+// 5 epilogue done (stores issued), 6 HW_ID register, 7 unused
+#ifdef LTG_STAMP
+__device__ unsigned long long ltg_stamp_buf[16384 * 8];
+__device__ __forceinline__ void ltg_stamp(int slot) {
+    if (threadIdx.x == 0) {
+        const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (wg < 16384u)
+            ltg_stamp_buf[wg * 8 + slot] = slot == 6 ? ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                                        ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32))   // HW_ID | XCC_ID << 32
+                                                     : wall_clock64();
+    }
+}
+#define LTG_STAMP_AT(SID, slot) do { if constexpr ((SID) == LTG_STAMP) ltg_stamp(slot); } while (0)
+#else
+#define LTG_STAMP_AT(SID, slot) do { } while (0)
+#endif
+
 template <int TM, int TN, int WM, int WN, int WK>
 struct LtgRg {
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
@@ -76,7 +96,7 @@ struct LtgXfId {
 
 // mid(): called once, after the requests of the first pass have been issued and before anything consumes them -- the place
 // for work that needs an earlier load of the caller's (e.g. row factors into LDS + a barrier) without costing a round trip.
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, int SID = 0, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
                                                   MID mid = MID()) {
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
@@ -120,7 +140,11 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
             for (int tn = 0; tn < TN; ++tn) rb[i][tn] = b_ld(i, kc, bn[tn]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (base == 0) mid();
+        if (base == 0) {
+            LTG_STAMP_AT(SID, 1);
+            mid();
+            LTG_STAMP_AT(SID, 2);
+        }
         // phase 2: transforms and MFMAs, block by block as the data lands
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) {
@@ -152,6 +176,7 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
     } else {
         for (int base = 0; base < per; base += NBLK) pass(base);
     }
+    LTG_STAMP_AT(SID, 3);
     float* mine = lds + wk * (G::BM * G::LDC);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -161,6 +186,7 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
             for (int x = 0; x < 4; ++x)
                 mine[((wm * TM + tm) * 16 + 4 * q + x) * G::LDC + (wn * TN + tn) * 16 + r] = acc[tm][tn][x];
     __syncthreads();
+    LTG_STAMP_AT(SID, 4);
 }
 
 // The same product on the bf16 matrix pipe, for the three decoder GEMMs whose operands the loaders round to bf16 anyway (round 5): the
@@ -269,13 +295,13 @@ __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int 
 }
 
 // BFM: the product on the bf16 matrix pipe (ltg_rgemm_product_bf16; NBLK then counts 32-deep blocks)
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, bool PEEL = false, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, bool PEEL = false, int SID = 0, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds,
                                           MID mid = MID()) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
     if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK, PEEL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     else
-    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, PEEL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, PEEL, SID>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
     static_assert(NE % 256 == 0, "tile must divide over 256 threads");
@@ -289,6 +315,8 @@ __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, A
         const int m = m0 + mm, n = n0 + nn;
         epi(e, m, n, v, m < M && n < N);
     }
+    LTG_STAMP_AT(SID, 5);
+    LTG_STAMP_AT(SID, 6);
 }
 
 // The same block with a float4 epilogue: epi4(pre, m, n, value4, in_range) with n % 4 == 0; in_range = m < M && n < N (a
