@@ -240,6 +240,21 @@ class KernelProfiler:
                 out[nm] = {"avg_us": float(np.mean(ms)) * 1e3, "samples": len(ms)}
         return out
 
+    def table(self, calib):
+        out = {}
+        for name, c in calib.items():
+            bf = self.a.precision == "bf16" and name in ("dec1_fwd", "dh2", "dec1_bwd_adam")
+            d_low = getattr(self.a, "d_precision", "fp32") in ("fp8", "bf16") and name.startswith("d_") and name != "d_adam"
+            peak_f = PEAK["mfma_bf16"] if (bf or d_low) else PEAK["mfma_fp32"]
+            avg, fl, by = c["avg_ms"], c["flops"], c["bytes"]
+            if avg <= 0:
+                continue
+            if by / PEAK["hbm"] >= fl / peak_f:
+                out[name] = {"bound": "hbm", "frac": round(by / (avg * 1e-3) / PEAK["hbm"], 4), "avg_us": round(avg * 1e3, 2)}
+            else:
+                out[name] = {"bound": "mfma", "frac": round(fl / (avg * 1e-3) / peak_f, 4), "avg_us": round(avg * 1e3, 2)}
+        return out
+
     def roofline(self, name, calib):
         ms = [e.elapsed_ms() for e, _, _ in self.samples]
         ms = [m for m in ms if m is not None]
@@ -642,6 +657,9 @@ def main():
         res["roofline"]["step_frac_of_copy_ceiling"] = res["roofline"]["step_frac"] * PEAK["hbm"] / 1e9 / cc["value"]
         if calib:
             res["kernels_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in calib.items()}
+            # every probed kernel against ITS roofline (calibration pass: HIP events around one kernel per call, same brackets as `roofline`):
+            # the dominant kernel changes as kernels get faster (round 5: fk_g_tail -> fk_d_l2), the table keeps them comparable
+            res["kernels_roofline"] = prof.table(calib)
         if n1_ref:
             res["n1_same_workload"] = {"value": n1_ref, "unit": "users/s", "note": "same workload, unsharded, on rank 0's GPU in this job"}
             res["strong_scaling_vs_1gpu"] = value / n1_ref
