@@ -5,5 +5,5 @@ set -e
 NAME=$1; shift
 ROOT=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $ROOT/ab_live
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -shared -o $ROOT/ab_live/libltg_$NAME.so $ROOT/long-tail-gan_amd/csrc/ltg_kernels.hip
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 "$@" -shared -o $ROOT/ab_live/libltg_$NAME.so $ROOT/long-tail-gan_amd/csrc/ltg_kernels.hip
 ls -la $ROOT/ab_live/libltg_$NAME.so
