@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
                                               LtgGate end_wait = LTG_NO_GATE) {
     // end_wait (one-call step): the kernel behind this one, dec-0, overwrites h2, which the previous step's weight update reads in its
     // prologue on the side stream -- ONE thread of this launch polls for the update's word as the last thing it does
+    LTG_STAMP_AT(11, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
     const LtgTile2 tl = xcd_tile2();
     const int m0 = tl.y * 16, n0 = tl.x * 16, Z2 = 2 * Z;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
         }
     };
     // the block sees logical columns [0, 32) of this tile (all "in range"; the real bounds are the functors' business)
-    ltg_rgemm<1, 2, 1, 1, 4, 10>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 4, 10, false, false, 11>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
 }
 
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     // one-call step: h2 may only be overwritten once the previous step's weight update (side stream) has read it -- the kernel in front
     // of this one waited for that (fk_enc1's end_wait; poison: the wait gave up).  end_wait: the kernel BEHIND this one streams the bf16
     // shadow of W_p1t, which that update rewrites until it ends: one thread of this launch polls for its end as the last thing it does.
+    LTG_STAMP_AT(12, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
     const unsigned dead = ltg_poison_word(poison);   // (requested first, looked at in front of the stores: not a round trip of its own)
     const LtgTile2 tl = xcd_tile2();
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(NT) void fk_dec0(int B, int H, int Z, const float* 
     auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
         if (ok && !ltg_word_set(dead)) h2[(size_t)m * H + n] = tanhf(v + biasv);
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 4>(B, H, Z, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 1, 1, 4, 4, false, false, 12>(B, H, Z, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
     if (ltg_word_set(dead)) return;
     if (tl.x == 0) {
 #pragma unroll
@@ -198,7 +200,7 @@ __device__ __forceinline__ void dz_tile(int B, int Z, int H, const float* __rest
         dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
         dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 10>(B, Z, H, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 1, 1, 4, 10, false, false, 15>(B, Z, H, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)                                      [B][H]
@@ -210,12 +212,13 @@ __device__ __forceinline__ void dh1_tile(int B, int H, int Z2, const float* __re
     auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
         if (ok) da1[(size_t)m * H + n] = v * (1.f - t * t);
     };
-    ltg_rgemm<1, 1, 1, 1, 4, 7>(B, H, Z2, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 1, 1, 4, 7, false, false, 16>(B, H, Z2, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
 }
 
 __global__ __launch_bounds__(NT) void fk_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
                                             const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
                                             float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
+    LTG_STAMP_AT(15, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
     const LtgTile2 tl = xcd_tile2();
     dz_tile(B, Z, H, da2, Wp0, mulv, eps_in, is_training, anneal, seed, step, dmlv, tl.y * 16, tl.x * 16, lds);
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(NT) void fk_dz_dh2(int B, int Z, int H, const float
 }
 __global__ __launch_bounds__(NT) void fk_dh1(int B, int H, int Z2, const float* __restrict__ dmlv, const float* __restrict__ Wq1,
                                              const float* __restrict__ h1, float* __restrict__ da1) {
+    LTG_STAMP_AT(16, 0);
     __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
     const LtgTile2 tl = xcd_tile2();
     dh1_tile(B, H, Z2, dmlv, Wq1, h1, da1, tl.y * 16, tl.x * 16, lds);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase timeline of ONE discriminator kernel (measurement build -DLTG_STAMP=<id>: 1 fk_d_l1, 2 fk_d_l2, 3 fk_d_bwd1 job A,
-4 job B, 5 fk_d_bwd2; csrc/ltg_rgemm.h).  Runs one D sub-epoch of the headline workload through bench.py and reads the stamps of the LAST
+"""Per-workgroup phase timeline of ONE latency kernel (measurement build -DLTG_STAMP=<id>: 1 fk_d_l1, 2 fk_d_l2, 3 fk_d_bwd1 job A,
+4 job B, 5 fk_d_bwd2, 11 fk_enc1, 12 fk_dec0, 15 fk_dz, 16 fk_dh1; csrc/ltg_rgemm.h).  Runs one D sub-epoch of the headline workload through bench.py and reads the stamps of the LAST
 launch.  usage: LTG_HIP_LIB=ab_live/libltg_stamp2.so python scripts/stamp_probe.py <n_workgroups>"""
 import ctypes, os, runpy, sys
 import numpy as np
