@@ -53,6 +53,7 @@ typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over
 // of logvar): logical tile column c < 16 is column n0 + c, c >= 16 is column Z + n0 + (c - 16), so the epilogue holds both
 // halves of a z value in two lanes 16 apart -- z is computed once per element, eps is drawn once per element.
 typedef LtgRg<1, 2, 1, 1, 4> Rg16x32;   // 16 x 32 tile, four K slices
+typedef LtgRg<1, 2, 1, 1, 8> Rg16x32k8; // the same tile over EIGHT K slices (512 threads): fk_enc1
 // a value and what its transform needs, requested together (operand loaders of ltg_rgemm return it RAW; the a_xf functor folds it)
 struct LtgRaw2 {
     ltg_f32x4 x, y;
@@ -60,8 +61,12 @@ struct LtgRaw2 {
 // PRE (item-sharded step): h1 holds the all-reduced PRE-activation of enc-0; the operand loader applies bias + tanh
 // (MultiVAE.py:152-155) and the column-tile-0 workgroups leave h1 = tanh(pre + b_q0) in h1_out for the backward -- no separate
 // k_bias_tanh launch between the exchange and this layer.
+// Round 5: EIGHT K slices (512 threads).  With four, a wave had 90 requests to issue -- 80 of them the strided 4-byte loads of the [K][N] weight
+// operand -- and can have 64 in flight: the last third waited for the first arrivals (2.6 us until all were issued, profiles/r5_stamp_fk_enc1_fk_dh1.txt);
+// with eight, 45 requests and 40 MFMAs per wave.
+constexpr int ENC1_NT = 512;
 template <bool PRE>
-__global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* __restrict__ h1, const float* __restrict__ Wq1,
+__global__ __launch_bounds__(ENC1_NT) void fk_enc1(int B, int H, int Z, const float* __restrict__ h1, const float* __restrict__ Wq1,
                                               const float* __restrict__ bq1, const float* __restrict__ eps_in, float is_training,
                                               uint64_t seed, uint64_t step, float* __restrict__ mulv, float* __restrict__ z,
                                               const float* __restrict__ bq0 = nullptr, float* __restrict__ h1_out = nullptr,
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
     // end_wait (one-call step): the kernel behind this one, dec-0, overwrites h2, which the previous step's weight update reads in its
     // prologue on the side stream -- ONE thread of this launch polls for the update's word as the last thing it does
     LTG_STAMP_AT(11, 0);
-    __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[Rg16x32k8::LDS_FLOATS];
     const LtgTile2 tl = xcd_tile2();
     const int m0 = tl.y * 16, n0 = tl.x * 16, Z2 = 2 * Z;
     auto col = [=] __device__(int c) { return min(n0 + (c & 15), Z - 1) + (c >> 4) * Z; };   // logical tile column -> column of mulv
@@ -89,12 +94,9 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
     // the epilogue's own operands are requested BEFORE the product (thread -> output map of ltg_rgemm: id = tid + 256 e,
     // row id / 32, logical column id % 32 = tid % 32), so the epilogue adds no round trip
     const float biasv = bq1[col(threadIdx.x & 31)];
-    float epsv[2] = {0.f, 0.f};
-    if (is_training != 0.f && eps_in) {   // uniform
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            epsv[e] = eps_in[(size_t)min(m0 + (int)(threadIdx.x + 256 * e) / 32, B - 1) * Z + min(n0 + (int)(threadIdx.x & 15), Z - 1)];
-    }
+    float epsv[1] = {0.f};          // (512 threads: one output of the 16 x 32 tile per thread)
+    if (is_training != 0.f && eps_in)   // uniform
+        epsv[0] = eps_in[(size_t)min(m0 + (int)threadIdx.x / 32, B - 1) * Z + min(n0 + (int)(threadIdx.x & 15), Z - 1)];
     auto epi = [=] __device__(int ei, int m, int c, float v, bool) {
         const int j = n0 + (c & 15);
         const bool ok = m < B && j < Z;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(NT) void fk_enc1(int B, int H, int Z, const float* 
         }
     };
     // the block sees logical columns [0, 32) of this tile (all "in range"; the real bounds are the functors' business)
-    ltg_rgemm<1, 2, 1, 1, 4, 10, false, false, 11>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 8, 5, false, false, 11>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);      // (5 blocks of 16 per slice: H <= 640)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
 }
 

@@ -3151,7 +3151,7 @@ int fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
         hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
     }
     if (mid_fast(cfg, R)) {
-        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<false>, grid2(Z, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->h1, gen->p[1], gen->p[5], o->eps, o->is_training,
+        LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<false>, grid2(Z, R, 16, 16), dim3(ENC1_NT), 0, st, R, H, Z, acts->h1, gen->p[1], gen->p[5], o->eps, o->is_training,
                                                       cfg->seed, o->rng_step, acts->mulv, acts->z));
         LTG_PROBED(pr, LTG_K_DEC0, hipLaunchKernelGGL(fk_dec0, grid2(H, R, 16, 16), dim3(NT), 0, st, R, H, Z, acts->z, acts->mulv, gen->p[2], gen->p[6],
                                                       acts->kl_rows, acts->h2));
@@ -4236,7 +4236,7 @@ int ltg_g_step_sharded(const ltg_config* cfg, const ltg_gen_state* gen, const lt
                                pp->seq, poison);
     }
     if (comm) LTG_PROBED(pr, LTG_K_EXCH_H1, LTG_COMM(comm->all_reduce(pp->h1pre, pp->h1pre, (size_t)B * H, LTG_NCCL_FLOAT32, LTG_NCCL_SUM, comm->comm, stream)));
-    LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,
+    LTG_PROBED(pr, LTG_K_ENC1, hipLaunchKernelGGL(fk_enc1<true>, grid2(Z, B, 16, 16), dim3(ENC1_NT), 0, st, B, H, Z, pp->h1pre, gen->p[1], gen->p[5], o->fwd.eps,
                                                   o->fwd.is_training, cfg->seed, o->fwd.rng_step, acts->mulv, acts->z, gen->p[4], acts->h1,
                                                   gates ? LtgGate{pp->sync + 1, pp->seq - 1u, pp->sync + 2, 0} : LTG_NO_GATE));
     // (dec-0 overwrites h2, which the previous step's weight update reads in its prologue: enc-1's last thread polled for word 1 -- or,

@@ -99,7 +99,7 @@ struct LtgXfId {
 template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, int SID = 0, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
                                                   MID mid = MID()) {
-    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+    static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per workgroup");
     typedef LtgRg<TM, TN, WM, WN, WK> G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -304,10 +304,11 @@ __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, A
     ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, PEEL, SID>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
-    static_assert(NE % 256 == 0, "tile must divide over 256 threads");
+    constexpr int NTH = 64 * WM * WN * WK;      // threads of the workgroup (256, or 512 with eight K slices)
+    static_assert(NE % NTH == 0, "tile must divide over the workgroup's threads");
 #pragma unroll
-    for (int e = 0; e < NE / 256; ++e) {
-        const int id = tid + 256 * e;
+    for (int e = 0; e < NE / NTH; ++e) {
+        const int id = tid + NTH * e;
         const int mm = id / G::BN, nn = id % G::BN;
         float v = lds[mm * G::LDC + nn];
 #pragma unroll

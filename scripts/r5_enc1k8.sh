@@ -1,0 +1,10 @@
+# round 5, experiment 18: fk_enc1 over eight K slices (512 threads)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5_enc1k8
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "forward or g_step or lazy or one_call" > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
+L="new= pre8=$GRAFT_REPO_ROOT/ab_live/libltg_pre8.so"
+{
+echo "== askubuntu"; bash scripts/ab_libs.sh "$L" --steps 10
+echo "== ml20m"; bash scripts/ab_libs.sh "$L" --workload ml20m --users 6400
+} 2>&1 | tee $O/ab.txt
