@@ -42,6 +42,7 @@ __device__ __forceinline__ float ltg_mul_rounded(float a, float b) {
 
 typedef LtgRg<1, 1, 1, 1, 4> Rg16;    // 16 x 16 tile, four K slices
 typedef LtgRg<2, 2, 1, 1, 4> Rg32k;   // 32 x 32 tile, four K slices (each wave the whole tile)
+typedef LtgRg<2, 2, 1, 1, 8> Rg32k8;  // the same over EIGHT K slices (512 threads): fk_d_l2
 typedef LtgRg<1, 1, 2, 2, 1> Rg32;    // 32 x 32 tile, one 16 x 16 per wave over the whole K
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -694,7 +695,9 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
 // fully connected layer + the output unit's dot product (discriminator.py:44-45, :54-55): A3 = dropout(tanh(A1 . w3 + b3));
 // G3 = w4 * d A3 / d pre (the factor the backward needs, so that dpre3 = ds[row] * G3); spart[tile_n][row] = this column
 // tile's share of A3[row] . w4 -- the consumers add the tiles up in a fixed order (no atomics: reproducible).
-__global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const float* __restrict__ A1, const float* __restrict__ w3,
+// (round 5: eight K slices, 512 threads -- 35 instead of 70 requests and 56 instead of 112 MFMAs per wave; see fk_enc1)
+constexpr int DL2_NT = 512;
+__global__ __launch_bounds__(DL2_NT) void fk_d_l2(int n, int h12, int h3, const float* __restrict__ A1, const float* __restrict__ w3,
                                               const float* __restrict__ b3, const float* __restrict__ w4, DropView dC, float keep,
                                               uint64_t seed, uint64_t step, float* __restrict__ A3, float* __restrict__ G3,
                                               float* __restrict__ spart) {
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
     if (n >= 0) return;
 #endif
     LTG_STAMP_AT(2, 0);
-    __shared__ __attribute__((aligned(16))) float lds[Rg32k::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[Rg32k8::LDS_FLOATS];
     const int tn = (h3 + 31) / 32;
     const int tid_ = xcd_chunk(blockIdx.x, gridDim.x);
     const int m0 = (tid_ / tn) * 32, n0 = (tid_ % tn) * 32;
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(NT) void fk_d_l2(int n, int h12, int h3, const floa
         for (int o = 16; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
         if ((threadIdx.x & 31) == 0 && m < n) spart[(size_t)tile * n + m] = pd;
     };
-    ltg_rgemm<2, 2, 1, 1, 4, 7, false, true, 2>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<2, 2, 1, 1, 8, 4, false, true, 2>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
 }
 
 // output unit from the tile partials (discriminator.py:45,55; train.py:142): y, d loss / d s, loss term of one pair row
@@ -1240,10 +1243,12 @@ __global__ __launch_bounds__(NT) void fk_row_dlogits(int B, int I, const int32_t
 }
 
 // da2 = (dlog . W_p1t) * (1 - h2^2)          [B][H], K = I
+// (round 5: eight K slices, 512 threads; the 16 x 16 tile is finished by the first four waves -- 40 instead of 80 requests per wave; see fk_enc1)
+constexpr int DH2_NT = 512;
 template <bool BF>
-__global__ __launch_bounds__(NT) void fk_dh2(int B, int I, int H, const float* __restrict__ dlog, const float* __restrict__ Wp1t,
+__global__ __launch_bounds__(DH2_NT) void fk_dh2(int B, int I, int H, const float* __restrict__ dlog, const float* __restrict__ Wp1t,
                                              const float* __restrict__ h2, float* __restrict__ da2) {
-    __shared__ __attribute__((aligned(16))) float lds[Rg16::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[LtgRg<1, 1, 1, 1, 8>::LDS_FLOATS];
     const LtgTile2 tl = xcd_tile2();     // (as fk_dec1: a column block of W_p1t per XCD)
     const int m0 = tl.y * 16, n0 = tl.x * 16;
     auto a_ld = [=] __device__(int, int m, int k) { return ltg_ld4(dlog + (size_t)m * I + k); };
@@ -1253,8 +1258,8 @@ __global__ __launch_bounds__(NT) void fk_dh2(int B, int I, int H, const float* _
     auto epi = [=] __device__(int, int m, int n, float v, bool ok) {
         if (ok) da2[(size_t)m * H + n] = v * (1.f - t * t);
     };
-    if constexpr (BF) ltg_rgemm<1, 1, 1, 1, 4, 8, true>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
-    else ltg_rgemm<1, 1, 1, 1, 4, 16>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
+    if constexpr (BF) ltg_rgemm<1, 1, 1, 1, 8, 4, true>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);      // (4 blocks of 32 per slice: I <= 1 024 in one pass)
+    else ltg_rgemm<1, 1, 1, 1, 8, 8>(B, H, I, m0, n0, a_ld, xf, b_ld, xf, epi, lds);
 }
 
 // "weight gradient + Adam" tile: G[m][n] = sum_k Lm(k, m) * Rm(k, n) over the K batch rows, fused with the TF-Adam update

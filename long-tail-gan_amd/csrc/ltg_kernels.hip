@@ -3280,7 +3280,7 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
         // A3, G3 (backward only) and the per-tile partial dot products of the output unit; y only when nothing else follows
         LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
                                                       d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
-        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk_d_l2, dim3(((h3 + 31) / 32) * ((n + 31) / 32)), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
+        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk_d_l2, dim3(((h3 + 31) / 32) * ((n + 31) / 32)), dim3(DL2_NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
                                                       cfg->seed, step, w.A3, with_bwd ? w.G3 : (float*)nullptr, w.spart));
         if (!with_bwd) hipLaunchKernelGGL(fk_d_y, dim3((n + NT - 1) / NT), dim3(NT), 0, st, pv, (h3 + 31) / 32, w.spart, d->p[7], w.y);
         return;
@@ -3952,8 +3952,8 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
                                                              acts->kl_rows, w.y, nf, o->cnt, o->gan_lambda, fake->row, fake->niche, fake->pop, w.dlog,
                                                              acts->lse, w.rowout));
         pr.before(LTG_K_DH2);
-        if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_dh2<true>, grid2(H, B, 16, 16), dim3(NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
-        else hipLaunchKernelGGL(fk_dh2<false>, grid2(H, B, 16, 16), dim3(NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
+        if (cfg->precision == LTG_PREC_BF16) hipLaunchKernelGGL(fk_dh2<true>, grid2(H, B, 16, 16), dim3(DH2_NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
+        else hipLaunchKernelGGL(fk_dh2<false>, grid2(H, B, 16, 16), dim3(DH2_NT), 0, st, B, I, H, w.dlog, gen->p[3], acts->h2, w.da2);
         pr.after(LTG_K_DH2);
         g_chain(cfg, gen, bt, o, acts, w, make_adam(cfg, o->adam_t), nullptr, true, loss_out, st);
         return check_launch();

@@ -198,7 +198,7 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
 template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
                                                        MID mid = MID()) {
-    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+    static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per workgroup");
     typedef LtgRg<TM, TN, WM, WN, WK> G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -305,9 +305,10 @@ __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, A
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
     constexpr int NTH = 64 * WM * WN * WK;      // threads of the workgroup (256, or 512 with eight K slices)
-    static_assert(NE % NTH == 0, "tile must divide over the workgroup's threads");
+    static_assert(NE % NTH == 0 || (NE < NTH && NE % 64 == 0), "tile must divide over the workgroup's threads, or be finished by its first waves");
+    if (NE < NTH && tid >= NE) return;          // (wave-uniform: a 16 x 16 tile over eight K slices is finished by the first four waves)
 #pragma unroll
-    for (int e = 0; e < NE / NTH; ++e) {
+    for (int e = 0; e < (NE + NTH - 1) / NTH; ++e) {
         const int id = tid + NTH * e;
         const int mm = id / G::BN, nn = id % G::BN;
         float v = lds[mm * G::LDC + nn];
