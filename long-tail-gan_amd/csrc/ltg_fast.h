@@ -203,6 +203,7 @@ __device__ __forceinline__ void dz_tile(int B, int Z, int H, const float* __rest
         dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
         dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
     };
+    // (eight K slices, as in fk_enc1 / fk_dh2, measured here: G phase 66.29 -> 66.45 ms per epoch with fk_dh1 -- 20 requests per wave are no queue)
     ltg_rgemm<1, 1, 1, 1, 4, 10, false, false, 15>(B, Z, H, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
@@ -918,7 +919,10 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
 }
 
 // Backward stage 2: dw1 / db1 and dw2 / db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), 16 x 32 tiles.
-__global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
+// (round 5: eight K slices, 512 threads -- two 16-deep blocks of a 256-row chunk per wave: 8 ids + 24 operand requests instead of 16 + 48; see fk_enc1)
+constexpr int DB2_NT = 512;
+typedef LtgRg<1, 2, 1, 1, 8> Rg16x32k8b;
+__global__ __launch_bounds__(DB2_NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
                                                 const float* __restrict__ dpre1, float* __restrict__ slab, LtgGate end_wait = LTG_NO_GATE) {
     // end_wait (jobs B / C of stage 1 on the aux stream): the Adam sweep behind this kernel adds THEIR slab entries too -- one more block
     // at the end of the grid polls for their word
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
     if (pv.nr >= 0) return;
 #endif
     LTG_STAMP_AT(5, 0);
-    __shared__ __attribute__((aligned(16))) float lds[Rg16x32::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[Rg16x32k8b::LDS_FLOATS];
     const int n = pv.nr + pv.nf, h12 = h1 + h2;
     const int tm = (h0 + 1 + 15) / 16;
     const int tn1 = (h1 + 31) / 32, tn2 = (h2 + 31) / 32;
@@ -946,12 +950,13 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
     const int ow = L.off[br ? 2 : 0], ob = L.off[br ? 3 : 1];
     const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK), K = kend - kbeg;
     float* out = slab + (size_t)z * SP;
-    // phase 0: the pair ids of the 16 pair rows this lane multiplies (4 blocks x 4): their embedding rows are the dependent
+    // phase 0: the pair ids of the 8 pair rows this lane multiplies (2 blocks x 4): their embedding rows are the dependent
     // second round trip
-    int ids[4][4];
+    constexpr int DB2_NB = D_KCHUNK / 16 / 8;      // 16-deep blocks per K slice
+    int ids[DB2_NB][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kc = Rg16x32::kc(K, i);
+    for (int i = 0; i < DB2_NB; ++i) {
+        const int kc = Rg16x32k8b::kc(K, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = kbeg + min(kc + j, K - 1);
@@ -982,7 +987,7 @@ __global__ __launch_bounds__(NT) void fk_d_bwd2(PairView pv, int h0, int h1, int
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    ltg_rgemm<1, 2, 1, 1, 4, 4, false, true, 5>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 8, DB2_NB, false, true, 5>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // (Measured and not kept, round 3: this sweep FUSED into fk_d_bwd2 -- every workgroup releases its slab tile with a device-scope fence

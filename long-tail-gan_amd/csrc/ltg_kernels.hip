@@ -3450,7 +3450,7 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
             hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, ax, LtgGate{o->sync + 1, o->seq, nullptr, 0}, LTG_NO_GATE);
         }
         const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2 + (fork ? 1 : 0)), dim3(NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab,
+        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2 + (fork ? 1 : 0)), dim3(DB2_NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab,
                                                         fork ? LtgGate{o->sync + 1, o->seq, o->sync + 2, 0} : LTG_NO_GATE));
         if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
         else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st, poison);
