@@ -565,71 +565,78 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        tr.epoch()
-    # ---- live per-kernel timing (HIP events recorded by the library around ONE kernel per call)
-    prof = KernelProfiler(eng, tr, data, a)
-    if a.no_probe:
-        calib, dominant = None, None
-    elif mode == "item-shard":
-        calib, dominant = None, "dec1_bwd_adam"        # monolithic probe steps would desynchronise the shards
-    else:
-        calib = prof.calibrate() if rank == 0 else None
-        dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
-    one_call = getattr(tr, "pipe", None) is not None and getattr(tr, "comm", None) is not None
-    exch = ("exch_h1", "exch_rowpart", "exch_dh2") if (mode == "item-shard" and one_call) else ()
-    tr.probe_hook = prof.hook(dominant, exch) if (dominant and rank == 0) else None
-    if tr.probe_hook:
-        prof.reserve(min(2048, a.steps * a.sub_epochs * data.n_batches // 32 + 1))
-    # who really runs this job: one line per rank (device identity as the runtime reports it), world size as RCCL reports it
-    ranks_info = None
-    if dist.is_initialized():
-        pr_ = torch.cuda.get_device_properties(local)
-        me = {"rank": rank, "local_rank": local, "pid": os.getpid(), "gpu_uuid": str(getattr(pr_, "uuid", "")), "gpu": pr_.name,
-              "pci_bus_id": getattr(pr_, "pci_bus_id", None), "cus": pr_.multi_processor_count}
-        ranks_info = [None] * world
-        dist.all_gather_object(ranks_info, me)
-    barrier()
-    t0 = time.perf_counter()
-    phases = []
-    for _ in range(a.steps):
-        phases.append(tr.epoch())
-    barrier()
-    dt = time.perf_counter() - t0
-    tr.probe_hook = None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    replicas = mode == "replicas" and world > 1
-    data_users = data.N
-    users = data.N * a.steps * (world if replicas else 1)   # replicas: every rank processes the full workload
-    value = users / dt
-    res = {
-        "metric": "train users/sec at BATCH_SIZE=%d" % a.batch_size,
-        "value": value, "unit": "users/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
-        "dtype": a.precision, "data": desc,
-        "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
-                   "sub_epochs": a.sub_epochs, "batch_size": a.batch_size, "warm_moments": bool(a.warm),
-                   "backend": ("%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "test rig: ranks share GPUs")) if dist.is_initialized() else "none",
-                   "backend_choice": backend_note if dist.is_initialized() else None,
-                   "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step %s)" %
-                                   (world, "pair rows split + gradient all-reduce" if getattr(tr, "d_split", False) else "replicated"))
-                   if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
-        "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
-    }
-    if mode == "item-shard":
-        comm = getattr(tr, "comm", None)
-        res["sharded_step"] = {
-            "one_call": bool(one_call),                          # ltg_g_step_sharded: every launch and the three exchanges from one C call
-            "handover": getattr(getattr(tr, "pipe", None), "handover", None),   # fork / join of the weight update: "device-words" | "events"
-            "pipe": pipe_facts(getattr(tr, "pipe", None)),
-            "transport": getattr(comm, "kind", "torch.distributed (%s), step cut at its exchange points" % backend),
-            "rccl_ranks": getattr(comm, "count", None) if getattr(comm, "kind", "") == "rccl-direct" else None,   # ncclCommCount
-            "ranks": ranks_info,
-            "distinct_gpus": len({r["gpu_uuid"] or r["pci_bus_id"] or r["local_rank"] for r in ranks_info}) if ranks_info else 1,
+    # (an exception between here and close() must not leave this rank's RCCL communicator alive while its peers sit in an in-stream collective:
+    # give it up without waiting -- ShardedTrainer.abort = ncclCommAbort -- and re-raise)
+    try:
+        for _ in range(a.warmup):
+            tr.epoch()
+        # ---- live per-kernel timing (HIP events recorded by the library around ONE kernel per call)
+        prof = KernelProfiler(eng, tr, data, a)
+        if a.no_probe:
+            calib, dominant = None, None
+        elif mode == "item-shard":
+            calib, dominant = None, "dec1_bwd_adam"        # monolithic probe steps would desynchronise the shards
+        else:
+            calib = prof.calibrate() if rank == 0 else None
+            dominant = max(calib, key=lambda k: calib[k]["epoch_ms"]) if calib else None
+        one_call = getattr(tr, "pipe", None) is not None and getattr(tr, "comm", None) is not None
+        exch = ("exch_h1", "exch_rowpart", "exch_dh2") if (mode == "item-shard" and one_call) else ()
+        tr.probe_hook = prof.hook(dominant, exch) if (dominant and rank == 0) else None
+        if tr.probe_hook:
+            prof.reserve(min(2048, a.steps * a.sub_epochs * data.n_batches // 32 + 1))
+        # who really runs this job: one line per rank (device identity as the runtime reports it), world size as RCCL reports it
+        ranks_info = None
+        if dist.is_initialized():
+            pr_ = torch.cuda.get_device_properties(local)
+            me = {"rank": rank, "local_rank": local, "pid": os.getpid(), "gpu_uuid": str(getattr(pr_, "uuid", "")), "gpu": pr_.name,
+                  "pci_bus_id": getattr(pr_, "pci_bus_id", None), "cus": pr_.multi_processor_count}
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, me)
+        barrier()
+        t0 = time.perf_counter()
+        phases = []
+        for _ in range(a.steps):
+            phases.append(tr.epoch())
+        barrier()
+        dt = time.perf_counter() - t0
+        tr.probe_hook = None
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        replicas = mode == "replicas" and world > 1
+        data_users = data.N
+        users = data.N * a.steps * (world if replicas else 1)   # replicas: every rank processes the full workload
+        value = users / dt
+        res = {
+            "metric": "train users/sec at BATCH_SIZE=%d" % a.batch_size,
+            "value": value, "unit": "users/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
+            "dtype": a.precision, "data": desc,
+            "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
+                       "sub_epochs": a.sub_epochs, "batch_size": a.batch_size, "warm_moments": bool(a.warm),
+                       "backend": ("%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "test rig: ranks share GPUs")) if dist.is_initialized() else "none",
+                       "backend_choice": backend_note if dist.is_initialized() else None,
+                       "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step %s)" %
+                                       (world, "pair rows split + gradient all-reduce" if getattr(tr, "d_split", False) else "replicated"))
+                       if mode == "item-shard" else ("replicas x%d" % world if replicas else "single GPU")},
+            "phases_ms": {k: float(np.median([p[k] for p in phases]) * 1e3) for k in ("t_create", "t_d", "t_g")},
         }
+        if mode == "item-shard":
+            comm = getattr(tr, "comm", None)
+            res["sharded_step"] = {
+                "one_call": bool(one_call),                          # ltg_g_step_sharded: every launch and the three exchanges from one C call
+                "handover": getattr(getattr(tr, "pipe", None), "handover", None),   # fork / join of the weight update: "device-words" | "events"
+                "pipe": pipe_facts(getattr(tr, "pipe", None)),
+                "transport": getattr(comm, "kind", "torch.distributed (%s), step cut at its exchange points" % backend),
+                "rccl_ranks": getattr(comm, "count", None) if getattr(comm, "kind", "") == "rccl-direct" else None,   # ncclCommCount
+                "ranks": ranks_info,
+                "distinct_gpus": len({r["gpu_uuid"] or r["pci_bus_id"] or r["local_rank"] for r in ranks_info}) if ranks_info else 1,
+            }
+    except BaseException:
+        if hasattr(tr, "abort"):
+            tr.abort()
+        raise
     if dist.is_initialized():
         if hasattr(tr, "close"):
             tr.close()                  # the step's own RCCL communicator (ncclCommDestroy) before the group it was created over goes

@@ -128,6 +128,14 @@ class RcclComm:
             self.comm = C.c_void_p()
 
 
+    def abort(self):
+        """ncclCommAbort: does NOT wait for outstanding operations -- the exception path of one rank (ShardedTrainer.__exit__ with an error), so
+        that its peers' in-stream collectives fail promptly and do not sit in RCCL's timeout"""
+        if self.comm:
+            self.lib.ncclCommAbort(self.comm)
+            self.comm = C.c_void_p()
+
+
 class HostComm:
     """ltg_comm whose entry points are host functions over the torch.distributed group (any backend).  `buffers`: the device
     tensors the library will hand in (looked up by address; the functions receive raw pointers)."""
@@ -181,4 +189,7 @@ class HostComm:
             return 2
 
     def close(self):
+        pass
+
+    def abort(self):
         pass

@@ -1011,11 +1011,15 @@ __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const flo
     // Workgroup 0 (dispatched first) does the ragged tail and d_loss and nothing else; the sweep belongs to workgroups 1 .. gridDim.x - 1.
     // (Round 5: as the epilogue of workgroup 0's share of the sweep, these two serial walks were a second and a third chain of round trips
     // that the whole launch waited for.)
+    // (The one launch site passes gridDim.x = sweep workgroups + 1.  A grid of ONE workgroup would leave nobody for the sweep: it then does the
+    // sweep itself behind its side job -- uniform per launch, never taken by the library's own launch.)
+    const bool alone = gridDim.x == 1;
     if (blockIdx.x == 0) {
         const int e = 4 * P4 + threadIdx.x;
         const bool tail = e < P, lossl = threadIdx.x == NT - 1;      // (the loss on another wave than the tail elements)
         const int col = tail ? e : P;
-        if (!tail && !lossl) return;
+        if (!tail && !lossl && !alone) return;
+        if (tail || lossl) {
         float pe = 0.f, me = 0.f, ve = 0.f;
         if (tail) { pe = p[e]; me = m[e]; ve = v[e]; }
         float t = 0.f;
@@ -1034,10 +1038,11 @@ __global__ __launch_bounds__(NT) void fk_d_adam(int ks, int P, int SP, const flo
             adam1(pe, me, ve, t, ad.lr_t, ad);
             p[e] = pe; m[e] = me; v[e] = ve;
         } else loss_out[0] = t;
-        return;
+        }
+        if (!alone) return;
     }
-    const int nb = gridDim.x - 1;
-    for (int e = (blockIdx.x - 1) * NT + threadIdx.x; e < P4; e += nb * NT) {
+    const int nb = alone ? 1 : gridDim.x - 1, b0 = alone ? 0 : blockIdx.x - 1;
+    for (int e = b0 * NT + threadIdx.x; e < P4; e += nb * NT) {
         // (round 5: theta / m / v and the first eight slabs requested together, the slabs added in ascending order as before -- the plain
         // loop over a runtime slab count made every slab a round trip of its own: eight of them in a 5.7-us launch)
         ltg_f32x4 pp = ltg_ld4(p + 4 * e), mm = ltg_ld4(m + 4 * e), vv = ltg_ld4(v + 4 * e);

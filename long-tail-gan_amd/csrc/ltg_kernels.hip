@@ -128,14 +128,18 @@ __device__ __forceinline__ void ltg_gate_wait_tail(LtgGate g) {
 // word 2 of ltg_pipe.sync: a device-side wait of this pipe has given up -- nothing that follows may touch the model
 // (round 5: a PLAIN load -- the scalar unit's, see ltg_poison_word below for why that is enough -- instead of an agent-scope atomic one: the
 // guard is the first statement of its kernels, and as a vector load it was a ~1-us round trip in front of every other request)
-__device__ __forceinline__ bool ltg_poisoned(const unsigned* __restrict__ p) { return p && *p != 0u; }
+// (round 6: the pointer is NOT __restrict__ -- waiters on other streams atomicAdd this word while the kernel runs, so a noalias promise would be
+// false.  The guarantee is stated as what it is: a kernel sees every expiry that happened before it STARTED (its dispatch acquires); an expiry
+// DURING the kernel is seen from the next kernel boundary on.  That is all the design needs: the wait that gates a kernel sits in front of it
+// on its own stream.)
+__device__ __forceinline__ bool ltg_poisoned(const unsigned* p) { return p && *p != 0u; }
 // The word itself, for kernels that REQUEST it first and look at it in front of their first store (round 5): `if (ltg_poisoned(p)) return;`
 // as a kernel's first statement is a vector-memory round trip of its own in front of every other request.  A PLAIN load of a uniform address
 // before the kernel's first store: the compiler issues it on the SCALAR unit (s_load_dword, beside the kernel-argument loads), so nothing in
 // the vector-memory queue waits for it.  Plain is enough here: every poisoner is a wait that sits IN FRONT of the reading kernel on its own
 // stream (a kernel's end releases, a kernel's start acquires); a wait on another stream that gives up while this kernel runs is seen by the
 // next kernel, as with the atomic load.
-__device__ __forceinline__ unsigned ltg_poison_word(const unsigned* __restrict__ p) { return p ? *p : 0u; }
+__device__ __forceinline__ unsigned ltg_poison_word(const unsigned* p) { return p ? *p : 0u; }
 __device__ __forceinline__ bool ltg_word_set(unsigned w) { return w != 0u; }
 // by ONE thread.  Every producer in this library is a WHOLE KERNEL that ended in front of the kernel that stores the word (the store
 // is the first thing a kernel does when it starts, or a one-wave kernel of its own behind the producer), and the end of a kernel is
@@ -603,7 +607,8 @@ __global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H,
     int t = w * G + (int)blockIdx.x;
     const bool any = t < ntiles;
     const ltg_gchar* Wg = ltg_uniform_ptr(Wb);
-    ltg_gchar* Lg = ltg_uniform_ptr(logits);      // (32-bit byte offsets: the host sends launches of 2^30 logits or more to the first form)
+    ltg_gchar* Lg = ltg_uniform_ptr(logits);      // (32-bit byte offsets into BOTH: the host sends launches of 2^30 logits or more, or of slabs whose shadow
+                                                  // is 2^32 bytes or more -- I >= 3 532 111 --, to the first form: launch_dec1_fwd_stream)
     // byte offset of this lane's A-fragment row in the shadow: item row (tile, sub-tile s, lr), chunk lq of the K step (the K step's
     // 64 B are added as an immediate).  Items past the end mirror the slab's last four (I % 4 == 0: a lane's four output items are all
     // inside or all outside): the product of a mirrored row group is the last group's, and it is stored to the last group's address.
@@ -3122,7 +3127,10 @@ int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int 
     // the second form for the HBM-bound slabs (see k_dec1_fwd_stream2); tuning-knob bit 26: the first form at every size, bit 17: the second
     // form from 8 192 items (A/B measurements)
     const int st2_min = (cfg->reserved0 & (1 << 17)) ? 8192 : ST2_MIN_ITEMS;
-    if ((cfg->reserved0 & (1 << 26)) == 0 && I >= st2_min && (size_t)R * (size_t)I < ((size_t)1 << 30)) {
+    // (the second form addresses the logits AND the shadow rows with 32-bit byte offsets from a uniform base: R * I * 4 and I * ST_KP * 2 must both
+    // stay below 2^32 -- 3 532 110 items of one slab for the shadow; beyond either limit the first form, which has none)
+    if ((cfg->reserved0 & (1 << 26)) == 0 && I >= st2_min && (size_t)R * (size_t)I < ((size_t)1 << 30) &&
+        (size_t)I * (size_t)(ST_KP * 2) < ((size_t)1 << 32)) {
         const int nt2 = (I + 31) / 32, G2 = nt2 < 256 ? nt2 : 256;
 #define LTG_ST2(STATS, NTB) hipLaunchKernelGGL((k_dec1_fwd_stream2<STATS, NTB>), dim3(G2), dim3(ST_NT), (size_t)ST_KS * NTB * 64 * 16, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat)
         if (stat) { if (R <= 112) LTG_ST2(true, 7); else LTG_ST2(true, 8); }

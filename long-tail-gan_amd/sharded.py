@@ -111,6 +111,24 @@ class ShardedTrainer(Trainer):
             self.comm.close()
             self.comm = None
 
+    def abort(self):
+        """the exception path: give up the communicator without waiting for what is in flight on it (ncclCommAbort), no device synchronisation"""
+        if self.comm is not None:
+            self.comm.abort()
+            self.comm = None
+
+    # `with ShardedTrainer(...) as tr:` -- close() on the way out, abort() when an exception is passing through (a blocking destroy on ONE
+    # rank's error path would leave that rank in ncclCommDestroy and its peers in an in-stream collective until RCCL's timeout)
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        else:
+            self.abort()
+        return False
+
     # -- collectives -------------------------------------------------------------------------------
     def _allreduce(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

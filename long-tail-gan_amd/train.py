@@ -166,32 +166,37 @@ def train_GAN(h0_size, h1_size, h2_size, h3_size, NUM_EPOCH, NUM_SUB_EPOCHS, BAT
     else:
         tr = Trainer(eng, data, **kw)
         ev = Evaluator(eng, EvalData(vtr, vte, eng.device))
-    start = 0
-    if to_restore:
-        ck = sorted(glob.glob(os.path.join(output_path, "model_*.pt")), key=lambda p: int(p.split("_")[-1][:-3]))
-        if ck:
-            start = load_checkpoint(ck[-1], eng, tr) + 1
-            print("Restored", ck[-1])
-    last = None
-    for i in range(start, NUM_EPOCH if max_epochs is None else min(NUM_EPOCH, start + max_epochs)):
-        err = tr.create_phase()
-        print("global-epoch:", i, "Data Creation Finished", "user_err_cnt:", err)
-        dl = tr.d_phase().cpu().numpy()
-        for j in range(NUM_SUB_EPOCHS):
-            print("global-epoch:%s, discr-epoch:%s, d_loss:%.5f" % (i, j, dl[j, 0]))
-        print("")
-        gl = tr.g_phase().cpu().numpy()
-        for j in range(NUM_SUB_EPOCHS):
-            print("global-epoch:%s, generator-epoch:%s, g_loss:%.5f (vae_loss: %.5f + gan_loss: %.5f, anneal: %.5f)" %
-                  (i, j, gl[j, 0], gl[j, 1], gl[j, 2], tr.last_anneal[j]))
-        print("")
-        m = ev.run(rng_step=10 ** 9 + i)
-        print("global-epoch:", i, "gen-epoch:", NUM_SUB_EPOCHS - 1, "Vad: NDCG:", m["ndcg"], "Recall@20:", m["recall20"], "Recall@50:",
-              m["recall50"], "Num_users:", m["n_users"], m["n_users"], m["n_users"])
-        print("")
-        save_checkpoint(os.path.join(output_path, "model_%d.pt" % i), eng, tr, i, rank, world)
-        print("Model saved at global-epoch", i)
-        last = m
+    try:
+        start = 0
+        if to_restore:
+            ck = sorted(glob.glob(os.path.join(output_path, "model_*.pt")), key=lambda p: int(p.split("_")[-1][:-3]))
+            if ck:
+                start = load_checkpoint(ck[-1], eng, tr) + 1
+                print("Restored", ck[-1])
+        last = None
+        for i in range(start, NUM_EPOCH if max_epochs is None else min(NUM_EPOCH, start + max_epochs)):
+            err = tr.create_phase()
+            print("global-epoch:", i, "Data Creation Finished", "user_err_cnt:", err)
+            dl = tr.d_phase().cpu().numpy()
+            for j in range(NUM_SUB_EPOCHS):
+                print("global-epoch:%s, discr-epoch:%s, d_loss:%.5f" % (i, j, dl[j, 0]))
+            print("")
+            gl = tr.g_phase().cpu().numpy()
+            for j in range(NUM_SUB_EPOCHS):
+                print("global-epoch:%s, generator-epoch:%s, g_loss:%.5f (vae_loss: %.5f + gan_loss: %.5f, anneal: %.5f)" %
+                      (i, j, gl[j, 0], gl[j, 1], gl[j, 2], tr.last_anneal[j]))
+            print("")
+            m = ev.run(rng_step=10 ** 9 + i)
+            print("global-epoch:", i, "gen-epoch:", NUM_SUB_EPOCHS - 1, "Vad: NDCG:", m["ndcg"], "Recall@20:", m["recall20"], "Recall@50:",
+                  m["recall50"], "Num_users:", m["n_users"], m["n_users"], m["n_users"])
+            print("")
+            save_checkpoint(os.path.join(output_path, "model_%d.pt" % i), eng, tr, i, rank, world)
+            print("Model saved at global-epoch", i)
+            last = m
+    except BaseException:
+        if hasattr(tr, "abort"):      # one rank's error path: ncclCommAbort, not the blocking destroy (its peers would wait in a collective)
+            tr.abort()
+        raise
     if world > 1:
         import torch.distributed as dist
         if hasattr(tr, "close"):

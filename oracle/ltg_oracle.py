@@ -224,9 +224,12 @@ def d_tower(D, pop_ids, niche_ids, masks, keep, dtype=np.float64, dq=None):
     return dict(ea=ea, eb=eb, tA=tA, tB=tB, hin=hin, tC=tC, aC=aC, s=s[:, 0], y=y[:, 0])
 
 
-def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64, dq=None):
+def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64, dq=None, dact16=True):
     """gradients of sum(ds * s) wrt the 8 trainable tensors (emb is frozen: discriminator.py:47).  dq as in d_tower:
-    the bias gradients of the quantised GEMMs are column sums of the QUANTISED operand (ones-augmented row)."""
+    the bias gradients of the quantised GEMMs are column sums of the QUANTISED operand (ones-augmented row).
+    dact16 (fp8 mode only): round d a / d pre of the branch layers to bf16 as the device stores it (dA1T_16).  False = the same
+    pipeline WITHOUT that storage rounding: the independent variant tests pin the approximation's cost against
+    (tests/test_gpu_parity.py::test_d_step_precision_modes)."""
     f = lambda a: np.asarray(a, dtype=dtype)
     mA, mB, mC = (f(m) for m in masks)
     ds = f(ds)[:, None]
@@ -243,7 +246,7 @@ def d_tower_backward(D, T, masks, keep, ds, dtype=np.float64, dq=None):
     dhin = qC @ _dq(f(D["w3"]), dq, "w").T
     h1 = mA.shape[1]
     fA, fB = mA / dtype(keep) * (1 - T["tA"] ** 2), mB / dtype(keep) * (1 - T["tB"] ** 2)
-    if dq == "fp8":     # the fp8 mode keeps d a / d pre of the branch layers as bf16 (csrc/ltg_fp8bwd.h: dA1T_16), not an fp32 copy of a
+    if dq == "fp8" and dact16:     # the fp8 mode keeps d a / d pre of the branch layers as bf16 (csrc/ltg_fp8bwd.h: dA1T_16), not an fp32 copy of a
         fA, fB = bf16_round(fA.astype(np.float32)).astype(dtype), bf16_round(fB.astype(np.float32)).astype(dtype)
     dpA = dhin[:, :h1] * fA
     dpB = dhin[:, h1:] * fB
