@@ -44,9 +44,12 @@ def parse():
                     help="discriminator h0,h1,h2,h3 (config.ini defaults; BASELINE config 5 = 2048,1024,512,256)")
     ap.add_argument("--d-precision", default="fp32", choices=["fp32", "bf16", "fp8"],
                     help="operand precision of the discriminator GEMMs (fp32 = the reference's arithmetic)")
+    ap.add_argument("--d-arith", default=None, choices=["fp32", "bf16x6", "bf16x4"],
+                    help="how the fp32 discriminator's products are formed (ltg_config.d_arith): exact fp32 MFMA, the fp32-accurate six-term bf16 split, "
+                         "or the four-term split (opt-in, 2^-17 per product); default: the engine's (D_ARITH_DEFAULT)")
     ap.add_argument("--d-split", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: split the discriminator's pair rows over the ranks + gradient all-reduce (auto: when the discriminator has >= 1 M parameters)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.reserved0)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel tuning knob (ltg_config.tuning)")
     ap.add_argument("--warm-moments", action="store_true", help="(the default for the synthetic workloads) give every row of W_q0 non-zero Adam moments "
                     "before timing: the state of the 136 000- / 1 000 000-user configurations, where every item has been seen -- the lazy clock "
                     "then has its full deferred arithmetic to do")
@@ -454,8 +457,8 @@ def other_workloads(a, device, users=6400, copy_gbs=None):
     out = {}
     for key, name in (("c3", "ml20m"), ("c4", "c4")):
         idx, data, desc = load_workload(name, a.batch_size, device, users)
-        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
-        eng.cfg.reserved0 = a.variant
+        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, d_arith=a.d_arith, device=device)
+        eng.cfg.tuning = a.variant
         warm = not a.cold_moments      # configs 3 / 4 are 136 000 / 1 000 000 users: every row of W_q0 carries moments there
         if warm:
             warm_moments(eng)
@@ -533,7 +536,7 @@ def main():
         from ltgan.sharded import ShardedTrainer, item_slab
         if world > 1 and rank == 0:
             # same workload on ONE GPU, measured in this very job (the other ranks wait): the strong-scaling reference
-            e1 = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
+            e1 = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, d_arith=a.d_arith, device=device)
             if a.warm:
                 warm_moments(e1)
             t1 = Trainer(e1, data, num_sub_epochs=a.sub_epochs)
@@ -547,14 +550,14 @@ def main():
             torch.cuda.empty_cache()
         lo, hi = item_slab(idx.n_items, rank, world)
         data = DeviceData(idx, a.batch_size, device, item_lo=lo, item_hi=hi)
-        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device, item_lo=lo, item_hi=hi)
-        eng.cfg.reserved0 = a.variant
+        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, d_arith=a.d_arith, device=device, item_lo=lo, item_hi=hi)
+        eng.cfg.tuning = a.variant
         if a.warm:
             warm_moments(eng)
         tr = ShardedTrainer(eng, data, num_sub_epochs=a.sub_epochs, d_split={"auto": None, "on": True, "off": False}[a.d_split])
     else:
-        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, device=device)
-        eng.cfg.reserved0 = a.variant
+        eng = Engine(idx.n_items, h_sizes=a.h_sizes, precision=a.precision, d_precision=a.d_precision, d_arith=a.d_arith, device=device)
+        eng.cfg.tuning = a.variant
         if a.warm:
             warm_moments(eng)
         tr = Trainer(eng, data, num_sub_epochs=a.sub_epochs)
@@ -615,6 +618,7 @@ def main():
             "dtype": a.precision, "data": desc,
             "config": {"workload": a.workload, "users": data.N, "items": data.I, "batches": data.n_batches,
                        "sub_epochs": a.sub_epochs, "batch_size": a.batch_size, "warm_moments": bool(a.warm),
+                       "d_arith": eng.d_arith if a.d_precision == "fp32" else a.d_precision,
                        "backend": ("%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "test rig: ranks share GPUs")) if dist.is_initialized() else "none",
                        "backend_choice": backend_note if dist.is_initialized() else None,
                        "parallelism": ("item-shard x%d (RCCL: 2 all-reduce [B,600] + 1 all-gather [B,5] per G step; D step %s)" %

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTG_ABI_VERSION 13
+#define LTG_ABI_VERSION 14
 
 #define LTG_OK 0
 #define LTG_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dims) */
@@ -42,6 +42,10 @@ extern "C" {
 #define LTG_PREC_BF16 0 /* decoder GEMM operands rounded to bf16, fp32 accumulate (MFMA 16x16x32 bf16) */
 #define LTG_PREC_FP32 1 /* exact fp32 MFMA (16x16x4 f32) everywhere */
 #define LTG_PREC_FP8 2  /* d_precision only: OCP e4m3 operands, static power-of-two scales, fp32 accumulate (16x16x32 fp8) */
+
+#define LTG_DARITH_FP32 0   /* ltg_config.d_arith: exact fp32 MFMA (16x16x4 f32) */
+#define LTG_DARITH_BF16X6 1 /* three-way bf16 split of every fp32 operand, six cross terms on the bf16 matrix pipe: fp32-accurate */
+#define LTG_DARITH_BF16X4 2 /* two-way split, four cross terms: 2^-17 per product, opt-in */
 
 typedef void* ltg_stream; /* hipStream_t */
 
@@ -64,7 +68,7 @@ typedef struct ltg_config {
      *   bit 23 register-resident forward-only towers; bit 25 sparse gradient and Adam as two launches; bits 27-30 = k: the streaming
      *   weight update with 256 - 8 k workgroups; bit 26 / 17: the streaming decoder forward's first form at every size / its second form
      *   (h2 resident in LDS, per-wave item tiles; default from 65 536 items) from 8 192 items */
-    int32_t reserved0;
+    int32_t tuning;
     /* item shard of this rank: it owns global items [item_lo, item_lo + n_items); n_items_global = 0 means
      * unsharded (n_items_global = n_items, item_lo = 0).  W_q0 / W_p1t / b_p1 and their Adam moments hold
      * only the local rows; CSR indices are local; fake-pair and candidate ids stay global. */
@@ -74,7 +78,13 @@ typedef struct ltg_config {
      * LTG_PREC_FP32 = the reference's arithmetic (default of the host layer), LTG_PREC_BF16, LTG_PREC_FP8
      * (BASELINE config 5).  Accumulation, activations, loss, Adam and the master weights are fp32 in every mode. */
     int32_t d_precision;
-    int32_t reserved1;
+    /* arithmetic of the fp32 discriminator's GEMMs (d_precision = LTG_PREC_FP32, config.ini-sized layers; discriminator.py:23-55, train.py:142-143,163):
+     * LTG_DARITH_FP32 = v_mfma_f32_16x16x4_f32, the exact fp32 fma chain; LTG_DARITH_BF16X6 = every fp32 operand split into three bf16 terms
+     * (x = hi + mid + lo exactly) and the six leading cross terms multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- leaves out
+     * 2^-26 |a b| per product, below fp32's own rounding of it; LTG_DARITH_BF16X4 = two terms per operand, four cross terms (2^-17 per product:
+     * NOT fp32-accurate, opt-in).  Bits 4-7 (measurements only): which of the step's four GEMM kernels take the split form (l1, l2, bwd1, bwd2;
+     * 0 = the library's choice). */
+    int32_t d_arith;
     float lr, beta1, beta2, adam_eps;
     uint64_t seed;
 } ltg_config;

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("LTG_HIP_LIB") or os.path.join(_HERE, "libltg_hip.so")
 LTG_PREC_BF16 = 0
 LTG_PREC_FP32 = 1
 LTG_PREC_FP8 = 2
-LTG_ABI_VERSION = 13
+LTG_DARITH_FP32, LTG_DARITH_BF16X6, LTG_DARITH_BF16X4 = 0, 1, 2    # ltg_config.d_arith
+LTG_ABI_VERSION = 14
 LTG_PLAN_AHEAD, LTG_PLAN_SHADOW = 1, 2
 LTG_Q0_HIST = 1024
 
@@ -26,8 +27,8 @@ vp = C.c_void_p
 class ltg_config(C.Structure):
     _fields_ = [("n_items", C.c_int32), ("h_enc", C.c_int32), ("z_dim", C.c_int32), ("d_feat", C.c_int32),
                 ("d_h0", C.c_int32), ("d_h1", C.c_int32), ("d_h2", C.c_int32), ("d_h3", C.c_int32),
-                ("precision", C.c_int32), ("reserved0", C.c_int32), ("item_lo", C.c_int32), ("n_items_global", C.c_int32),
-                ("d_precision", C.c_int32), ("reserved1", C.c_int32),
+                ("precision", C.c_int32), ("tuning", C.c_int32), ("item_lo", C.c_int32), ("n_items_global", C.c_int32),
+                ("d_precision", C.c_int32), ("d_arith", C.c_int32),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("seed", C.c_uint64)]
 

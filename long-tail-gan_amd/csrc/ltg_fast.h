@@ -659,6 +659,8 @@ __global__ __launch_bounds__(G0_NT) void fk_enc0_grad_rows(int B, int I, int H, 
 
 // branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular -> h1, 1 niche -> h2.  32 x 32 tiles, each wave
 // a 16 x 16 product over the whole K = h0 (7 blocks in flight).
+// SPL (all four GEMM kernels of the step): 0 = v_mfma_f32_16x16x4_f32, 6 / 4 = the bf16 cross terms of the split operands (ltg_rgemm.h; ltg_config.d_arith)
+template <int SPL>
 __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
                                               const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                               const float* __restrict__ b2, DropView dA, DropView dB, float keep, uint64_t seed,
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
         const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep) : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
         A1[(size_t)m * h12 + coff + nn] = kp ? t / keep : 0.f;
     };
-    ltg_rgemm<1, 1, 2, 2, 1, 7, false, true, 1>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 1, 2, 2, 1, 7, false, true, 1, SPL>(n, N, h0, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // fully connected layer + the output unit's dot product (discriminator.py:44-45, :54-55): A3 = dropout(tanh(A1 . w3 + b3));
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(NT) void fk_d_l1(PairView pv, int h0, int h1, int h
 // tile's share of A3[row] . w4 -- the consumers add the tiles up in a fixed order (no atomics: reproducible).
 // (round 5: eight K slices, 512 threads -- 35 instead of 70 requests and 56 instead of 112 MFMAs per wave; see fk_enc1)
 constexpr int DL2_NT = 512;
+template <int SPL>
 __global__ __launch_bounds__(DL2_NT) void fk_d_l2(int n, int h12, int h3, const float* __restrict__ A1, const float* __restrict__ w3,
                                               const float* __restrict__ b3, const float* __restrict__ w4, DropView dC, float keep,
                                               uint64_t seed, uint64_t step, float* __restrict__ A3, float* __restrict__ G3,
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(DL2_NT) void fk_d_l2(int n, int h12, int h3, const 
         for (int o = 16; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
         if ((threadIdx.x & 31) == 0 && m < n) spart[(size_t)tile * n + m] = pd;
     };
-    ltg_rgemm<2, 2, 1, 1, 8, 4, false, true, 2>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<2, 2, 1, 1, 8, 4, false, true, 2, SPL>(n, h3, h12, m0, n0, a_ld, LtgXfId(), b_ld, LtgXfId(), epi, lds);
 }
 
 // output unit from the tile partials (discriminator.py:45,55; train.py:142): y, d loss / d s, loss term of one pair row
@@ -767,10 +770,12 @@ __global__ __launch_bounds__(NT) void fk_d_y(PairView pv, int ntile, const float
 //   job B  slab[z] = A1^T . (ds G3) (+ ones row -> db3), split over row chunks [h12+1][h3]  32 x 32 tiles
 //   job C  slab[z]: dw4 = A3^T . ds, db4 = sum ds, and the chunk's share of d_loss (slot P of the slab)
 // Every job first rebuilds ds (and the loss terms) of the pair rows it touches from the tile partials of fk_d_l2.
+template <int SPL>
 __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int h3, int bid, int nB, int ntile, const DLayout& L, int SP,
                                                const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
                                                const float* __restrict__ spart, float b4v, float* __restrict__ slab, float* __restrict__ lds,
                                                float* __restrict__ s_ds, float* __restrict__ s_lr);
+template <int SPL>
 __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, int nA, int nB, int ntile, DLayout L, int SP,
                                                 const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
                                                 const float* __restrict__ spart, const float* __restrict__ b4p,
@@ -824,14 +829,15 @@ __global__ __launch_bounds__(NT) void fk_d_bwd1(PairView pv, int h12, int h3, in
         auto epi = [=] __device__(int e, int m, int nn, float v, bool ok) {
             if (ok) dpre1[(size_t)m * h12 + nn] = v * dact(a1v[e], keep);
         };
-        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA, false, true, 3>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NA, false, true, 3, SPL>(n, h12, h3, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds, mid);
         return;
     }
-    d_bwd1_jobs_bc(pv, h12, h3, bid - nA, nB, ntile, L, SP, A1, A3, G3, spart, b4v, slab, lds, s_ds, s_lr);
+    d_bwd1_jobs_bc<SPL>(pv, h12, h3, bid - nA, nB, ntile, L, SP, A1, A3, G3, spart, b4v, slab, lds, s_ds, s_lr);
 }
 
 // jobs B and C of backward stage 1 (see fk_d_bwd1) for block `bid` of nB + nC: they need the forward's outputs only, not dpre1 --
 // either kernel of the backward may carry them (d_step_impl: beside job A, or beside the embedding products of stage 2)
+template <int SPL>
 __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int h3, int bid, int nB, int ntile, const DLayout& L, int SP,
                                                const float* __restrict__ A1, const float* __restrict__ A3, const float* __restrict__ G3,
                                                const float* __restrict__ spart, float b4v, float* __restrict__ slab, float* __restrict__ lds,
@@ -891,7 +897,7 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
             if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
             else out[ob + nn] = g;
         };
-        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB, false, true, 4>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
+        ltg_rgemm<2, 2, 1, 1, 4, LTG_BWD1_NB, false, true, 4, SPL>(h12 + 1, h3, K, m0, n0, a_ld, a_xf, b_ld, b_xf, epi, lds, rows_to_lds);
         return;
     }
     bid -= nB;
@@ -922,6 +928,7 @@ __device__ __forceinline__ void d_bwd1_jobs_bc(const PairView& pv, int h12, int 
 // (round 5: eight K slices, 512 threads -- two 16-deep blocks of a 256-row chunk per wave: 8 ids + 24 operand requests instead of 16 + 48; see fk_enc1)
 constexpr int DB2_NT = 512;
 typedef LtgRg<1, 2, 1, 1, 8> Rg16x32k8b;
+template <int SPL>
 __global__ __launch_bounds__(DB2_NT) void fk_d_bwd2(PairView pv, int h0, int h1, int h2, DLayout L, int SP, const float* __restrict__ emb,
                                                 const float* __restrict__ dpre1, float* __restrict__ slab, LtgGate end_wait = LTG_NO_GATE) {
     // end_wait (jobs B / C of stage 1 on the aux stream): the Adam sweep behind this kernel adds THEIR slab entries too -- one more block
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(DB2_NT) void fk_d_bwd2(PairView pv, int h0, int h1,
         if (m < h0) out[ow + (size_t)m * N + nn] = g;
         else out[ob + nn] = g;
     };
-    ltg_rgemm<1, 2, 1, 1, 8, DB2_NB, false, true, 5>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
+    ltg_rgemm<1, 2, 1, 1, 8, DB2_NB, false, true, 5, SPL>(h0 + 1, N, K, m0, n0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);
 }
 
 // (Measured and not kept, round 3: this sweep FUSED into fk_d_bwd2 -- every workgroup releases its slab tile with a device-scope fence

@@ -2899,7 +2899,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // the streaming decoder kernels: bf16, large item slab, a training batch (<= 128 rows), H <= 608, 16-B aligned rows
 inline bool stream_ok(const ltg_config* cfg, const ltg_gen_state* gen, int rows) {
     return gen->wp1t_bf16 && cfg->precision == LTG_PREC_BF16 && cfg->n_items >= 8192 && (cfg->n_items % 8) == 0 && rows <= 128 && cfg->h_enc <= ST_KP &&
-           (cfg->h_enc % 4) == 0 && (cfg->reserved0 & 15) != 9;
+           (cfg->h_enc % 4) == 0 && (cfg->tuning & 15) != 9;
 }
 // k_dec1_bwd_adam_stream walks the 4 H/4 float4 a wave owns per tile as exactly ten 64-lane accesses
 inline bool dw_stream_ok(int H) { return (H % 4) == 0 && H > 576 && H <= 640; }
@@ -2940,11 +2940,31 @@ struct Workspace {
     uint8_t *A1T_8, *dpre3_8, *dpre3T_8, *dpre1T_8, *ET_8;
     unsigned short* dA1T_16;
     int np8;
+    float* wsp;         // the discriminator's weights split into bf16 terms in MFMA fragment order (ltg_tower.h), rebuilt by every forward-only tower
     size_t bytes;
 };
 // stride of one discriminator gradient slab: the P gradients + one slot for the chunk's loss sum, padded to whole float4
 inline int d_slab_stride(int P) { return (P + 1 + 3) & ~3; }
 
+// geometry of the one-kernel forward-only tower (ltg_tower.h)
+constexpr int FT_BM = 64, FT_NT = 512;
+constexpr int FT_KP1_MAX = 4;       // h0 <= 128: the gathered embedding rows of a wave stay in registers, split
+inline int ft_lda(int h12) { return ((h12 + 31) & ~31) + 4; }      // floats; = 4 mod 32: the 16 rows of a ds_read_b128 fragment read hit every bank once
+inline size_t ft_lds_bytes(int h12) { return ((size_t)FT_BM * ft_lda(h12) + 4 * FT_BM) * sizeof(float); }
+// fragment triples (3 KiB each) of the three split matrices
+inline size_t ft_wsp_triples(int h0, int h1, int h2, int h3) {
+    const size_t kp1 = (h0 + 31) / 32, kp3 = (h1 + h2 + 31) / 32;
+    return (size_t)((h1 + 15) / 16) * kp1 + (size_t)((h2 + 15) / 16) * kp1 + (size_t)((h3 + 15) / 16) * kp3;
+}
+inline size_t ft_wsp_bytes(int h0, int h1, int h2, int h3) { return ft_wsp_triples(h0, h1, h2, h3) * 3 * 1024; }
+// sizes the one-kernel forward-only tower (ltg_tower.h) serves: the latency path's fp32 discriminator with h0 <= 128 (a wave's gathered rows stay in
+// registers), h3 <= 320 (five 16-column tiles per wave column) and A1 [64][h1 + h2] within the LDS.  The choice depends on the layer sizes and
+// d_arith only, so the tower inside a step and the batched tower run the same kernel and produce the same bits.
+inline bool ft_wsp_capable(const ltg_config* c) {
+    return (c->tuning & 262144) == 0 && c->d_precision == LTG_PREC_FP32 && !(c->d_h0 >= 512 && c->d_h1 + c->d_h2 >= 512 && c->d_h3 >= 128) && c->d_h0 >= 4 &&
+           c->d_h0 <= 32 * FT_KP1_MAX && (c->d_h0 % 4) == 0 && c->d_h1 >= 1 && c->d_h2 >= 1 && c->d_h3 >= 1 && c->d_h3 <= 320 &&
+           ft_lds_bytes(c->d_h1 + c->d_h2) <= (size_t)160 * 1024;
+}
 Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) {
     Workspace w;
     size_t off = 0;
@@ -3003,6 +3023,7 @@ Workspace carve(const ltg_config* cfg, int max_rows, int max_pairs, char* base) 
         w.dpre1T_8 = take8(h12 * np);
         w.ET_8 = take8(2 * (h0 + 1) * np);
     }
+    w.wsp = take(ft_wsp_capable(cfg) ? ft_wsp_bytes(cfg->d_h0, cfg->d_h1, cfg->d_h2, cfg->d_h3) / sizeof(float) : 1);
     w.bytes = off;
     return w;
 }
@@ -3044,12 +3065,13 @@ inline dim3 grid2(int N, int M, int bn = 64, int bm = 64, int z = 1) { return di
 namespace {
 #include "ltg_fast.h"
 #include "ltg_fp8bwd.h"
+#include "ltg_tower.h"
 }
 namespace {
 
-// Which of the round-2 latency-path kernels (ltg_fast.h) apply.  Tuning-knob bit 18 of ltg_config.reserved0 switches all of
+// Which of the round-2 latency-path kernels (ltg_fast.h) apply.  Tuning-knob bit 18 of ltg_config.tuning switches all of
 // them off (the round-1 kernels compute the same function; kept for A/B measurements and as the path of unusual sizes).
-inline bool fast_on(const ltg_config* c) { return (c->reserved0 & 262144) == 0; }
+inline bool fast_on(const ltg_config* c) { return (c->tuning & 262144) == 0; }
 inline bool mid_fast(const ltg_config* c, int rows) { return fast_on(c) && (c->z_dim % 4) == 0 && rows <= 256; }
 inline bool d_wide(const ltg_config* c) { return c->d_h0 >= 512 && c->d_h1 + c->d_h2 >= 512 && c->d_h3 >= 128; }
 // fp8 discriminator with EVERY GEMM operand in operand format (ltg_fp8bwd.h).  Tuning-knob bit 24 (register-resident forward
@@ -3057,11 +3079,28 @@ inline bool d_wide(const ltg_config* c) { return c->d_h0 >= 512 && c->d_h1 + c->
 inline bool d_fp8_opfmt(const ltg_config* c, const ltg_disc_state* d) {
     return fast_on(c) && c->d_precision == LTG_PREC_FP8 && d->emb_fp8 && d->w1t_fp8 && d->w2t_fp8 && d->w3t_fp8 && d->w3_fp8 && (c->d_h0 % 128) == 0 &&
            ((c->d_h1 + c->d_h2) % 128) == 0 && (c->d_h3 % 128) == 0 && (c->d_h1 % 64) == 0 && (c->d_h2 % 64) == 0 && c->d_h3 <= 64 * D8_OUT_CM &&
-           (c->reserved0 & ((1 << 24) | (1 << 19))) == 0;
+           (c->tuning & ((1 << 24) | (1 << 19))) == 0;
 }
 inline bool d_fast(const ltg_config* c) {
     return fast_on(c) && c->d_precision == LTG_PREC_FP32 && !d_wide(c) && c->d_h3 <= 512 && (c->d_h0 % 4) == 0 && ((c->d_h1 + c->d_h2) % 4) == 0 && (c->d_h3 % 4) == 0;
 }
+// ltg_config.d_arith: SPL of kernel `which` (0 fk_d_l1, 1 fk_d_l2, 2 fk_d_bwd1, 3 fk_d_bwd2) of the config.ini-sized fp32 discriminator step --
+// 0 = v_mfma_f32_16x16x4_f32, 6 / 4 = bf16 cross terms of the split operands (ltg_rgemm.h).  Bits 4-7 choose the kernels (measurements);
+// 0 = the library's set LTG_D_SPLIT_SET.
+#ifndef LTG_D_SPLIT_SET
+#define LTG_D_SPLIT_SET 0xE      // l2, bwd1, bwd2 (l1: one 16 x 16 output per wave -- the split's 36 vector instructions per block buy 4 MFMAs of 32 cycles)
+#endif
+inline int d_spl(const ltg_config* c, int which) {
+    const int mode = c->d_arith & 3, set = ((c->d_arith >> 4) & 15) ? ((c->d_arith >> 4) & 15) : LTG_D_SPLIT_SET;
+    if (mode == LTG_DARITH_FP32 || !((set >> which) & 1)) return 0;
+    return mode == LTG_DARITH_BF16X4 ? 4 : 6;
+}
+#define LTG_D_SPL_LAUNCH(SPLV, KERNEL, ...)                                       \
+    do {                                                                          \
+        if ((SPLV) == 6) hipLaunchKernelGGL((KERNEL<6>), __VA_ARGS__);            \
+        else if ((SPLV) == 4) hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERNEL<0>), __VA_ARGS__);                        \
+    } while (0)
 inline bool unsharded(const ltg_config* c) { return c->item_lo == 0 && (c->n_items_global == 0 || c->n_items_global == c->n_items); }
 inline bool small_fast(const ltg_config* c, int rows) {
     return fast_on(c) && unsharded(c) && c->n_items <= RD_MAXI && (c->n_items % 4) == 0 && (c->z_dim % 4) == 0 && rows <= 256;
@@ -3069,7 +3108,8 @@ inline bool small_fast(const ltg_config* c, int rows) {
 
 bool cfg_ok(const ltg_config* c) {
     return c && c->n_items > 0 && c->h_enc > 0 && c->h_enc <= 768 && (c->h_enc % 4) == 0 && c->z_dim > 0 &&
-           (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32) && c->d_precision >= 0 && c->d_precision <= LTG_PREC_FP8;
+           (c->precision == LTG_PREC_BF16 || c->precision == LTG_PREC_FP32) && c->d_precision >= 0 && c->d_precision <= LTG_PREC_FP8 &&
+           c->d_arith >= 0 && (c->d_arith & 3) <= LTG_DARITH_BF16X4 && (c->d_arith & ~0xF3) == 0;
 }
 
 inline int Ig_of(const ltg_config* cfg) { return cfg->n_items_global > 0 ? cfg->n_items_global : cfg->n_items; }
@@ -3126,10 +3166,10 @@ int launch_dec1_fwd_stream(const ltg_config* cfg, const ltg_gen_state* gen, int 
     const int I = cfg->n_items, H = cfg->h_enc;
     // the second form for the HBM-bound slabs (see k_dec1_fwd_stream2); tuning-knob bit 26: the first form at every size, bit 17: the second
     // form from 8 192 items (A/B measurements)
-    const int st2_min = (cfg->reserved0 & (1 << 17)) ? 8192 : ST2_MIN_ITEMS;
+    const int st2_min = (cfg->tuning & (1 << 17)) ? 8192 : ST2_MIN_ITEMS;
     // (the second form addresses the logits AND the shadow rows with 32-bit byte offsets from a uniform base: R * I * 4 and I * ST_KP * 2 must both
     // stay below 2^32 -- 3 532 110 items of one slab for the shadow; beyond either limit the first form, which has none)
-    if ((cfg->reserved0 & (1 << 26)) == 0 && I >= st2_min && (size_t)R * (size_t)I < ((size_t)1 << 30) &&
+    if ((cfg->tuning & (1 << 26)) == 0 && I >= st2_min && (size_t)R * (size_t)I < ((size_t)1 << 30) &&
         (size_t)I * (size_t)(ST_KP * 2) < ((size_t)1 << 32)) {
         const int nt2 = (I + 31) / 32, G2 = nt2 < 256 ? nt2 : 256;
 #define LTG_ST2(STATS, NTB) hipLaunchKernelGGL((k_dec1_fwd_stream2<STATS, NTB>), dim3(G2), dim3(ST_NT), (size_t)ST_KS * NTB * 64 * 16, st, R, I, H, acts->h2, gen->wp1t_bf16, gen->p[7], acts->logits, stat)
@@ -3153,7 +3193,7 @@ int fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
     int stat_groups = 0;
     const int R = bt->n_rows, I = cfg->n_items, H = cfg->h_enc, Z = cfg->z_dim;
     const Probe pr{o->probe, st};
-    const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
+    const bool vz = (Z % 4) == 0 && (cfg->tuning & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
     if (apply_bias_tanh) {
         const int n = R * H;
         hipLaunchKernelGGL(k_bias_tanh, dim3((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024), dim3(NT), 0, st, n, H, gen->p[4], acts->h1);
@@ -3182,12 +3222,12 @@ int fwd_stage_rest(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_ba
             if (bf) hipLaunchKernelGGL(fk_dec1<true>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
             else hipLaunchKernelGGL(fk_dec1<false>, grid2(I, R, 16, 16), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         } else if (stream_ok(cfg, gen, R)) {
-            if (stat && (cfg->reserved0 & (1 << 21)) == 0)   // (tuning-knob bit 21: statistics from a second pass over the logits)
+            if (stat && (cfg->tuning & (1 << 21)) == 0)   // (tuning-knob bit 21: statistics from a second pass over the logits)
                 stat_groups = launch_dec1_fwd_stream(cfg, gen, R, acts, stat, st);
             else
                 launch_dec1_fwd_stream(cfg, gen, R, acts, nullptr, st);
         } else if (bf && big) hipLaunchKernelGGL((k_dec1_fwd<true, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
-        else if (bf && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dec1_fwd<true, false, true>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
+        else if (bf && (cfg->tuning & 65536) == 0) hipLaunchKernelGGL((k_dec1_fwd<true, false, true>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (bf) hipLaunchKernelGGL((k_dec1_fwd<true, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else if (big) hipLaunchKernelGGL((k_dec1_fwd<false, true>), grid2(I, R, 64, 128), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
         else hipLaunchKernelGGL((k_dec1_fwd<false, false>), grid2(I, R, 32, 32), dim3(NT), 0, st, R, I, H, acts->h2, gen->p[3], gen->p[7], acts->logits);
@@ -3236,14 +3276,14 @@ inline int d_mode(const ltg_config* cfg) { return cfg->d_precision == LTG_PREC_B
 inline int d_tile(const ltg_config* cfg, int which) {
     const bool wide = cfg->d_h0 >= 512 && cfg->d_h1 + cfg->d_h2 >= 512 && cfg->d_h3 >= 128;
     const bool vec = (cfg->d_h0 % 4) == 0 && (cfg->d_h1 % 4) == 0 && (cfg->d_h2 % 4) == 0 && (cfg->d_h3 % 4) == 0;
-    const int knob = (cfg->reserved0 >> 10) & 7;        // tuning: 1 scalar, 2 all 64, 3 all 128
+    const int knob = (cfg->tuning >> 10) & 7;        // tuning: 1 scalar, 2 all 64, 3 all 128
     if (knob == 1) return 32;
     if (!(wide && vec)) {
         // default sizes (100/150/250/300): l2 and backward stage 1 only touch h12 = 400 and h3 = 300 wide rows -> 16-B
         // loaders on the 32 x 32 tiles; l1 / stage 2 index columns of width h1 = 150 (8-B aligned only) -> scalar
         const bool v12 = ((cfg->d_h1 + cfg->d_h2) % 4) == 0 && (cfg->d_h3 % 4) == 0;
         if (which == 1 || which == 2) return v12 ? -32 : 32;
-        return ((cfg->d_h0 % 4) == 0 && (cfg->reserved0 & 32768) == 0) ? -33 : 32;   // embedding rows (operand A) in 16-B pieces
+        return ((cfg->d_h0 % 4) == 0 && (cfg->tuning & 32768) == 0) ? -33 : 32;   // embedding rows (operand A) in 16-B pieces
     }
     if (knob == 2) return 64;
     if (knob == 3) return 128;
@@ -3273,7 +3313,26 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    if (d_fast(cfg) && !with_bwd && h0 >= 32 && h12 >= 32 && (h0 % 4) == 0 && (h12 % 4) == 0 && (cfg->reserved0 & (1 << 23)) == 0) {
+    if (!with_bwd && ft_wsp_capable(cfg) && (cfg->d_arith & 3) != LTG_DARITH_FP32 && (cfg->tuning & ((1 << 23) | (1 << 20))) == 0) {
+        // forward only, split arithmetic: ONE kernel from the id lists to y, A1 stays in LDS (ltg_tower.h).  (Tuning-knob bit 20: the three
+        // launches below instead.)  The weights are split first: 1 MB at config.ini's sizes, ~3 us, once per call.
+        ltg_ft_u32x4* wsp = reinterpret_cast<ltg_ft_u32x4*>(w.wsp);
+        const int nwv = (int)ft_wsp_triples(h0, h1, h2, h3);
+        hipLaunchKernelGGL(fkt_split_weights, dim3((nwv + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, st, h0, h1, h2, h3, d->p[0], d->p[2], d->p[4], wsp);
+        const dim3 g((n + FT_BM - 1) / FT_BM);
+        const size_t lds = ft_lds_bytes(h12);
+        pr.before(LTG_K_D_L1);
+        const bool inj = dA.real || dA.fake || dB.real || dB.fake || dC.real || dC.fake;
+#define LTG_FT_LAUNCH(SPLV, INJV)                                                                                                                              \
+    hipLaunchKernelGGL((fkt_d_tower<SPLV, 5, INJV>), g, dim3(FT_NT), lds, st, pv, h0, h1, h2, h3, d->emb, wsp, d->p[1], d->p[3], d->p[5], d->p[6], d->p[7], dA, dB, dC, \
+                       keep, cfg->seed, step, w.y)
+        if ((cfg->d_arith & 3) == LTG_DARITH_BF16X4) { if (inj) LTG_FT_LAUNCH(4, true); else LTG_FT_LAUNCH(4, false); }
+        else { if (inj) LTG_FT_LAUNCH(6, true); else LTG_FT_LAUNCH(6, false); }
+#undef LTG_FT_LAUNCH
+        pr.after(LTG_K_D_L1);
+        return;
+    }
+    if (d_fast(cfg) && !with_bwd && h0 >= 32 && h12 >= 32 && (h0 % 4) == 0 && (h12 % 4) == 0 && (cfg->tuning & (1 << 23)) == 0) {
         // forward only (the fake tower of the G steps, one batch or -- ltg_fake_tower_batched -- 10^5 pair rows): LDS-staged 64 x 64
         // tiles.  The choice depends on the layer sizes only, so the tower inside a step and the batched tower run the same
         // kernels and produce the same bits.  (Tuning-knob bit 23: the register-resident 32 x 32 tiles.)
@@ -3286,17 +3345,17 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     }
     if (d_fast(cfg)) {
         // A3, G3 (backward only) and the per-tile partial dot products of the output unit; y only when nothing else follows
-        LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fk_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
-                                                      d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
-        LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fk_d_l2, dim3(((h3 + 31) / 32) * ((n + 31) / 32)), dim3(DL2_NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
-                                                      cfg->seed, step, w.A3, with_bwd ? w.G3 : (float*)nullptr, w.spart));
+        LTG_PROBED(pr, LTG_K_D_L1, LTG_D_SPL_LAUNCH(d_spl(cfg, 0), fk_d_l1, grid2(nmax, n, 32, 32, 2), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0], d->p[1], d->p[2],
+                                                    d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
+        LTG_PROBED(pr, LTG_K_D_L2, LTG_D_SPL_LAUNCH(d_spl(cfg, 1), fk_d_l2, dim3(((h3 + 31) / 32) * ((n + 31) / 32)), dim3(DL2_NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,
+                                                    cfg->seed, step, w.A3, with_bwd ? w.G3 : (float*)nullptr, w.spart));
         if (!with_bwd) hipLaunchKernelGGL(fk_d_y, dim3((n + NT - 1) / NT), dim3(NT), 0, st, pv, (h3 + 31) / 32, w.spart, d->p[7], w.y);
         return;
     }
     const int md = d_mode(cfg), ts = d_tile(cfg, 0), ts2 = d_tile(cfg, 1), t1 = ts < 0 ? 32 : ts, t2 = ts2 < 0 ? 32 : ts2;
     if (md == 2 && fast_on(cfg) && d->emb_fp8 && d->w1t_fp8 && d->w2t_fp8 && d->w3t_fp8 && (h0 % 64) == 0 && (h12 % 64) == 0) {
         // operand-format storage: both forward layers read e4m3 bytes (embedding table, transposed weight shadows, A1 in e4m3)
-        const bool staged = (h0 % 128) == 0 && (h12 % 128) == 0 && (cfg->reserved0 & (1 << 24)) == 0;   // LDS-staged tiles (knob bit 24: register-resident)
+        const bool staged = (h0 % 128) == 0 && (h12 % 128) == 0 && (cfg->tuning & (1 << 24)) == 0;   // LDS-staged tiles (knob bit 24: register-resident)
         if (with_bwd && d_fp8_opfmt(cfg, d)) {
             // the step's own forward: the same products, and every activation the backward multiplies is left behind in e4m3 in the
             // orientation its GEMM contracts over (ltg_fp8bwd.h)
@@ -3444,22 +3503,23 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         // launch structure: the five grids returning at once take 18 us.)
         // (only with the FLAT tensor layout: the poison word reaches fk_d_adam alone -- separate tensors take k_d_adam, which has no early
         // return, so a direct C-ABI caller with that layout keeps the whole step on one stream)
-        const bool fork = o->aux_stream && o->sync && !grad_out && (cfg->reserved0 & 64) == 0 &&      // (tuning-knob bit 6: no fork)
+        const bool fork = o->aux_stream && o->sync && !grad_out && (cfg->tuning & 64) == 0 &&      // (tuning-knob bit 6: no fork)
                           d_adam_flat(cfg, disc, L, SP, w.slab, nullptr);
         const unsigned* poison = fork ? o->sync + 2 : nullptr;
-        LTG_PROBED(pr, LTG_K_D_BWD1, hipLaunchKernelGGL(fk_d_bwd1, dim3(fork ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
-                                                        w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab,
-                                                        fork ? LtgGate{o->sync, o->seq, nullptr, 0} : LTG_NO_GATE));
+        const int spl1 = d_spl(cfg, 2), spl2 = d_spl(cfg, 3);
+        LTG_PROBED(pr, LTG_K_D_BWD1, LTG_D_SPL_LAUNCH(spl1, fk_d_bwd1, dim3(fork ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
+                                                      w.spart, disc->p[7], disc->p[4], o->keep_prob, w.dpre1, w.slab,
+                                                      fork ? LtgGate{o->sync, o->seq, nullptr, 0} : LTG_NO_GATE));
         if (fork) {
             hipStream_t ax = (hipStream_t)o->aux_stream;
             hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, ax, LtgGate{o->sync, o->seq, o->sync + 2, 0}, LTG_NO_GATE);
-            hipLaunchKernelGGL(fk_d_bwd1, dim3(nB + nC), dim3(NT), 0, ax, pv, h12, h3, 0, nB, ntile, L, SP, w.A1, w.A3, w.G3, w.spart, disc->p[7], disc->p[4],
-                               o->keep_prob, w.dpre1, w.slab, LTG_NO_GATE);
+            LTG_D_SPL_LAUNCH(spl1, fk_d_bwd1, dim3(nB + nC), dim3(NT), 0, ax, pv, h12, h3, 0, nB, ntile, L, SP, w.A1, w.A3, w.G3, w.spart, disc->p[7], disc->p[4],
+                             o->keep_prob, w.dpre1, w.slab, LTG_NO_GATE);
             hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(64), 0, ax, LtgGate{o->sync + 1, o->seq, nullptr, 0}, LTG_NO_GATE);
         }
         const int n2 = ks * ((h0 + 1 + 15) / 16) * ((h1 + 31) / 32 + (h2 + 31) / 32);
-        LTG_PROBED(pr, LTG_K_D_BWD2, hipLaunchKernelGGL(fk_d_bwd2, dim3(n2 + (fork ? 1 : 0)), dim3(DB2_NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab,
-                                                        fork ? LtgGate{o->sync + 1, o->seq, o->sync + 2, 0} : LTG_NO_GATE));
+        LTG_PROBED(pr, LTG_K_D_BWD2, LTG_D_SPL_LAUNCH(spl2, fk_d_bwd2, dim3(n2 + (fork ? 1 : 0)), dim3(DB2_NT), 0, st, pv, h0, h1, h2, L, SP, disc->emb, w.dpre1, w.slab,
+                                                      fork ? LtgGate{o->sync + 1, o->seq, o->sync + 2, 0} : LTG_NO_GATE));
         if (grad_out) hipLaunchKernelGGL(k_d_grad_sum, dim3(64), dim3(NT), 0, st, ks, P, SP, w.slab, 0, (const float*)nullptr, grad_out);
         else d_apply(cfg, disc, L, ks, SP, w.slab, 0, nullptr, ad, loss_out, pr, st, poison);
         return check_launch();
@@ -3482,7 +3542,7 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
     int ts = d_tile(cfg, 2);
     {   // backward stage 1 with > 1024 32 x 32 tiles is throughput-bound, not latency-bound: 64 x 64 tiles (measured -5 %)
         const long t32 = (long)((n + 31) / 32) * ((h12 + 31) / 32) + (long)ks * ((h12 + 32) / 32) * ((h3 + 31) / 32);
-        if (ts == -32 && t32 > 1024 && (cfg->reserved0 & 4096) == 0) ts = 64;
+        if (ts == -32 && t32 > 1024 && (cfg->tuning & 4096) == 0) ts = 64;
     }
     const int md = d_mode(cfg), tsb = d_tile(cfg, 3), ta = ts < 0 ? 32 : ts, tb = tsb < 0 ? 32 : tsb;
     auto tiles = [ta](int x) { return (x + ta - 1) / ta; };
@@ -3584,7 +3644,7 @@ static void g_row_partial(const ltg_config* cfg, const ltg_batch* bt, const ltg_
 
 // dlog as bf16: when BOTH its consumers are the streaming kernels (k_dh2_stream, k_dec1_bwd_adam_stream + ragged tail)
 static bool dlog16_ok(const ltg_config* cfg, const ltg_gen_state* gen, int B) {
-    return fast_on(cfg) && stream_ok(cfg, gen, B) && dw_stream_ok(cfg->h_enc) && (cfg->reserved0 & 15) == 0 && (cfg->reserved0 & (1 << 22)) == 0;
+    return fast_on(cfg) && stream_ok(cfg, gen, B) && dw_stream_ok(cfg->h_enc) && (cfg->tuning & 15) == 0 && (cfg->tuning & (1 << 22)) == 0;
 }
 
 static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_state* disc, const ltg_batch* bt,
@@ -3623,7 +3683,7 @@ static int g_stage_bwd_dec(const ltg_config* cfg, const ltg_gen_state* gen, cons
     if (stream && d16) hipLaunchKernelGGL((k_dh2_stream<true, DH2_NH>), dim3(nsplit, DH2_NH), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
     else if (stream) hipLaunchKernelGGL((k_dh2_stream<false, DH2_NH>), dim3(nsplit, DH2_NH), dim3(ST_NT), (size_t)2 * ST_BN * ST_LDW * 2, st, B, I, H, kchunk, w.dlog, gen->wp1t_bf16, w.part);
     else if (bf && big) hipLaunchKernelGGL((k_dh2_partial<true, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
-    else if (bf && (I % 4) == 0 && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dh2_partial<true, false, true>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
+    else if (bf && (I % 4) == 0 && (cfg->tuning & 65536) == 0) hipLaunchKernelGGL((k_dh2_partial<true, false, true>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (bf) hipLaunchKernelGGL((k_dh2_partial<true, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else if (big) hipLaunchKernelGGL((k_dh2_partial<false, true>), grid2(H, B, 64, 128, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
     else hipLaunchKernelGGL((k_dh2_partial<false, false>), grid2(H, B, 32, 32, nsplit), dim3(NT), 0, st, B, I, H, kchunk, w.dlog, gen->p[3], w.part);
@@ -3748,8 +3808,8 @@ static void g_chain(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_b
     LTG_PROBED(pr, LTG_K_DZ, hipLaunchKernelGGL(fk_dz, grid2(Z, B, 16, 16), dim3(NT), 0, st, B, Z, H, w.da2, gen->p[2], acts->mulv, o->fwd.eps,
                                                 o->fwd.is_training, o->anneal, cfg->seed, o->fwd.rng_step, w.dmlv));
     LTG_PROBED(pr, LTG_K_DH1, hipLaunchKernelGGL(fk_dh1, grid2(H, B, 16, 16), dim3(NT), 0, st, B, H, 2 * Z, w.dmlv, gen->p[1], acts->h1, w.da1));
-    const bool fused = lazy && fast_on(cfg) && (cfg->reserved0 & (1 << 25)) == 0;   // Adam on the batch's rows inside the gradient kernel
-    const bool row_waves = (cfg->reserved0 & (1 << 14)) == 0;   // tuning-knob bit 14: the column-blocked shape of the sparse gradient
+    const bool fused = lazy && fast_on(cfg) && (cfg->tuning & (1 << 25)) == 0;   // Adam on the batch's rows inside the gradient kernel
+    const bool row_waves = (cfg->tuning & (1 << 14)) == 0;   // tuning-knob bit 14: the column-blocked shape of the sparse gradient
     if (fused) g_enc0_grad(cfg, bt, o, acts, w, st, gen, &ad, row_waves);
     else if (slot || lazy) g_enc0_grad(cfg, bt, o, acts, w, st, nullptr, nullptr, row_waves);
     const bool own_sweep = (slot && cfg->n_items >= 8192) || lazy;   // HBM-bound sweep: its own launch at full occupancy (measured 490 vs
@@ -3773,7 +3833,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     const AdamC ad = make_adam(cfg, o->adam_t);
     const bool bf = cfg->precision == LTG_PREC_BF16;
     const bool big = I >= 8192;
-    const bool vz = (Z % 4) == 0 && (cfg->reserved0 & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
+    const bool vz = (Z % 4) == 0 && (cfg->tuning & 8192) == 0;   // 16-B loaders of the middle layers (H % 4 == 0 always)
     // Everything on `st` unless the lazy clock's chain runs beside the weight update (below).  (Measured and removed: small item slabs,
     // the three weight-gradient + Adam kernels on the aux stream beside da2 -> dz -> dh1 -> sweep -- the event pairs cost more than the
     // overlap saves once the chain's kernels take 6-18 us; I = 200 000, the two HBM sweeps side by side: they only contend.)
@@ -3793,13 +3853,13 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
     auto launch_dw = [&]() {
         const Probe prs{o->probe, s_dw};
         prs.before(LTG_K_DEC1_BWD_ADAM);
-        const int var = (cfg->reserved0 & 15) > 0 ? (cfg->reserved0 & 15) - 1 : (big ? 2 : 0);   // reserved0: tuning knob (0 = auto)
-        if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->reserved0 & 15) == 0) {
+        const int var = (cfg->tuning & 15) > 0 ? (cfg->tuning & 15) - 1 : (big ? 2 : 0);   // tuning: tuning knob (0 = auto)
+        if (stream_ok(cfg, gen, B) && dw_stream_ok(H) && (cfg->tuning & 15) == 0) {
             const int ntl = I / 32;
             if (dlog16_ok(cfg, gen, B)) {   // (the producer, g_stage_bwd_dec, stored dlog as bf16 under the same predicate)
                 // persistent workgroups: 224 = 28 per XCD (measured 657 us at 200 000 items; 256: 678, 240: 669, 192: 671) -- and 32 CUs
                 // stay free for whatever runs beside it.  Tuning-knob bits 27-30 = k: 256 - 8 k instead.
-                const int gk = (cfg->reserved0 >> 27) & 15;
+                const int gk = (cfg->tuning >> 27) & 15;
                 int gmax = gk ? 256 - 8 * gk : dw_gmax;
                 // ... and no more workgroups than the same number of rounds needs (782 tiles of a 25 024-item slab: 4 rounds with
                 // 224 or with 196 workgroups -- 60 CUs left to the chain and the collective running beside it)
@@ -3817,7 +3877,7 @@ static int g_stage_bwd_rest(const ltg_config* cfg, const ltg_gen_state* gen, con
         } else if (!bf) {
             if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<false, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
             else hipLaunchKernelGGL((k_dec1_bwd_adam<false, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
-        } else if (var == 0 && (I % 4) == 0 && (cfg->reserved0 & 65536) == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0, true>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
+        } else if (var == 0 && (I % 4) == 0 && (cfg->tuning & 65536) == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0, true>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         else if (var == 0) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 0>), grid2(H + 1, I, 32, 32), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         else if (var == 1) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 1>), grid2(H + 1, I, 128, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
         else if (var == 2) hipLaunchKernelGGL((k_dec1_bwd_adam<true, 2>), grid2(H + 1, I, 64, 64), dim3(NT), 0, s_dw, B, I, H, w.dlog, acts->h2, *gen, ad, 0);
@@ -3925,9 +3985,9 @@ int ltg_g_step(const ltg_config* cfg, const ltg_gen_state* gen, const ltg_disc_s
     // lazy Adam clock of W_q0: the batch's rows up to date first; its rotating slice (rows NOT of this batch: arithmetic-bound,
     // 48 registers -- it fits beside the 2 x 232-register waves of the HBM-bound decoder kernels) then runs on the aux stream
     q0_touch(cfg, gen, bt, st);
-    const bool aux_sweep = q0_lazy(cfg, gen) && o->aux_stream && o->ev_fork && o->ev_sweep && (cfg->reserved0 & 512) == 0;
+    const bool aux_sweep = q0_lazy(cfg, gen) && o->aux_stream && o->ev_fork && o->ev_sweep && (cfg->tuning & 512) == 0;
     // fork: the fake tower (independent of the generator forward) runs on the caller's aux stream
-    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0 && (cfg->reserved0 & 512) == 0 && !have_y;
+    const bool fork = o->aux_stream && o->ev_fork && o->ev_join && nf > 0 && (cfg->tuning & 512) == 0 && !have_y;
     if (fork || aux_sweep) {
         hipStream_t aux = (hipStream_t)o->aux_stream;
         if (hipEventRecord((hipEvent_t)o->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)o->ev_fork, 0) != hipSuccess)

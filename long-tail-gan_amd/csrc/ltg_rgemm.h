@@ -62,6 +62,37 @@ __device__ __forceinline__ void ltg_stamp(int slot) {
 #define LTG_STAMP_AT(SID, slot) do { } while (0)
 #endif
 
+// fp32 operands on the bf16 matrix pipe without giving up fp32 accuracy (round 6; discriminator GEMMs, ltg_config.d_arith): x = hi + mid + lo EXACTLY with
+// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (RNE: each residual is exact in fp32 and 8 bits shorter, |mid| <= 2^-9 |x|,
+// |lo| <= 2^-18 |x|), every bf16 x bf16 product is exact in fp32, and the accumulation is the matrix pipe's fp32.  Six cross terms
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) leave out 2 * 2^-27 |a b| per product -- below the fp32 rounding of the product itself; four
+// terms (no lo) leave out 2^-17.  Two elements per dword as v_mfma_f32_16x16x32_bf16 wants them: v_cvt_pk_bf16_f32 + v_pk_add_f32, 18 vector
+// instructions per four elements (SPL = 6) / 10 (SPL = 4).
+struct LtgSplit {
+    unsigned hi[2], mid[2], lo[2];
+};
+template <int SPL>
+__device__ __forceinline__ LtgSplit ltg_split_bf16(ltg_f32x4 v) {
+    typedef float ltg_rg_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 ltg_rg_bf16x2 __attribute__((ext_vector_type(2)));
+    LtgSplit s;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const ltg_rg_f32x2 x = {v[2 * h], v[2 * h + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, ltg_rg_bf16x2));
+        const ltg_rg_f32x2 r1 = x - ltg_rg_f32x2{__uint_as_float(hu << 16), __uint_as_float(hu & 0xFFFF0000u)};
+        const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, ltg_rg_bf16x2));
+        s.hi[h] = hu;
+        s.mid[h] = mu;
+        s.lo[h] = 0u;
+        if constexpr (SPL == 6) {
+            const ltg_rg_f32x2 r2 = r1 - ltg_rg_f32x2{__uint_as_float(mu << 16), __uint_as_float(mu & 0xFFFF0000u)};
+            s.lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, ltg_rg_bf16x2));
+        }
+    }
+    return s;
+}
+
 template <int TM, int TN, int WM, int WN, int WK>
 struct LtgRg {
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
@@ -96,9 +127,14 @@ struct LtgXfId {
 
 // mid(): called once, after the requests of the first pass have been issued and before anything consumes them -- the place
 // for work that needs an earlier load of the caller's (e.g. row factors into LDS + a barrier) without costing a round trip.
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, int SID = 0, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
+// SPL = 0: v_mfma_f32_16x16x4_f32 (the exact fp32 fma chain).  SPL = 6 / 4: the same product as bf16 cross terms of the split operands
+// (ltg_split_bf16) on v_mfma_f32_16x16x32_bf16 -- two 16-deep blocks share an MFMA: slots 0..3 of a lane's fragment are block i's k = 4 q + j,
+// slots 4..7 block i + 1's, for both operands, so the instruction adds up 32 k of one cross term; six (four) MFMAs of 16 cycles per block pair
+// and output tile instead of eight of 32.
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool PEEL = false, int SID = 0, int SPL = 0, class ALD, class AXF, class BLD, class BXF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, float* __restrict__ lds,
                                                   MID mid = MID()) {
+    static_assert(SPL == 0 || SPL == 4 || SPL == 6, "fp32 MFMA, or the four- / six-term bf16 split");
     static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "4 or 8 waves per workgroup");
     typedef LtgRg<TM, TN, WM, WN, WK> G;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -144,6 +180,64 @@ __device__ __forceinline__ void ltg_rgemm_product(int M, int N, int K, int m0, i
             LTG_STAMP_AT(SID, 1);
             mid();
             LTG_STAMP_AT(SID, 2);
+        }
+        if constexpr (SPL != 0) {
+            // phase 2, split form: pairs of blocks; a block of the pair that is out of range contributes zeros (its A fragment is zeroed)
+            typedef unsigned ltg_rg_u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < NBLK; i += 2) {
+                if (base + i >= per || 16 * (wk * per + base + i) >= K) continue;   // wave-uniform: nothing of this pair is in range
+                LtgSplit sa[TM][2], sb[TN][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (i + h < NBLK) {
+                        const int k = 16 * (wk * per + base + i + h) + 4 * q;
+                        const bool ok = base + i + h < per && k < K;
+                        const int kc = min(k, Kc);
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            const ltg_f32x4 v = a_xf(ra[i + h][tm], i + h, am[tm], kc);
+                            const bool o = ok && aok[tm];
+                            sa[tm][h] = ltg_split_bf16<SPL>(ltg_f32x4{o ? v[0] : 0.f, o ? v[1] : 0.f, o ? v[2] : 0.f, o ? v[3] : 0.f});
+                        }
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) sb[tn][h] = ltg_split_bf16<SPL>(b_xf(rb[i + h][tn], i + h, kc, bn[tn]));
+                    } else {
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) sa[tm][h] = LtgSplit{{0u, 0u}, {0u, 0u}, {0u, 0u}};
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) sb[tn][h] = LtgSplit{{0u, 0u}, {0u, 0u}, {0u, 0u}};
+                    }
+                }
+                ltg_bf16x8 ah[TM], am_[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    ah[tm] = __builtin_bit_cast(ltg_bf16x8, ltg_rg_u32x4{sa[tm][0].hi[0], sa[tm][0].hi[1], sa[tm][1].hi[0], sa[tm][1].hi[1]});
+                    am_[tm] = __builtin_bit_cast(ltg_bf16x8, ltg_rg_u32x4{sa[tm][0].mid[0], sa[tm][0].mid[1], sa[tm][1].mid[0], sa[tm][1].mid[1]});
+                    al[tm] = __builtin_bit_cast(ltg_bf16x8, ltg_rg_u32x4{sa[tm][0].lo[0], sa[tm][0].lo[1], sa[tm][1].lo[0], sa[tm][1].lo[1]});
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    bh[tn] = __builtin_bit_cast(ltg_bf16x8, ltg_rg_u32x4{sb[tn][0].hi[0], sb[tn][0].hi[1], sb[tn][1].hi[0], sb[tn][1].hi[1]});
+                    bm[tn] = __builtin_bit_cast(ltg_bf16x8, ltg_rg_u32x4{sb[tn][0].mid[0], sb[tn][0].mid[1], sb[tn][1].mid[0], sb[tn][1].mid[1]});
+                    bl[tn] = __builtin_bit_cast(ltg_bf16x8, ltg_rg_u32x4{sb[tn][0].lo[0], sb[tn][0].lo[1], sb[tn][1].lo[0], sb[tn][1].lo[1]});
+                }
+                // the small terms first
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        if constexpr (SPL == 6) {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        }
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am_[tm], bm[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bm[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am_[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+            return;
         }
         // phase 2: transforms and MFMAs, block by block as the data lands
 #pragma unroll
@@ -295,13 +389,15 @@ __device__ __forceinline__ void ltg_rgemm_product_bf16(int M, int N, int K, int 
 }
 
 // BFM: the product on the bf16 matrix pipe (ltg_rgemm_product_bf16; NBLK then counts 32-deep blocks)
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, bool PEEL = false, int SID = 0, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
+// SPL: the fp32 product as bf16 cross terms of the split operands (ltg_rgemm_product; not with BFM)
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, bool PEEL = false, int SID = 0, int SPL = 0, class ALD, class AXF, class BLD, class BXF, class EF, class MID = LtgNoMid>
 __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, EF epi, float* __restrict__ lds,
                                           MID mid = MID()) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
+    static_assert(!(BFM && SPL != 0), "operands that are bf16-rounded anyway need no split");
     if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK, PEEL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     else
-    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, PEEL, SID>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, PEEL, SID, SPL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, mid);
     const int tid = threadIdx.x;
     constexpr int NE = G::BM * G::BN;
     constexpr int NTH = 64 * WM * WN * WK;      // threads of the workgroup (256, or 512 with eight K slices)

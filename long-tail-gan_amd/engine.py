@@ -211,13 +211,22 @@ class DFork:
         return int(self.sync[2].item())
 
 
+# arithmetic of the fp32 discriminator's GEMMs (ltg_config.d_arith): the six-term bf16 split is fp32-accurate (every fp32-path parity test passes at
+# its fp32 bound with it: tests/test_gpu_parity.py::test_d_step_parity) and 3.9 ms per epoch faster on Askubuntu_Sample (profiles/r6_ab_d_arith.txt);
+# "fp32" = v_mfma_f32_16x16x4_f32, the exact fma chain, stays selectable
+D_ARITH_DEFAULT = "bf16x6"
+
+
 class Engine:
     def __init__(self, n_items, h_sizes=(100, 150, 250, 300), lr=1e-4, p_dims=None, feature_len=None,
                  precision="bf16", seed=98765, d_seed=0, device="cuda:0", beta1=0.9, beta2=0.999, eps=1e-8,
-                 item_lo=0, item_hi=None, d_precision="fp32", lazy_q0=None, q0_period=32):
+                 item_lo=0, item_hi=None, d_precision="fp32", lazy_q0=None, q0_period=32, d_arith=None):
         """n_items = GLOBAL item count; [item_lo, item_hi) = the slab this rank owns (default: everything).
         precision: operands of the three decoder GEMMs; d_precision: operands of the discriminator GEMMs
         ("fp32" = the reference's arithmetic, "bf16", "fp8" = BASELINE config 5).
+        d_arith (d_precision "fp32", config.ini-sized layers): how the fp32 products are formed -- "fp32" = exact fp32 MFMA, "bf16x6" = the
+        fp32-accurate six-term bf16 split on the bf16 matrix pipe, "bf16x4" = the four-term split (2^-17 per product, opt-in); None = D_ARITH_DEFAULT
+        (environment LTGAN_D_ARITH overrides; include/ltg.h: ltg_config.d_arith).
         lazy_q0: lazy Adam clock of W_q0 (include/ltg.h, ltg_gen_state.q0_last; same results as the dense sweep).  None = on
         for item slabs of 8192 items or more.  Rows are brought up to date by every forward that reads them; `g_flush()`
         does it for all rows and runs after every G step unless a trainer holds `q0_defer` for the length of its phase."""
@@ -241,8 +250,13 @@ class Engine:
         self.feature_len = feature_len or n_items
         self.precision = {"bf16": cabi.LTG_PREC_BF16, "fp32": cabi.LTG_PREC_FP32}[precision]
         self.d_precision = {"fp32": cabi.LTG_PREC_FP32, "bf16": cabi.LTG_PREC_BF16, "fp8": cabi.LTG_PREC_FP8}[d_precision]
+        if d_arith is None:
+            d_arith = os.environ.get("LTGAN_D_ARITH", D_ARITH_DEFAULT)
+        self.d_arith = d_arith
+        d_arith_code = {"fp32": cabi.LTG_DARITH_FP32, "bf16x6": cabi.LTG_DARITH_BF16X6, "bf16x4": cabi.LTG_DARITH_BF16X4}[d_arith]
+        d_arith_code |= (int(os.environ.get("LTGAN_D_ARITH_SET", "0"), 0) & 15) << 4     # measurement switch: which of the four GEMM kernels
         self.cfg = cabi.ltg_config(self.I, self.H, self.Z, self.feature_len, self.h0, self.h1, self.h2, self.h3,
-                                   self.precision, 0, self.item_lo, n_items if self.sharded else 0, self.d_precision, 0,
+                                   self.precision, 0, self.item_lo, n_items if self.sharded else 0, self.d_precision, d_arith_code,
                                    lr, beta1, beta2, eps, seed)
         self.lr, self.beta1, self.beta2 = lr, beta1, beta2
         self.adam_t = 0                                              # shared by D and G (Q5)

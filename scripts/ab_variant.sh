@@ -1,4 +1,4 @@
-# same library, two settings of the tuning knob (cfg.reserved0) on ONE box: A/B of a schedule or kernel variant
+# same library, two settings of the tuning knob (cfg.tuning) on ONE box: A/B of a schedule or kernel variant
 # usage: ab_variant.sh <workload> <variantA> <variantB> [kernel names...]
 W=${1:-c4}; A=${2:-0}; B=${3:-512}; shift 3 2>/dev/null
 KS=${@:-dec1_bwd_adam enc0_bwd_adam dz dh1}

@@ -1,6 +1,6 @@
 """The streaming decoder forward ALONE on the chip (one stream, nothing beside it): `python scripts/fwd_alone.py <items> <reps> [variant]`
 under `rocprofv3 --kernel-trace --stats` gives the kernel's own duration, without the side stream's clock kernels it shares the CUs with
-inside the one-call step.  variant = ltg_config.reserved0 (bit 26: the first form of the kernel)."""
+inside the one-call step.  variant = ltg_config.tuning (bit 26: the first form of the kernel)."""
 import sys
 
 import numpy as np
@@ -17,7 +17,7 @@ def main():
     variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     B = 100
     eng = Engine(I, lr=1e-4, precision="bf16", seed=1)
-    eng.cfg.reserved0 = variant
+    eng.cfg.tuning = variant
     rng = np.random.default_rng(0)
     X = Hh.random_history(rng, B, I, mean_nnz=18)
     dev = eng.device

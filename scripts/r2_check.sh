@@ -1,5 +1,5 @@
 # round-2 GPU check: parity tests, then Askubuntu bench with the round-2 latency kernels and with the round-1 ones
-# (ltg_config.reserved0 bit 18), then a kernel trace of each.
+# (ltg_config.tuning bit 18), then a kernel trace of each.
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,4 @@
-# timing experiments through tuning-knob bits (ltg_config.reserved0): kernel trace of one bench step per variant
+# timing experiments through tuning-knob bits (ltg_config.tuning): kernel trace of one bench step per variant
 # usage: EXTRA="--workload c4 --users 3200" bash scripts/r2_exp.sh <variant>...
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     lib = cabi.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 13
+    assert lib.ltg_abi_version() == cabi.LTG_ABI_VERSION == 14
 
 
 def test_struct_layouts_match_header():

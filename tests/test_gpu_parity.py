@@ -125,7 +125,7 @@ def test_forward_parity_of_the_second_streaming_form(I, B):
     outs = {}
     for knob in (1 << 17, 1 << 26):
         eng = _engine(I, "bf16")
-        eng.cfg.reserved0 = knob
+        eng.cfg.tuning = knob
         eng.set_generator(Hh.gen_to_engine(P))
         acts = eng.new_acts(B)
         batch = _upload_batch(eng, X)
@@ -277,7 +277,7 @@ def _g_step_case(precision, I, B, path, warm):
     eng = _engine(I, precision, hs=hs, lr=1e-3)
     assert eng.Z == 200
     if path.endswith("-generic"):
-        eng.cfg.reserved0 = 1 << 18
+        eng.cfg.tuning = 1 << 18
     if warm:
         eng.set_generator(Hh.gen_to_engine(P), m=Hh.gen_to_engine(m0), v=Hh.gen_to_engine(v0))
     else:
@@ -356,9 +356,21 @@ def test_g_step_adam_quotient_from_warm_moments(precision, I, B, path):
     _g_step_case(precision, I, B, path, warm=True)
 
 
+@pytest.mark.parametrize("d_arith", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (1, 0), (0, 5), (260, 250)])
-def test_d_step_parity(nr, nf):
-    _d_step_case(nr, nf, warm=False)
+def test_d_step_parity(nr, nf, d_arith):
+    """d_arith (ltg_config.d_arith): the exact fp32 MFMA and the six-term bf16 split of the same fp32 operands -- SAME bounds (the split leaves
+    out 2^-26 per product, below fp32's own rounding); the wide sizes (260, 250) do not take the latency-path kernels: one arithmetic"""
+    if d_arith != "fp32" and nr == 260:
+        pytest.skip("config-5 sizes run the LDS-staged kernels: d_arith does not apply")
+    _d_step_case(nr, nf, warm=False, d_arith=d_arith)
+
+
+@pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7)])
+def test_d_step_parity_four_term_split(nr, nf):
+    """d_arith = bf16x4 (opt-in, labelled NOT fp32-accurate: hi / mid terms only, 2^-17 per product): the same step against the same oracle at
+    bounds 8x wider than fp32's (loss 1e-4 holds; first moments 4e-3, second 8e-3)"""
+    _d_step_case(nr, nf, warm=False, d_arith="bf16x4", loosen=8.0)
 
 
 @pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7)])
@@ -367,14 +379,17 @@ def test_d_step_parity_of_the_generic_kernels(nr, nf):
     _d_step_case(nr, nf, warm=False, knob=1 << 18)
 
 
+@pytest.mark.parametrize("d_arith", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("nr,nf", [(900, 950), (33, 7), (260, 250)])
-def test_d_step_adam_quotient_from_warm_moments(nr, nf):
+def test_d_step_adam_quotient_from_warm_moments(nr, nf, d_arith):
     """The D step from injected non-zero Adam moments at shared step t = 212 (train.py:160-163): the flat Adam sweep's theta move,
     m and v element-wise against oracle.SharedAdam."""
-    _d_step_case(nr, nf, warm=True)
+    if d_arith != "fp32" and nr == 260:
+        pytest.skip("config-5 sizes run the LDS-staged kernels: d_arith does not apply")
+    _d_step_case(nr, nf, warm=True, d_arith=d_arith)
 
 
-def _d_step_case(nr, nf, warm, knob=0):
+def _d_step_case(nr, nf, warm, knob=0, d_arith=None, loosen=1.0):
     import torch
     from ltgan.engine import Pairs
     I = 500
@@ -420,8 +435,8 @@ def _d_step_case(nr, nf, warm, knob=0):
     D64 = {k: np.asarray(v, np.float64) for k, v in D.items()}
     ad.apply(D64, g, O.D_KEYS)
     # device
-    eng = _engine(I, "fp32", hs=hs, lr=1e-3)
-    eng.cfg.reserved0 = knob
+    eng = _engine(I, "fp32", hs=hs, lr=1e-3, d_arith=d_arith)
+    eng.cfg.tuning = knob
     emb, darr = Hh.disc_to_engine(D)
     if warm:
         eng.set_discriminator(emb, darr, m=[m0[k] for k in O.D_KEYS], v=[v0[k] for k in O.D_KEYS])
@@ -443,14 +458,64 @@ def _d_step_case(nr, nf, warm, knob=0):
                                                 eng.d_v[i].cpu().numpy().reshape(sh), ad.v[k], 1e-4, ("d tensor", k), t0 + 1))
         print("D step (%d, %d): worst relative error of a theta move from warm moments %.2e" % (nr, nf, worst))
         return
+    worst_m = worst_v = 0.0
     for i, k in enumerate(O.D_KEYS):
         m_got = eng.d_m[i].cpu().numpy().reshape(-1)
-        assert Hh.rel_err(m_got, ad.m[k].reshape(-1)) < 5e-4, ("m", k)
+        worst_m = max(worst_m, Hh.rel_err(m_got, ad.m[k].reshape(-1)))
+        assert Hh.rel_err(m_got, ad.m[k].reshape(-1)) < 5e-4 * loosen, ("m", k)
         v_got = eng.d_v[i].cpu().numpy().reshape(-1)
-        assert Hh.rel_err(v_got, ad.v[k].reshape(-1)) < 1e-3, ("v", k)
+        worst_v = max(worst_v, Hh.rel_err(v_got, ad.v[k].reshape(-1)))
+        assert Hh.rel_err(v_got, ad.v[k].reshape(-1)) < 1e-3 * loosen, ("v", k)
+    print("D step (%d, %d) d_arith %s: loss rel err %.2e, worst first / second moment rel err %.2e / %.2e" %
+          (nr, nf, eng.d_arith, abs(loss - want_loss) / max(1.0, abs(want_loss)), worst_m, worst_v))
+    for i, k in enumerate(O.D_KEYS):
         move_got = eng.d_p[i].cpu().numpy().reshape(-1) - np.asarray(D[k], np.float64).reshape(-1)
         move_want = D64[k].reshape(-1) - np.asarray(D[k], np.float64).reshape(-1)
         _check_adam_move(move_got, move_want, ad.m[k].reshape(-1), ad.lr_t(3), ("theta", k))
+
+
+@pytest.mark.parametrize("d_arith,tol", [("bf16x6", 2e-6), ("bf16x4", 2e-5), ("fp32", 2e-6)])
+@pytest.mark.parametrize("hs,segs", [((100, 150, 250, 300), (1, 63, 64, 65, 700, 1311)), ((12, 20, 28, 16), (5, 130)), ((64, 96, 200, 320), (257,))])
+def test_forward_only_tower_matches_oracle(hs, segs, d_arith, tol):
+    """ltg_fake_tower_batched (discriminator.py:51-55 for many pair batches in one pass; consumed at train.py:155): y of every slot against the
+    oracle's tower, segment by segment with the segment's own dropout counter -- through the ONE-kernel tower (csrc/ltg_tower.h: d_arith bf16x6 /
+    bf16x4) and through the three-launch tower (d_arith fp32).  Ragged last row blocks, a one-row segment, holes (id -1 -> y = 0), layer sizes
+    that are not multiples of 16 / 32, the largest fc layer the kernel takes (320)."""
+    import torch
+    from ltgan.engine import Pairs
+    I, keep = 400, 0.7
+    rng = np.random.default_rng(sum(segs) + hs[0])
+    D = O.init_discriminator(I, *hs, seed=11)
+    for k in ("b1", "b2", "b3", "b4"):
+        D[k] = rng.normal(0, 0.05, D[k].shape).astype(np.float32)
+    eng = _engine(I, "fp32", hs=hs, lr=1e-3, d_arith=d_arith)
+    emb, darr = Hh.disc_to_engine(D)
+    eng.set_discriminator(emb, darr)
+    dev = eng.device
+    n = sum(segs)
+    pop, nic = rng.integers(0, I, n).astype(np.int32), rng.integers(0, I, n).astype(np.int32)
+    hole = rng.random(n) < 0.04
+    pop[hole] = -1
+    nic[hole] = -1
+    row0 = np.concatenate([[0], np.cumsum(segs)[:-1]]).astype(np.int32)
+    seg_of = np.repeat(np.arange(len(segs), dtype=np.int32), segs)
+    steps = (1000 + 7 * np.arange(len(segs))).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    y = torch.full((n,), -1.0, dtype=torch.float32, device=dev)
+    eng.fake_tower_batched(Pairs(t(pop), t(nic)), t(seg_of), t(row0), t(steps), y, keep)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().astype(np.float64)
+    worst = 0.0
+    for sidx, (r0, ns) in enumerate(zip(row0, segs)):
+        sl = slice(r0, r0 + ns)
+        dm = Hh.d_masks(SEED, int(steps[sidx]), ns, hs[1:], keep)
+        v = pop[sl] >= 0
+        T = O.d_tower(D, np.where(v, pop[sl], 0), np.where(v, nic[sl], 0), dm, keep)
+        want = np.where(v, T["y"], 0.0)
+        worst = max(worst, float(np.max(np.abs(got[sl] - want))))
+        assert np.all(got[sl][~v] == 0.0)
+    print("forward-only tower %s d_arith %s: worst |y - oracle| %.2e over %d slots" % (hs, d_arith, worst, n))
+    assert worst < tol, worst
 
 
 def test_d_step_with_its_backward_jobs_on_the_aux_stream_is_bit_identical():
@@ -964,7 +1029,7 @@ def test_fp8_operand_shadows_stay_in_step_with_the_master_weights():
     rng = np.random.default_rng(9)
     a, b = _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8"), _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8")
     assert a.d_fp8 is not None
-    b.cfg.reserved0 = 262144                      # round-1 path: operands converted on the fly from fp32
+    b.cfg.tuning = 262144                      # round-1 path: operands converted on the fly from fp32
     b.set_discriminator(a.d_emb.cpu().numpy(), [p.cpu().numpy() for p in a.d_p])
     dev = a.device
     t = lambda x: torch.from_numpy(x.astype(np.int32)).to(dev)
@@ -999,7 +1064,7 @@ def test_fp8_backward_in_operand_format_equals_the_on_the_fly_conversion(hs, nr,
     I = 500
     rng = np.random.default_rng(77)
     a, b = _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8"), _engine(I, "fp32", hs=hs, lr=1e-3, d_precision="fp8")
-    b.cfg.reserved0 = 1 << 19                     # forward from the shadows, backward converts on the fly (the round-2 path)
+    b.cfg.tuning = 1 << 19                     # forward from the shadows, backward converts on the fly (the round-2 path)
     b.set_discriminator(a.d_emb.cpu().numpy(), [p.cpu().numpy() for p in a.d_p])
     dev = a.device
     t = lambda x: torch.from_numpy(x.astype(np.int32)).to(dev)
@@ -1264,7 +1329,7 @@ def test_streaming_decoder_storage_choices_are_bit_identical():
     outs = {}
     for knob in (0, 1 << 22, 1 << 21):
         eng = _engine(I, "bf16", lr=1e-3)
-        eng.cfg.reserved0 = knob
+        eng.cfg.tuning = knob
         eng.set_generator(Hh.gen_to_engine(P))
         dev = eng.device
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
