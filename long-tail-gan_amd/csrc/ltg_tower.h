@@ -65,42 +65,45 @@ __device__ __forceinline__ float ft_tanh(float x) {
 // + column K3 -- the bracket once per row (ft_drop_rows), column K3 once per column, one 64-bit add per element; the two mixing rounds per
 // element.  keep <=> (z >> 40) 2^-24 < kp <=> (z >> 40) < ceil(kp 2^24) (both sides integers below 2^24 + 1; only the top 24 bits of the last
 // product are needed, and the final z ^= z >> 31 does not reach them).  Same bits as ltg_rng_keep.
-// row parts of the 8 rows a lane finishes (C layout: rows 4 q + x of its two 16-row tiles); ONE uniform branch around the batched-tower lookups
-__device__ __forceinline__ void ft_drop_rows(uint64_t (&zrow)[2][4], const DropView& dv, int mrow0, int q, int n, int width, uint64_t seed, uint32_t stream,
-                                             uint64_t step) {
-    const uint64_t k0 = seed ^ ((uint64_t)stream * 0xD6E8FEB86659FD93ull);
-    if (dv.seg_of) {
+// The row parts of the 8 rows a lane finishes (C layout: rows 4 q + x of its two 16-row tiles): the batched tower's lookups (segment -> counter,
+// first row) are requested ONCE at the top of the kernel and serve all three dropout streams.
+struct FtRows {
+    uint64_t st[2][4];      // the row's dropout counter
+    uint32_t rl[2][4];      // the row's number inside its pair batch
+};
+__device__ __forceinline__ FtRows ft_rows(const DropView& dv, int mrow0, int q, int n, uint64_t step) {
+    FtRows R;
+    if (dv.seg_of) {        // (uniform: ONE branch around the lookups)
         int sg[2][4];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int x = 0; x < 4; ++x) sg[tm][x] = dv.seg_of[min(mrow0 + 16 * tm + 4 * q + x, n - 1)];
-        uint64_t st[2][4];
-        int r0[2][4];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                st[tm][x] = dv.seg_step[sg[tm][x]];
-                r0[tm][x] = dv.seg_row0[sg[tm][x]];
-            }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const uint64_t rl = (uint64_t)(min(mrow0 + 16 * tm + 4 * q + x, n - 1) - r0[tm][x]);
-                zrow[tm][x] = k0 + st[tm][x] * 0x94D049BB133111EBull + (rl * (uint64_t)width + 1ull) * 0x9E3779B97F4A7C15ull;
+                R.st[tm][x] = dv.seg_step[sg[tm][x]];
+                R.rl[tm][x] = (uint32_t)(min(mrow0 + 16 * tm + 4 * q + x, n - 1) - dv.seg_row0[sg[tm][x]]);
             }
     } else {
-        const uint64_t ks = k0 + step * 0x94D049BB133111EBull;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const uint64_t rl = (uint64_t)(min(mrow0 + 16 * tm + 4 * q + x, n - 1) + dv.row0);
-                zrow[tm][x] = ks + (rl * (uint64_t)width + 1ull) * 0x9E3779B97F4A7C15ull;
+                R.st[tm][x] = step;
+                R.rl[tm][x] = (uint32_t)(min(mrow0 + 16 * tm + 4 * q + x, n - 1) + dv.row0);
             }
     }
+    return R;
+}
+__device__ __forceinline__ void ft_drop_rows(uint64_t (&zrow)[2][4], const FtRows& R, int width, uint64_t seed, uint32_t stream) {
+    const uint64_t k0 = seed ^ ((uint64_t)stream * 0xD6E8FEB86659FD93ull);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            zrow[tm][x] = k0 + R.st[tm][x] * 0x94D049BB133111EBull + ((uint64_t)R.rl[tm][x] * (uint64_t)width + 1ull) * 0x9E3779B97F4A7C15ull;
 }
 __device__ __forceinline__ bool ft_drop_keep(uint64_t zrow, uint64_t zcol, unsigned thr) {
     uint64_t z = zrow + zcol;
@@ -155,6 +158,17 @@ __global__ __launch_bounds__(FT_NT) void fkt_d_tower(PairView pv, int h0, int h1
     // the K padding of A1 (columns h12 .. 32 KP3 - 1) is read by the last k pair of layer 2
     for (int e = tid; e < FT_BM * (32 * KP3 - h12); e += FT_NT) A1s[(e / (32 * KP3 - h12)) * LDA + h12 + e % (32 * KP3 - h12)] = 0.f;
 
+    // the dropout draws' row lookups: requested first, consumed by the epilogues (their round trips overlap the gather's)
+    FtRows R;
+    if constexpr (!INJ) R = ft_rows(dA, m0 + 32 * mh, q, n, step);
+    // layer 2's first B fragments do not depend on layer 1 either
+    const int ng = w >> 1;
+    const int nt3 = (h3 + 15) / 16;
+    const ltg_ft_u32x4* wb3 = wsp + (size_t)(((h1 + 15) / 16) + ((h2 + 15) / 16)) * KP1 * 3 * 64 + lane;
+    int tl[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) tl[j] = min(ng * NTW + j, nt3 - 1);       // (tiles beyond the last one recompute it; their results are dropped)
+
     // ---- layer 1: A1 = dropout(tanh(E . w + b)), this wave's 32 rows x its half of one branch's columns
     {
         const bool br = w >= 4;
@@ -166,6 +180,16 @@ __global__ __launch_bounds__(FT_NT) void fkt_d_tower(PairView pv, int h0, int h1
         const DropView& dv = br ? dB : dA;
         const uint32_t stream = br ? LTG_STREAM_D_DROP_B : LTG_STREAM_D_DROP_A;
         const ltg_ft_u32x4* wb = wsp + (size_t)(br ? ((h1 + 15) / 16) * KP1 : 0) * 3 * 64 + lane;
+        // ONE B fragment set, refilled for the next tile as soon as this tile's MFMAs are issued: in flight under the epilogue
+        ltg_ft_u32x4 bf[FT_KP1_MAX][3];
+        auto load_b = [&] __device__(int t) {
+            const int tc = min(t, t1 - 1);
+#pragma unroll
+            for (int p = 0; p < FT_KP1_MAX; ++p)
+#pragma unroll
+                for (int tt = 0; tt < NTERM; ++tt) bf[p][tt] = wb[((size_t)tc * KP1 + min(p, KP1 - 1)) * 3 * 64 + tt * 64];
+        };
+        load_b(t0);
         // A fragments: the embedding rows of this lane's two operand rows, split, all k pairs
         ltg_ft_u32x4 af[2][FT_KP1_MAX][3];
         {
@@ -195,23 +219,19 @@ __global__ __launch_bounds__(FT_NT) void fkt_d_tower(PairView pv, int h0, int h1
                     ft_split_frag<SPL>(x[0], x[1], af[tm][p]);
                 }
         }
-        // the dropout counters' row parts of the 8 rows this lane finishes (C layout: row 4 q + x of each 16-row tile)
         uint64_t zrow[2][4];
-        if constexpr (!INJ) ft_drop_rows(zrow, dv, m0 + 32 * mh, q, n, Nb, seed, stream, step);
-        for (int t = t0; t < t1; ++t) {
-            ltg_ft_u32x4 bf[FT_KP1_MAX][3];
+        if constexpr (!INJ) ft_drop_rows(zrow, R, Nb, seed, stream);
+        auto product = [&] __device__(ltg_f32x4 (&acc)[2]) {       // (k pairs beyond h0 multiply zeroed A fragments: no branch)
+            acc[0] = acc[1] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < FT_KP1_MAX; ++p)
 #pragma unroll
-                for (int tt = 0; tt < NTERM; ++tt) bf[p][tt] = wb[((size_t)t * KP1 + min(p, KP1 - 1)) * 3 * 64 + tt * 64];
+                for (int tm = 0; tm < 2; ++tm) ft_mfma_terms<SPL>(acc[tm], af[tm][p], bf[p]);
+        };
+        auto finish = [&] __device__(const ltg_f32x4 (&acc)[2], int t) {
             const int col = 16 * t + r, cc = min(col, Nb - 1);
             const float bv = bias[cc];
             const uint64_t zcol = (uint64_t)cc * 0x9E3779B97F4A7C15ull;
-            ltg_f32x4 acc[2] = {ltg_f32x4{0.f, 0.f, 0.f, 0.f}, ltg_f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int p = 0; p < FT_KP1_MAX; ++p)       // (k pairs beyond h0 multiply zeroed A fragments: no branch in the loop)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) ft_mfma_terms<SPL>(acc[tm], af[tm][p], bf[p]);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -223,18 +243,38 @@ __global__ __launch_bounds__(FT_NT) void fkt_d_tower(PairView pv, int h0, int h1
                     else kp = ft_drop_keep(zrow[tm][x], zcol, thr);
                     if (col < Nb) A1s[row * LDA + coff + col] = (kp && m < n) ? tv * inv_keep : 0.f;
                 }
+        };
+        // tile t + 1's MFMAs are issued in front of tile t's epilogue (the matrix pipe works under the epilogue's vector instructions), the B
+        // fragments of tile t + 2 are requested behind them
+        if (t0 < t1) {
+            ltg_f32x4 accA[2], accB[2];
+            product(accA);
+            load_b(t0 + 1);
+            for (int t = t0; t < t1; t += 2) {
+                product(accB);
+                load_b(t + 2);
+                finish(accA, t);
+                if (t + 1 < t1) {
+                    product(accA);
+                    load_b(t + 3);
+                    finish(accB, t + 1);
+                }
+            }
         }
     }
+    // layer 2's B fragments of the first TWO k pairs: in flight across the barrier
+    ltg_ft_u32x4 bfe[NTW][3], bfo[NTW][3];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int tt = 0; tt < NTERM; ++tt) {
+            bfe[j][tt] = wb3[((size_t)tl[j] * KP3) * 3 * 64 + tt * 64];
+            bfo[j][tt] = wb3[((size_t)tl[j] * KP3 + min(1, KP3 - 1)) * 3 * 64 + tt * 64];
+        }
     __syncthreads();
 
     // ---- layer 2: A3 = dropout(tanh(A1 . w3 + b3)), reduced against w4 on the way out
     {
-        const int ng = w >> 1;
-        const int nt3 = (h3 + 15) / 16;
-        const ltg_ft_u32x4* wb = wsp + (size_t)(((h1 + 15) / 16) + ((h2 + 15) / 16)) * KP1 * 3 * 64 + lane;
-        int tl[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) tl[j] = min(ng * NTW + j, nt3 - 1);       // (tiles beyond the last one recompute it; their results are dropped)
         ltg_f32x4 acc[2][NTW];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -243,32 +283,31 @@ __global__ __launch_bounds__(FT_NT) void fkt_d_tower(PairView pv, int h0, int h1
         const float* arow[2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) arow[tm] = A1s + (32 * mh + 16 * tm + r) * LDA + 8 * q;
-        // ONE fragment set, refilled tile by tile: the requests of k pair p + 1 for tile j go out as soon as tile j's MFMAs of pair p are issued,
-        // so they are in flight under the MFMAs of the other tiles and of the next A split (two sets in turn cost 120 registers and spilled)
-        ltg_ft_u32x4 bf[NTW][3];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int tt = 0; tt < NTERM; ++tt) bf[j][tt] = wb[((size_t)tl[j] * KP3) * 3 * 64 + tt * 64];
-        for (int p = 0; p < KP3; ++p) {
+        // TWO fragment sets (even / odd k pairs), each refilled tile by tile for pair p + 2 as soon as the tile's MFMAs of pair p are issued: a
+        // request has two k pairs of MFMAs (~2 000 cycles) to land
+        auto block = [&] __device__(ltg_ft_u32x4 (&bf)[NTW][3], int p) {
             ltg_ft_u32x4 af[2][3];
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 const ltg_f32x4 x0 = *reinterpret_cast<const ltg_f32x4*>(arow[tm] + 32 * p), x1 = *reinterpret_cast<const ltg_f32x4*>(arow[tm] + 32 * p + 4);
                 ft_split_frag<SPL>(x0, x1, af[tm]);
             }
-            const int pn = min(p + 1, KP3 - 1);
+            const int pn = min(p + 2, KP3 - 1);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) ft_mfma_terms<SPL>(acc[tm][j], af[tm], bf[j]);
 #pragma unroll
-                for (int tt = 0; tt < NTERM; ++tt) bf[j][tt] = wb[((size_t)tl[j] * KP3 + pn) * 3 * 64 + tt * 64];
+                for (int tt = 0; tt < NTERM; ++tt) bf[j][tt] = wb3[((size_t)tl[j] * KP3 + pn) * 3 * 64 + tt * 64];
             }
+        };
+        for (int p = 0; p < KP3; p += 2) {
+            block(bfe, p);
+            if (p + 1 < KP3) block(bfo, p + 1);
         }
         // epilogue: this wave column's share of A3[row] . w4 for its 32 rows
         uint64_t zrow[2][4];
-        if constexpr (!INJ) ft_drop_rows(zrow, dC, m0 + 32 * mh, q, n, h3, seed, LTG_STREAM_D_DROP_C, step);
+        if constexpr (!INJ) ft_drop_rows(zrow, R, h3, seed, LTG_STREAM_D_DROP_C);
         float pd[2][4];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -278,7 +317,7 @@ __global__ __launch_bounds__(FT_NT) void fkt_d_tower(PairView pv, int h0, int h1
         for (int j = 0; j < NTW; ++j) {
             const int col = 16 * (ng * NTW + j) + r, cc = min(col, h3 - 1);
             const bool cok = ng * NTW + j < nt3 && col < h3;
-            const float bv = b3[cc], wv = cok ? w4[cc] : 0.f;
+            const float bv = b3[cc], w4v = w4[cc], wv = cok ? w4v : 0.f;
             const uint64_t zcol = (uint64_t)cc * 0x9E3779B97F4A7C15ull;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)

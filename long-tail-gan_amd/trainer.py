@@ -29,7 +29,10 @@ TOWER_PAIRS = 1 << 17              # fake pairs per launch of the batched fake t
 
 class Trainer:
     def __init__(self, engine: Engine, data: DeviceData, num_sub_epochs=10, gan_lambda=1.0, total_anneal_steps=20000,
-                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None, batched_tower=None, pipe_step=None):
+                 anneal_cap=0.2, vae_keep=0.75, d_keep=0.7, shuffle_seed=0, span_create=None, batched_tower=None, pipe_step=None, step_log=0):
+        """step_log = n: the losses of the FIRST n steps of every D phase and G phase are kept one row per step (d_step_log [n, 8]: d_loss;
+        g_step_log [n, 8]: g_loss, vae_loss, gan_loss) -- what SURVEY 8/d6's per-step parity gate compares (tests/test_gpu_trajectory.py).  The
+        per-sub-epoch rows d_losses / g_losses (the reference prints the sub-epoch's LAST step: train.py:300-303, :326-329) are unaffected."""
         self.eng, self.data = engine, data
         if span_create is None:
             span_create = os.environ.get("LTGAN_SPAN_CREATE", "1") != "0"    # measurement switch
@@ -71,6 +74,9 @@ class Trainer:
         self.d_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
         self.g_losses = torch.zeros(max(1, self.S), 8, dtype=torch.float32, device=dev)
         self.probe_hook = None                       # bench.py: (kind, batch) -> ltg_probe or None
+        self.step_log = int(step_log)
+        self.d_step_log = torch.zeros(max(1, self.step_log), 8, dtype=torch.float32, device=dev)
+        self.g_step_log = torch.zeros(max(1, self.step_log), 8, dtype=torch.float32, device=dev)
 
     def _step(self):
         self.rng_step += 1
@@ -110,11 +116,17 @@ class Trainer:
         d, eng = self.data, self.eng
         eng.pin_stream()
         try:
+            i = 0
             for j in range(self.S):
-                for k in self.order:
+                for n, k in enumerate(self.order):
                     v = d.view(self.active[k])
                     pr = self.probe_hook("d", self.active[k]) if self.probe_hook else None
-                    eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(), loss_out=self.d_losses[j], probe=pr)
+                    logged = i < self.step_log                   # (a logged step that ends its sub-epoch is copied into the sub-epoch's row)
+                    eng.d_step(v["real"], v["fake"], keep_prob=self.d_keep, rng_step=self._step(),
+                               loss_out=self.d_step_log[i] if logged else self.d_losses[j], probe=pr)
+                    if logged and n == len(self.order) - 1:
+                        self.d_losses[j].copy_(self.d_step_log[i])
+                    i += 1
         finally:
             eng.pin_stream(False)           # (also when a step raised: nothing may stay pinned to a stale stream handle)
         if eng._dfork is not None and eng.check_on_flush:
@@ -170,9 +182,10 @@ class Trainer:
             eng.q0_defer = False
             eng.pin_stream(False)
 
-    def _g_one(self, j, b, v, a):
+    def _g_one(self, j, b, v, a, loss_out=None):
         """one generator update (train.py:326) of batch b in sub-epoch j"""
         d, eng = self.data, self.eng
+        loss_out = self.g_losses[j] if loss_out is None else loss_out
         rs, ds = self._step(), self._step()
         if self.batched_tower and ds != self._tower_steps[j, b]:
             raise RuntimeError("the fake tower of this step was evaluated ahead with another RNG counter")
@@ -180,12 +193,12 @@ class Trainer:
         if self.pipe is not None:
             go = eng.g_opts(d.fake_cnt[b:], a, self.lam, self.vae_keep, 1.0, self.d_keep, rs, ds, probe=pr,
                             y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
-            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j],
+            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=loss_out,
                                next_batch=getattr(self, "_next_batch", None))
         else:
             eng.g_step(v["batch"], v["fake"], self.acts, d.fake_cnt[b:], anneal=a, gan_lambda=self.lam,
                        keep_prob=self.vae_keep, is_training=1.0, d_keep_prob=self.d_keep, rng_step=rs,
-                       d_rng_step=ds, loss_out=self.g_losses[j], probe=pr,
+                       d_rng_step=ds, loss_out=loss_out, probe=pr,
                        y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
 
     def g_phase(self):
@@ -195,6 +208,7 @@ class Trainer:
         try:
             self._tower_ahead()        # every fake tower of the phase in a few large launches
             seq = [self.active[k] for k in self.order]
+            i = 0
             for j in range(self.S):
                 a = self.anneal()
                 for n, b in enumerate(seq):
@@ -203,7 +217,11 @@ class Trainer:
                     # the batch of the NEXT step (known: the phase's order is fixed): its rows of W_q0 are caught up during this one
                     nb = seq[n + 1] if n + 1 < len(seq) else (seq[0] if j + 1 < self.S else None)
                     self._next_batch = d.view(nb)["batch"] if nb is not None else None
-                    self._g_one(j, b, d.view(b), a)
+                    logged = i < self.step_log
+                    self._g_one(j, b, d.view(b), a, loss_out=self.g_step_log[i] if logged else None)
+                    if logged and n == len(seq) - 1:
+                        self.g_losses[j].copy_(self.g_step_log[i])
+                    i += 1
                 self.last_anneal.append(a)
             ok = True
         finally:

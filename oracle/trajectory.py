@@ -24,6 +24,7 @@ class OracleTrainer:
         self.n_batches = nb if n_batches is None else min(nb, n_batches)
         self.I = idx.n_items
         self.fake = {}
+        self.d_log, self.g_log = [], []      # every step of the LAST phase: d_loss / (g_loss, vae_loss, gan_loss, anneal) (train.py:300, :326)
 
     def _step(self):
         self.rng_step += 1
@@ -118,6 +119,7 @@ class OracleTrainer:
     def d_phase(self):
         out = []
         hs = self.hs
+        self.d_log = []
         for j in range(self.S):
             loss = None
             for k in self.order:
@@ -134,16 +136,21 @@ class OracleTrainer:
                 gr = O.d_tower_backward(self.D, Tr, [m[:nr] for m in dm], 0.7, -(1 - Tr["y"]))
                 gf = O.d_tower_backward(self.D, Tf, [m[nr:] for m in dm], 0.7, Tf["y"] * vf)
                 self.adam.apply(self.D, {k2: gr[k2] + gf[k2] for k2 in gr}, O.D_KEYS)
+                self.d_log.append(loss)
             out.append(loss)
         return out
 
     # ------------------------------------------------------------------ phase G
-    def g_phase(self):
+    def g_phase(self, max_steps=None):
+        """max_steps: stop after that many generator updates (a fixture that only needs the phase's first steps)"""
         out = []
         hs = self.hs
+        self.g_log = []
         for j in range(self.S):
             last = None
             for k in self.order:
+                if max_steps is not None and len(self.g_log) >= max_steps:
+                    return out
                 b = self.active[k]
                 anneal = O.anneal_value(self.update_count)
                 self.update_count += 1
@@ -162,6 +169,7 @@ class OracleTrainer:
                                                   1.0, np.float64, self.quant)
                 self.adam.apply(self.P, g, O.G_KEYS)
                 last = (losses["g_loss"], losses["vae_loss"], losses["gan_loss"], anneal)
+                self.g_log.append(last)
             out.append(last)
         return out
 

@@ -134,6 +134,23 @@ def test_bench_contract_one_json_line():
     ow = d["other_workloads"]
     assert ow["c3"]["items"] == 20000 and ow["c4"]["items"] == 200000 and ow["c3"]["value"] > 0 and ow["c4"]["value"] > 0
     assert ow["c4"]["dominant_kernel"]["bound"] == "hbm" and 0 < ow["c4"]["dominant_kernel"]["frac"] < 1
+    # round 6: the arithmetic of the discriminator's products is named; `frac` follows from the tracked rocprofv3 summary when there is one
+    # (both durations in the line); the dominant kernel BY TOTAL TIME of that summary with its own fraction; the per-rank proxy of an 8-GPU
+    # run on RCCL at world size 1 and the scaling bound it gives
+    assert d["config"]["d_arith"] in ("fp32", "bf16x6", "bf16x4")
+    assert r["avg_us_event_bracket"] > 0 and "avg_us_rocprof" in r and "frac_source" in r
+    if r["avg_us_rocprof"]:
+        assert abs(r["frac"] - (r["algorithmic_bytes"] if r["bound"] == "hbm" else r["algorithmic_flops"]) / (r["avg_us_rocprof"] * 1e-6) /
+                   (r["peak"] * (1e9 if r["bound"] == "hbm" else 1e12))) < 1e-6
+        dom = r["dominant_by_total_time"]
+        assert dom["kernel"] not in ("k_gate_wait", "k_gate_set") and 0 < dom["share_of_kernel_time"] < 1 and 0 < dom["frac"] < 1
+    rp = ow["rank_proxy"]
+    assert "error" not in rp, rp
+    assert rp["items"] == 25024 and rp["one_call"] and rp["transport"] == "rccl-direct" and rp["rccl_ranks"] == 1
+    assert rp["g_step_us"] > 0 and rp["d_step_us"] > 0 and set(rp["exchanges_us"]) == {"exch_h1", "exch_rowpart", "exch_dh2"}
+    assert 0 < rp["step_frac_of_copy_ceiling"] < 1.2
+    want = (ow["c4"]["g_step_us"] + ow["c4"]["d_step_us"]) / (rp["g_step_us"] + rp["d_step_us"])
+    assert abs(d["projected_strong_scaling_8gpu_upper_bound"] - want) < 1e-9 and 1 < want < 8
 
 
 def test_bench_two_ranks_item_sharded():

@@ -61,6 +61,52 @@ def test_two_epoch_trajectory_matches_oracle(tmp_path):
     np.testing.assert_allclose(eng.d_p[6].cpu().numpy()[:64], gold["final_w4_head"], atol=5e-4)
 
 
+def test_first_fifty_steps_of_each_phase_match_oracle(tmp_path):
+    """SURVEY 8/d6 literally: the loss of EACH of the first 50 discriminator updates and the loss triplet of EACH of the first 50 generator
+    updates of global epoch 0 under config.ini's schedule (S = 10: the 50 G steps sit behind all 1 010 D steps; train.py:287-329) against
+    tests/golden/oracle_trajectory_steps.npz (tests/golden/make_trajectory_steps.py) at 1e-3 relative -- a drift that cancels by the sub-epoch's
+    last step (what the two-epoch test compares) would show here."""
+    import torch
+    import helpers as Hh
+    from ltgan.dataset import DeviceData, IndexData, materialize_askubuntu
+    from ltgan.engine import Engine
+    from ltgan.trainer import Trainer
+    gold = np.load(os.path.join(G, "oracle_trajectory_steps.npz"))
+    d = str(tmp_path / "ds")
+    materialize_askubuntu(os.path.join(G, "askubuntu_raw.npz"), d)
+    idx = IndexData.from_dir(d)
+    hs = tuple(int(x) for x in gold["hs"])
+    n = int(gold["n_steps"])
+    eng = Engine(idx.n_items, h_sizes=hs, lr=float(gold["lr"]), precision="bf16", seed=int(gold["seed"]))
+    eng.set_generator(Hh.gen_to_engine(O.init_generator(idx.n_items, seed=int(gold["gen_seed"]))))
+    emb, darr = Hh.disc_to_engine(O.init_discriminator(idx.n_items, *hs, seed=int(gold["disc_seed"])))
+    eng.set_discriminator(emb, darr)
+    data = DeviceData(idx, 100, eng.device)
+    tr = Trainer(eng, data, num_sub_epochs=int(gold["S"]), shuffle_seed=0, step_log=n)
+    tr.create_phase()
+    cnt = data.fake_cnt.cpu().numpy()
+    assert np.abs(cnt - gold["cnt"]).sum() <= 2                      # sampler flips are rare
+    gen = data.fake_gen.cpu().numpy()
+    same = np.array_equal(np.sort(gen[gen >= 0]), np.sort(gold["fake_gen"].astype(np.int64)))
+    assert np.array_equal(tr.order, gold["order"])
+    tol = 1e-3 if same else 3e-3
+    sub = tr.d_phase().cpu().numpy()[:, 0]
+    dl = tr.d_step_log.cpu().numpy()[:n, 0]
+    assert len(tr.order) * tr.S == int(gold["d_steps_total"])
+    err_d = np.max(np.abs(dl - gold["d_loss_steps"]) / np.abs(gold["d_loss_steps"]))
+    np.testing.assert_allclose(dl, gold["d_loss_steps"], rtol=tol)
+    np.testing.assert_allclose(sub, gold["d_loss_sub_epochs"], rtol=tol)       # every sub-epoch's last step too
+    tr.g_phase()
+    gl = tr.g_step_log.cpu().numpy()[:n, :3]
+    want = gold["g_loss_steps"]
+    err_g = np.max(np.abs(gl[:, :2] - want[:, :2]) / np.abs(want[:, :2]))
+    print("first %d steps, same fake pairs %s: worst relative error d_loss %.2e, g / vae loss %.2e, gan loss %.2e" %
+          (n, same, err_d, err_g, np.max(np.abs(gl[:, 2] - want[:, 2]) / np.maximum(np.abs(want[:, 2]), 1e-5))))
+    np.testing.assert_allclose(gl[:, 0], want[:, 0], rtol=tol)
+    np.testing.assert_allclose(gl[:, 1], want[:, 1], rtol=tol)
+    np.testing.assert_allclose(gl[:, 2], want[:, 2], rtol=5 * tol, atol=1e-5)  # small-magnitude GAN term (as in the two-epoch test)
+
+
 @pytest.mark.parametrize("workload,users,hs", [("custom:1000", 450, (20, 24, 40, 36)), ("custom:8264", 230, (20, 24, 40, 36)),
                                                ("custom:1000", 450, (100, 150, 250, 300))])     # config.ini's sizes: the LDS-staged tower kernels
 def test_hoisted_phase_work_is_bit_identical_to_the_step_by_step_loop(workload, users, hs):
