@@ -58,16 +58,21 @@ typedef struct ltg_config {
     int32_t d_feat;  /* FEATURE_LEN: rows of the frozen embedding table */
     int32_t d_h0, d_h1, d_h2, d_h3;
     int32_t precision; /* LTG_PREC_* */
-    /* kernel tuning knob for A/B measurements, 0 = auto (every setting computes the same function):
-     *   bits 0-3   decoder weight-gradient kernel: 1..4 = tile variant 0..3 of the generic kernel, 9 = no streaming kernels
-     *   bits 10-12 discriminator tiles: 1 = scalar loaders, 2 = all 64 x 64, 3 = all 128 x 128
-     *   bit 13 / 15 / 16  scalar instead of 16-byte loaders: middle layers / embedding gathers / small-item decoder kernels
-     *   bit 9  no fake-tower fork onto the aux stream;
-     *   bit 14 column-blocked sparse W_q0 gradient; bit 18 the round-1 kernels instead of csrc/ltg_fast.h; bit 19 / 24 fp8 discriminator:
-     *   backward converts on the fly / register-resident forward tiles; bits 21 / 22 softmax statistics from a second pass / fp32 dlogits;
-     *   bit 23 register-resident forward-only towers; bit 25 sparse gradient and Adam as two launches; bits 27-30 = k: the streaming
-     *   weight update with 256 - 8 k workgroups; bit 26 / 17: the streaming decoder forward's first form at every size / its second form
-     *   (h2 resident in LDS, per-wave item tiles; default from 65 536 items) from 8 192 items */
+    /* kernel selection knob, 0 = auto; every setting computes the same function (ABI v14: was `reserved0`).
+     * STABLE bits -- the host layer and the parity tests select code paths with them:
+     *   bit 18  the generic (round-1, LDS-staged, any size) kernels instead of the latency path of csrc/ltg_fast.h
+     *   bit 17 / 26  the streaming decoder forward: its second form (h2 resident in LDS, per-wave item tiles; default from 65 536 items) from
+     *           8 192 items / its first form at every size
+     *   bit 19  fp8 discriminator: the backward converts its operands on the fly (instead of operand-format storage)
+     *   bit 20  the forward-only tower as three launches (fks_d_l1 -> fks_d_l2 -> fk_d_y) instead of the one-kernel tower of csrc/ltg_tower.h
+     *   bit 21 / 22  softmax statistics from a second pass over the logits / fp32 instead of bf16 dlogits on the streaming path
+     * MEASUREMENT bits -- A/B switches of closed or running experiments (profiles/README.md); they may go without an ABI bump:
+     *   bits 0-3 decoder weight-gradient kernel (1..4 = tile variant of the generic kernel, 9 = no streaming kernels); bit 6 no fork of the D
+     *   step's backward jobs; bit 9 no fake-tower fork; bits 10-12 discriminator tiles (1 scalar loaders, 2 all 64 x 64, 3 all 128 x 128);
+     *   bit 13 / 15 / 16 scalar instead of 16-byte loaders (middle layers / embedding gathers / small-item decoder kernels); bit 14 column-blocked
+     *   sparse W_q0 gradient; bit 24 fp8 register-resident forward tiles; bit 25 sparse gradient and Adam as two launches; bits 27-30 = k: the
+     *   streaming weight update with 256 - 8 k workgroups.
+     * (bit 23, the register-resident forward-only towers, is gone: the one-kernel tower superseded the experiment.) */
     int32_t tuning;
     /* item shard of this rank: it owns global items [item_lo, item_lo + n_items); n_items_global = 0 means
      * unsharded (n_items_global = n_items, item_lo = 0).  W_q0 / W_p1t / b_p1 and their Adam moments hold

@@ -165,2731 +165,12 @@ __global__ __launch_bounds__(64) void k_gate_set(LtgGate g, LtgGate g2 = LTG_NO_
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Generator forward
-// ---------------------------------------------------------------------------------------------
-
-// enc-0 as a sparse row gather-sum (MultiVAE.py:148-155): h1 = tanh(dropout(l2norm(x)) . W_q0 + b).
-// One 1024-thread workgroup per user row.  The row's (item, value*keep) list is staged through LDS;
-// the 16 waves split the row's entries (so a 900-item history does not serialise on one wave), each
-// lane owning float4 column chunks of the gathered W_q0 rows (coalesced 16-B loads); the wave
-// partials meet in LDS.
-constexpr int ENC_NT = 1024;
-constexpr int ENC_NW = ENC_NT / 64;
-__global__ __launch_bounds__(ENC_NT) void k_enc0_fwd(int H, int I, const int32_t* __restrict__ indptr,
-                                                     const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                     const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed,
-                                                     uint64_t step, const float* __restrict__ Wq0,
-                                                     const float* __restrict__ bq0, float* __restrict__ h1,
-                                                     float* __restrict__ row_scale, const float* __restrict__ row_norm2,
-                                                     int item_lo, int Ig, int pre_only, int rps) {
-    // item shard: `indices` are LOCAL item ids of this rank's slab [item_lo, item_lo + I); the dropout
-    // RNG is keyed by the GLOBAL id so every shard draws the mask the unsharded run draws; row_norm2
-    // (sum x^2 over the FULL row) replaces the local sum; pre_only writes the partial pre-activation
-    // (no bias, no tanh) that the ranks all-reduce.
-    extern __shared__ __attribute__((aligned(16))) float s_part[];  // [ENC_NW][H]
-    __shared__ int s_idx[ENC_NT];
-    __shared__ float s_val[ENC_NT];
-    __shared__ float red[ENC_NW];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint64_t kb = rps > 0 ? (uint64_t)(b % rps) : (uint64_t)b;   // several batches in one launch (ltg_fwd_opts.rows_per_step)
-    step += rps > 0 ? (uint64_t)(b / rps) : 0;
-    const int beg = indptr[b], end = indptr[b + 1];
-    float ss = 0.f;
-    for (int e = beg + tid; e < end; e += ENC_NT) {
-        const float v = values ? values[e] : 1.f;
-        ss += v * v;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if (lane == 0) red[w] = ss;
-    __syncthreads();
-    ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < ENC_NW; ++i) ss += red[i];
-    if (row_norm2) ss = row_norm2[b];
-    const float scale = 1.f / (keep * sqrtf(fmaxf(ss, 1e-12f)));  // l2_normalize eps, then /keep
-    if (tid == 0) row_scale[b] = scale;
-    const int H4 = H >> 2;
-    constexpr int MAXQ = 4;  // H <= 1024
-    float4 acc[MAXQ];
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c0 = beg; c0 < end; c0 += ENC_NT) {
-        __syncthreads();
-        const int e = c0 + tid;
-        if (e < end) {
-            const int it = indices[e];
-            const float v = values ? values[e] : 1.f;
-            const bool kp = drop_keep ? (drop_keep[e] != 0)
-                                      : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, kb * (uint64_t)Ig + item_lo + it, keep);
-            s_idx[tid] = it;
-            s_val[tid] = kp ? v : 0.f;
-        }
-        __syncthreads();
-        const int cnt = min(ENC_NT, end - c0);
-        // 4 entries per trip: their W_q0 row loads are independent, so 4 x MAXQ float4 loads are in flight
-        for (int j = w; j < cnt; j += 4 * ENC_NW) {
-            float v[4];
-            const float4* wr[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ju = j + u * ENC_NW;
-                const bool ok = ju < cnt;
-                v[u] = ok ? s_val[ju] : 0.f;
-                wr[u] = reinterpret_cast<const float4*>(Wq0 + (size_t)s_idx[ok ? ju : j] * H);
-            }
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int c4 = lane + 64 * q;
-                if (c4 < H4) {
-                    float4 x[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) x[u] = wr[u][c4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc[q].x += v[u] * x[u].x;
-                        acc[q].y += v[u] * x[u].y;
-                        acc[q].z += v[u] * x[u].z;
-                        acc[q].w += v[u] * x[u].w;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int c4 = lane + 64 * q;
-        if (c4 < H4) reinterpret_cast<float4*>(s_part + (size_t)w * H)[c4] = acc[q];
-    }
-    __syncthreads();
-    for (int c = tid; c < H; c += ENC_NT) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < ENC_NW; ++i) t += s_part[(size_t)i * H + c];
-        h1[(size_t)b * H + c] = pre_only ? t * scale : tanhf(t * scale + bq0[c]);
-    }
-}
-
-// h1 = tanh(h1_pre + b) after the partial pre-activations of the item shards were all-reduced
-__global__ __launch_bounds__(NT) void k_bias_tanh(int n, int H, const float* __restrict__ bias, float* __restrict__ h) {
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) h[i] = tanhf(h[i] + bias[i % H]);
-}
-
-// float4 of 4 consecutive floats at p[i .. i+3], zero where i + j >= n (n % 4 == 0 at every call site, so a group is
-// either whole or absent; the address is clamped, the load unconditional)
-__device__ __forceinline__ float4 ltg_ld4(const float* __restrict__ p, int i, int n, bool ok) {
-    const float4 v = *reinterpret_cast<const float4*>(p + min(i, n - 4));
-    const bool k = ok && i < n;
-    return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
-}
-
-// Generic dense layer  C = act(A[M][K] . B[K][N] + bias)  (fp32 MFMA); act: 0 none, 1 tanh.
-// Serves enc-1 (MultiVAE.py:152) and dec-0 (MultiVAE.py:168-172).
-template <int ACT, bool V, int BKV = 128>
-__global__ __launch_bounds__(NT) void k_dense_fwd(int M, int N, int K, const float* __restrict__ A,
-                                                  const float* __restrict__ Bw, const float* __restrict__ bias,
-                                                  float* __restrict__ C) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return A[(size_t)m * K + k]; };
-    auto b = [=] __device__(int k, int n) -> float { return Bw[(size_t)k * N + n]; };
-    auto epi = [=] __device__(int m, int n, float acc) {
-        const float x = acc + bias[n];
-        C[(size_t)m * N + n] = ACT == 1 ? tanhf(x) : x;
-    };
-    if constexpr (V) {   // 16-B loads (K % 4 == 0, N % 4 == 0): same MFMA sequence, a quarter of the load instructions
-        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A + (size_t)min(m, M - 1) * K, k, K, m < M); };
-        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Bw + (size_t)min(k, K - 1) * N, n, N, k < K); };
-        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, true, false, 0, 0, 3>(M, N, m0, n0, 0, K, a4, b4, epi);
-    } else {
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, true>(M, N, m0, n0, 0, K, a, b, epi);
-    }
-}
-
-// Reparameterisation + KL (MultiVAE.py:157-162, :178-181).
-__global__ __launch_bounds__(NT) void k_reparam(int Z, const float* __restrict__ mulv, const float* __restrict__ eps_in,
-                                                float is_training, uint64_t seed, uint64_t step,
-                                                float* __restrict__ z, float* __restrict__ kl_rows) {
-    __shared__ float red[NT / 64];
-    const int b = blockIdx.x;
-    float kl = 0.f;
-    for (int j = threadIdx.x; j < Z; j += NT) {
-        const float mu = mulv[(size_t)b * 2 * Z + j], lv = mulv[(size_t)b * 2 * Z + Z + j];
-        const float sd = expf(0.5f * lv);
-        kl += 0.5f * (-lv + expf(lv) + mu * mu - 1.f);
-        float e = 0.f;
-        if (is_training != 0.f)
-            e = eps_in ? eps_in[(size_t)b * Z + j] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)b * Z + j);
-        z[(size_t)b * Z + j] = mu + is_training * e * sd;
-    }
-    kl = block_sum(kl, red);
-    if (threadIdx.x == 0) kl_rows[b] = kl;
-}
-
-// dec-1 (MultiVAE.py:169): logits[b][i] = h2[b][:] . W_p1t[i][:] + b_p1[i]; the big GEMM.
-template <bool BF16, bool BIG, bool V = false>
-__global__ __launch_bounds__(NT) void k_dec1_fwd(int M, int I, int H, const float* __restrict__ h2,
-                                                 const float* __restrict__ Wp1t, const float* __restrict__ bp1,
-                                                 float* __restrict__ logits) {
-    // BIG: 128 x 64 tiles (a whole training batch per tile: W_p1t leaves HBM once); small item counts
-    // use 32 x 32 tiles to spread the few tiles over more CUs.
-    constexpr int BM = BIG ? 128 : 32, BN = BIG ? 64 : 32;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    auto a = [=] __device__(int m, int k) -> float { return h2[(size_t)m * H + k]; };
-    auto b = [=] __device__(int k, int n) -> float { return Wp1t[(size_t)n * H + k]; };
-    auto epi = [=] __device__(int m, int n, float acc) { logits[(size_t)m * I + n] = acc + bp1[n]; };
-    if constexpr (V) {   // 16-B loaders (H % 4 == 0)
-        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(h2 + (size_t)min(m, M - 1) * H, k, H, m < M); };
-        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp1t + (size_t)min(n, I - 1) * H, k, H, n < I); };
-        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false, false, 0, 0, 3>(M, I, m0, n0, 0, H, a4, b4, epi);
-    } else {
-        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, false>(M, I, m0, n0, 0, H, a, b, epi);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Streaming decoder kernels for large item counts (training batch <= 128 rows, H <= 608, bf16 MFMA).
-// Both read W_p1t exactly once from HBM with 16-B loads, convert to bf16 on the fly into a double-
-// buffered LDS tile of 32 items, and keep the small operand stationary in registers:
-//   k_dec1_fwd_stream : h2 fragments stationary (each of the 8 waves owns 16 batch rows),
-//                       logits[b][i] = h2[b][:] . W_p1t[i][:] + b_p1[i]
-//   k_dh2_stream      : the [16 rows x 608] accumulator of each wave stationary over its item chunk,
-//                       dh2[b][:] += dlog[b][i] * W_p1t[i][:]; W is consumed TRANSPOSED straight from its
-//                       row-major LDS image by ds_read_b64_tr_b16 (no transposing stores)
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) short ltg_s16x4;
-constexpr int ST_NT = 512;      // 8 waves
-constexpr int ST_BN = 32;       // items per LDS tile
-constexpr int ST_KP = 608;      // K padded to 19 x 32
-constexpr int ST_LDW = 616;     // LDS row stride in bf16 (1232 B: 16-B aligned rows, conflict-free fragment reads)
-constexpr int ST_KS = ST_KP / 32;
-
-// A wave-uniform GLOBAL pointer pinned to SGPRs: `ltg_uniform_ptr(base + uniform) + (unsigned)lane_offset` selects the
-// scalar-base form of global_load/store (one 32-bit VGPR offset) instead of a 64-bit VGPR address per access.
-typedef char __attribute__((address_space(1))) ltg_gchar;
-typedef unsigned ltg_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ ltg_gchar* ltg_uniform_ptr(const void* p) {
-    const uint64_t x = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-    return (ltg_gchar*)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ uint2 ltg_pack4(float4 v) {
-    return make_uint2((unsigned)ltg_f2bf(v.x) | ((unsigned)ltg_f2bf(v.y) << 16), (unsigned)ltg_f2bf(v.z) | ((unsigned)ltg_f2bf(v.w) << 16));
-}
-
-// The streaming kernels read the bf16 SHADOW of W_p1t ([I][ST_KP] bf16, K padded with zeros, maintained by the
-// Adam epilogue of k_dec1_bwd_adam): 1216 B per item instead of 2400, no conversion on the hot path.
-// global -> registers for one 32-item tile: 16 threads walk one item row in 256-B steps, 5 x 16 B per thread.
-constexpr int ST_C16 = ST_KP * 2 / 16;  // 76 16-byte chunks per shadow row
-// (five named members, not an array: a conditionally written register array is demoted to scratch)
-typedef __attribute__((ext_vector_type(4))) unsigned int ltg_u32x4;  // native vector: stays in VGPRs (HIP's uint4 is a union struct)
-struct StW {
-    ltg_u32x4 a, b, c, d, e;
-};
-__device__ __forceinline__ void st_fetch_w(const unsigned short* __restrict__ Wb, int I, int i0, StW& r) {
-    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
-    const ltg_u32x4* row = reinterpret_cast<const ltg_u32x4*>(Wb + (size_t)min(i0 + it, I - 1) * ST_KP);
-    r.a = row[c0];
-    r.b = row[c0 + 16];
-    r.c = row[c0 + 32];
-    r.d = row[c0 + 48];
-    r.e = row[min(c0 + 64, ST_C16 - 1)];
-}
-// one HALF of the shadow rows (the dh2 product split over column halves): 38 chunks of 16 B per item row, stored compactly (LDS columns
-// 0 .. 303); lanes 6 .. 15 of a row's 16 threads have no third chunk (clamped duplicate load, no store)
-__device__ __forceinline__ void st_fetch_w_half(const unsigned short* __restrict__ Wb, int I, int i0, int half, StW& r) {
-    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
-    const ltg_u32x4* row = reinterpret_cast<const ltg_u32x4*>(Wb + (size_t)min(i0 + it, I - 1) * ST_KP) + half * (ST_C16 / 2);
-    r.a = row[c0];
-    r.b = row[c0 + 16];
-    r.c = row[min(c0 + 32, ST_C16 / 2 - 1)];
-}
-__device__ __forceinline__ void st_stash_w_half(unsigned short* __restrict__ Wl, const StW& r) {
-    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
-    ltg_u32x4* row = reinterpret_cast<ltg_u32x4*>(Wl + it * ST_LDW);
-    row[c0] = r.a;
-    row[c0 + 16] = r.b;
-    if (c0 + 32 < ST_C16 / 2) row[c0 + 32] = r.c;
-}
-__device__ __forceinline__ void st_stash_w(unsigned short* __restrict__ Wl, const StW& r) {
-    const int it = threadIdx.x >> 4, c0 = threadIdx.x & 15;
-    ltg_u32x4* row = reinterpret_cast<ltg_u32x4*>(Wl + it * ST_LDW);
-    row[c0] = r.a;
-    row[c0 + 16] = r.b;
-    row[c0 + 32] = r.c;
-    row[c0 + 48] = r.d;
-    if (c0 + 64 < ST_C16) row[c0 + 64] = r.e;
-}
-
-// STATS: every lane also keeps the running (max, sum of exp) of the logits it stores (four batch rows x two items per tile);
-// at the end the 16 lanes of a row merge theirs and the workgroup writes stat[blockIdx.x][row] = (max, sum exp(. - max)) over
-// ITS tiles -- the softmax statistics come out of the producing epilogue, the [B, I] logits are not read again for them
-// (k_row_stats_merge folds the workgroups' pairs and adds the sparse terms).
-// PF: W tiles of HBM loads in flight per workgroup (register sets of 20 VGPRs each).  Measured at 200 000 items (85 us): PF = 3
-// changes nothing; without the logits stores 69 us, with 1 of the 19 MFMA / LDS-read rounds 66 us, with neither 56 us (the
-// 243 MB of W at 4.3 TB/s): loads, product and stores add up rather than overlap -- one lock-step workgroup per CU.
-template <bool STATS, int PF = 2>
-__global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream(int M, int I, int H, const float* __restrict__ h2,
-                                                           const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
-                                                           float* __restrict__ logits, float* __restrict__ stat) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    // stationary A fragments: rows 16w + lr, all K (fp32 -> bf16 once per workgroup).  Rows >= M MIRROR row M - 1:
-    // their products equal row M - 1's and are stored to row M - 1's addresses (same value twice) -- no row predicate
-    // anywhere in the loop, so every s_waitcnt is an exact count and the prefetch is never drained.
-    // (round 5: the first two / three W tiles are requested BEFORE the h2 fragments, the first one goes to LDS behind them -- h2, then the first
-    // tile, then the others was three dependent round trips in front of the first product of workgroups that own two or three tiles in all)
-    const int ntiles = (I + ST_BN - 1) / ST_BN, G = gridDim.x, last = ntiles - 1;
-    StW r0, r1, r2;
-    int t = blockIdx.x, cur = 0;
-    if (t < ntiles) {
-        st_fetch_w(Wb, I, t * ST_BN, r0);
-        st_fetch_w(Wb, I, min(t + G, last) * ST_BN, r1);
-        if constexpr (PF == 3) st_fetch_w(Wb, I, min(t + 2 * G, last) * ST_BN, r2);
-    }
-    ltg_bf16x8 af[ST_KS];
-    {
-        // (the fragments in TWO batches of requests: all 38 at once beside the W tiles took 248 registers, and two such waves per SIMD leave the
-        // side stream's clock kernels no room -- see DESIGN 5.3)
-        const int row = min(16 * w + lr, M - 1);
-        const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)row * H);
-        const int H4 = H >> 2;
-        constexpr int KSA = (ST_KS + 1) / 2;
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            float4 x0[KSA], x1[KSA];
-#pragma unroll
-            for (int j = 0; j < KSA; ++j) {
-                const int ks = hb * KSA + j;
-                if (ks < ST_KS) {
-                    const int c4 = ks * 8 + 2 * lq;
-                    x0[j] = hr[min(c4, H4 - 1)];
-                    x1[j] = hr[min(c4 + 1, H4 - 1)];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < KSA; ++j) {
-                const int ks = hb * KSA + j;
-                if (ks < ST_KS) {
-                    const int c4 = ks * 8 + 2 * lq;
-                    const uint2 p0 = ltg_pack4(x0[j]), p1 = ltg_pack4(x1[j]);
-                    const unsigned k0 = c4 < H4 ? 0xFFFFFFFFu : 0u, k1 = c4 + 1 < H4 ? 0xFFFFFFFFu : 0u;   // K padding -> 0
-                    ltg_u32x4 tt;
-                    tt[0] = p0.x & k0; tt[1] = p0.y & k0; tt[2] = p1.x & k1; tt[3] = p1.y & k1;
-                    if (hb == 0) asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));   // (packed HERE: the compiler otherwise sinks the packing behind the second batch)
-                    af[ks] = __builtin_bit_cast(ltg_bf16x8, tt);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t < ntiles) st_stash_w(st_lds, r0);
-    __syncthreads();
-    // ST_STEP(RL, RS): LDS[cur] holds tile tc = min(t, last), RS holds tile min(t + G, last) (in flight since the previous
-    // step); tile min(t + 2G, last) is requested into RL, so two tiles of HBM loads are always outstanding per workgroup.
-    // Tile indices are clamped instead of guarded: a step past the end recomputes the last tile and stores the same
-    // logits again.  (A macro, not a lambda: register arrays captured by reference end up in scratch.)
-#define ST_STEP(RL, RS)                                                                                                         \
-    {                                                                                                                           \
-        const int tc = min(t, last);                                                                                            \
-        const int ia = min(tc * ST_BN + lr, I - 1), ib = min(tc * ST_BN + 16 + lr, I - 1);                                      \
-        const float biasa = bp1[ia], biasb = bp1[ib]; /* BEFORE the prefetch: waiting for a younger load drains it */           \
-        st_fetch_w(Wb, I, min(t + PF * G, last) * ST_BN, RL);                                                                   \
-        const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
-        ltg_f32x4 acc0 = ltg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = ltg_f32x4{0.f, 0.f, 0.f, 0.f};                                   \
-        _Pragma("unroll") for (int ks = 0; ks < ST_KS; ++ks) {                                                                  \
-            const ltg_u16x8 b0 = *reinterpret_cast<const ltg_u16x8*>(Wl + lr * ST_LDW + ks * 32 + 8 * lq);                      \
-            const ltg_u16x8 b1 = *reinterpret_cast<const ltg_u16x8*>(Wl + (16 + lr) * ST_LDW + ks * 32 + 8 * lq);               \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], __builtin_bit_cast(ltg_bf16x8, b0), acc0, 0, 0, 0);          \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], __builtin_bit_cast(ltg_bf16x8, b1), acc1, 0, 0, 0);          \
-        }                                                                                                                       \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                         \
-            const size_t ro = (size_t)min(16 * w + 4 * lq + q, M - 1) * I;                                                      \
-            const float la = acc0[q] + biasa, lb = acc1[q] + biasb;                                                             \
-            logits[ro + ia] = la;                                                                                               \
-            logits[ro + ib] = lb;                                                                                               \
-            if constexpr (STATS) { /* a clamped repeat of the last tile / an item past the end counts for nothing */            \
-                const float xa = (t <= last && tc * ST_BN + lr < I) ? la : -INFINITY;                                           \
-                const float xb = (t <= last && tc * ST_BN + 16 + lr < I) ? lb : -INFINITY;                                      \
-                const float mn = fmaxf(rm[q], fmaxf(xa, xb)), mr = fmaxf(mn, -1e30f);                                           \
-                rs[q] = rs[q] * __expf(rm[q] - mr) + __expf(xa - mr) + __expf(xb - mr);                                         \
-                rm[q] = mn;                                                                                                     \
-            }                                                                                                                   \
-        }                                                                                                                       \
-        st_stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                    \
-        __syncthreads();                                                                                                        \
-        cur ^= 1;                                                                                                               \
-    }
-    if constexpr (PF == 3) {
-        for (; t < ntiles; t += 3 * G) {
-            ST_STEP(r0, r1)
-            t += G;
-            ST_STEP(r1, r2)
-            t += G;
-            ST_STEP(r2, r0)
-            t -= 2 * G;
-        }
-    } else {
-        for (; t < ntiles; t += 2 * G) {
-            ST_STEP(r0, r1)
-            t += G;
-            ST_STEP(r1, r0)
-            t -= G;
-        }
-    }
-#undef ST_STEP
-    if constexpr (STATS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {   // the 16 lanes lr of a row
-                const float m2 = __shfl_xor(rm[q], o), s2 = __shfl_xor(rs[q], o);
-                const float mn = fmaxf(rm[q], m2), mr = fmaxf(mn, -1e30f);
-                rs[q] = rs[q] * __expf(rm[q] - mr) + s2 * __expf(m2 - mr);
-                rm[q] = mn;
-            }
-            const int row = 16 * w + 4 * lq + q;
-            if (lr == 0 && row < M) {
-                float* o2 = stat + ((size_t)blockIdx.x * M + row) * 2;
-                o2[0] = rm[q];
-                o2[1] = rs[q];
-            }
-        }
-    }
-}
-
-// ---- The streaming decoder forward, second form (round 5; slabs of 65 536 items or more): WHO OWNS WHAT is turned round.  Above, the
-// eight waves of a workgroup split the BATCH rows, so every wave needs every W tile: the tile goes through LDS, each wave reads all 39 KB
-// of it (311 KB of LDS reads per 32 items and CU), and one barrier per tile keeps the eight waves in lock step -- loads, product and
-// stores add up (56 + 13 + 16 us at 200 000 items).  Here h2 -- the SMALL operand, 100 x 608 bf16 -- is resident in LDS for the whole
-// kernel, laid out in fragment order (every fragment read is one contiguous, conflict-free 1-KiB ds_read_b128), and each WAVE owns its
-// own 32-item tiles:
-//   * items are the M dimension of v_mfma_f32_16x16x32_bf16 (A = W_p1t shadow rows, B = h2^T): a lane's A fragment is 16 contiguous
-//     bytes of ONE shadow row, loaded global -> VGPR in fragment order (16 rows x 64 B per wave instruction: every byte of a 128-B
-//     line is used by two consecutive K steps) -- no LDS staging of W, no barrier in the loop, the waves drift apart and one wave's
-//     loads overlap another's MFMAs and stores;
-//   * two 16-item sub-tiles per wave tile share every B fragment read: 133 KB of LDS reads per 32 items and wave (NTB = 7) instead of
-//     311 KB per 32 items and workgroup -- 2.3x fewer LDS bytes per item;
-//   * W travels through a RING of 19 load units (one unit = one wave instruction = 16 B per lane = one (K step, sub-tile) fragment;
-//     a tile is 38 units): the unit consumed by K step ks is re-requested for 19 units ahead -- the same tile's second half, then the
-//     NEXT tile's first half -- so 19 KB per wave = 152 KB per CU of HBM loads are in flight at every moment, through the epilogue's
-//     stores and across tile boundaries, with no register-set swap (19 is odd: unit u and u + 19 sit in the same registers);
-//   * the accumulator of a lane is four CONSECUTIVE items of one batch row: logits leave as 16-B stores, 64 B contiguous per row and
-//     instruction (128 B per row over the two sub-tiles), and the softmax statistics stay per lane (one (max, sum exp) pair per batch
-//     tile), merged over the four lane groups and the eight waves once at the end -- same stat[workgroup][row] = (max, sum) output;
-//   * the bias of a tile goes through the SCALAR unit (one s_load of the tile's 32 values, the lane picks its two groups of four with
-//     bit masks): as a vector load it joins the in-order vmcnt queue wherever the compiler sinks it -- K step 14 -- and the wait for it
-//     in front of the stores then drains 15 of the ring's 19 units.
-// No branch in the loop: indices are clamped (a wave's last tile re-requests the tile it has just read instead of a next one: L2 hits),
-// rows >= M mirror row M - 1, items >= I mirror the slab's last four, so every s_waitcnt is an exact count.
-// Where it is used, and why not everywhere (round 5, profiles/README.md): ALONE on the chip it runs 74.7 us at 200 000 items against the
-// first form's 79.2 (4.33 TB/s of a box that copies at 5.2) and 17.9 against 19.9 us at 25 024; INSIDE the one-call step of a 20 000- /
-// 25 024-item slab the step got 1-3 / 4 us LONGER with it: its two waves per SIMD take all 512 registers (256 each), so the side
-// stream's clock kernels (26-30 VGPRs), which the first form (2 x 224) leaves room for, wait for whole CUs to drain.  A 16-item-tile
-// variant held to 168 VGPRs co-resides again but reads twice the LDS bytes per item: 85 us alone at 200 000 items, no gain in any step.
-// So: this form for the HBM-bound slabs, the first form below 65 536 items.
-// NTB: 16-row batch tiles (7 for <= 112 rows: the 100-row batches of config.ini; 8 up to 128 rows).
-constexpr int ST2_UNITS = 2 * ST_KS;   // 38 load units per 32-item tile
-constexpr int ST2_RING = ST_KS;        // 19 units in flight per wave
-constexpr int ST2_MIN_ITEMS = 65536;
-template <bool STATS, int NTB>
-__global__ __launch_bounds__(ST_NT) void k_dec1_fwd_stream2(int M, int I, int H, const float* __restrict__ h2,
-                                                            const unsigned short* __restrict__ Wb, const float* __restrict__ bp1,
-                                                            float* __restrict__ logits, float* __restrict__ stat) {
-    extern __shared__ __attribute__((aligned(16))) ltg_u32x4 Hs[];   // h2 in B-fragment order: [K step][batch tile][lane] x 16 B = 19 NTB KiB
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    const int ntiles = (I + 31) >> 5, G = gridDim.x, GW = 8 * G;
-    // tiles are dealt to waves CU-first (wave w of workgroup g is wave number w * G + g): a slab with fewer tiles than waves spreads over
-    // all CUs, a few waves each, instead of filling some CUs with eight waves
-    int t = w * G + (int)blockIdx.x;
-    const bool any = t < ntiles;
-    const ltg_gchar* Wg = ltg_uniform_ptr(Wb);
-    ltg_gchar* Lg = ltg_uniform_ptr(logits);      // (32-bit byte offsets into BOTH: the host sends launches of 2^30 logits or more, or of slabs whose shadow
-                                                  // is 2^32 bytes or more -- I >= 3 532 111 --, to the first form: launch_dec1_fwd_stream)
-    // byte offset of this lane's A-fragment row in the shadow: item row (tile, sub-tile s, lr), chunk lq of the K step (the K step's
-    // 64 B are added as an immediate).  Items past the end mirror the slab's last four (I % 4 == 0: a lane's four output items are all
-    // inside or all outside): the product of a mirrored row group is the last group's, and it is stored to the last group's address.
-    auto rowoff = [&](int tt, int ss) -> unsigned {
-        int it = tt * 32 + 16 * ss + lr;
-        it = it < I ? it : I - 4 + (it & 3);
-        return (unsigned)it * (unsigned)(ST_KP * 2) + 16u * (unsigned)lq;
-    };
-    ltg_u32x4 Wr[ST2_RING];
-    typedef const ltg_u32x4 __attribute__((address_space(1))) * st2_gp;
-#define ST2_LOAD(u, OFF0, OFF1) Wr[(u) % ST2_RING] = *(st2_gp)(Wg + (((u) & 1) ? (OFF1) : (OFF0)) + 64u * (unsigned)((u) >> 1));
-    unsigned c0 = any ? rowoff(t, 0) : 0u, c1 = any ? rowoff(t, 1) : 0u;
-    // the ring's first 19 units BEFORE the prologue: the first HBM round trip runs under the construction of the h2 image
-#pragma unroll
-    for (int u = 0; u < ST2_RING; ++u) { ST2_LOAD(u, c0, c1) }
-    {   // h2 (fp32, [M][H]) -> bf16 fragments in LDS; rows >= M mirror row M - 1, columns >= H are zero (K padding)
-        const int H4 = H >> 2;
-        constexpr int NE = ST_KS * NTB * 64, PER = (NE + ST_NT - 1) / ST_NT, CH = 6;
-#pragma unroll 1
-        for (int j0 = 0; j0 < PER; j0 += CH) {
-            float4 x0[CH], x1[CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int e = min(tid + (j0 + j) * ST_NT, NE - 1), ln = e & 63, fr = e >> 6, nt = fr % NTB, ks = fr / NTB;
-                const int row = min(16 * nt + (ln & 15), M - 1), c4 = ks * 8 + 2 * (ln >> 4);
-                const float4* hr = reinterpret_cast<const float4*>(h2 + (size_t)row * H);
-                x0[j] = hr[min(c4, H4 - 1)];
-                x1[j] = hr[min(c4 + 1, H4 - 1)];
-            }
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int e = tid + (j0 + j) * ST_NT, fr = min(e, NE - 1) >> 6, ks = fr / NTB, c4 = ks * 8 + 2 * ((e & 63) >> 4);
-                const uint2 p0 = ltg_pack4(x0[j]), p1 = ltg_pack4(x1[j]);
-                const unsigned k0 = c4 < H4 ? 0xFFFFFFFFu : 0u, k1 = c4 + 1 < H4 ? 0xFFFFFFFFu : 0u;
-                ltg_u32x4 v;
-                v[0] = p0.x & k0; v[1] = p0.y & k0; v[2] = p1.x & k1; v[3] = p1.y & k1;
-                if (e < NE && j0 + j < PER) Hs[e] = v;
-            }
-        }
-    }
-    __syncthreads();
-    float rm[NTB], rs[NTB];
-#pragma unroll
-    for (int nt = 0; nt < NTB; ++nt) {
-        rm[nt] = -INFINITY;
-        rs[nt] = 0.f;
-    }
-    if (any) {
-        const ltg_u32x4* Hl = Hs + lane;
-#pragma unroll 1
-        for (; t < ntiles; t += GW) {
-            const bool more = t + GW < ntiles;
-            // the next tile's row offsets; on the wave's last tile the ring re-requests the tile it has just read (a uniform select, no branch:
-            // a join of divergent paths would cost every wait its exact count): served by the L2, no HBM traffic
-            const int tnx = more ? t + GW : t;
-            const unsigned n0 = rowoff(tnx, 0), n1 = rowoff(tnx, 1);
-            const int i0 = t * 32 + 4 * lq, i1 = i0 + 16;
-            const int g0 = i0 < I ? i0 : I - 4, g1 = i1 < I ? i1 : I - 4;
-            // bias of the lane's 2 x 4 output items: the tile's 32 values through the scalar unit (I % 8 == 0: 32-B aligned), picked by bit masks
-            // (?: on scalar-loaded values is turned into branches)
-            const int bbase = __builtin_amdgcn_readfirstlane(min(t * 32, I - 32));
-            typedef float st2_f8 __attribute__((ext_vector_type(8)));
-            const st2_f8* __restrict__ bs = reinterpret_cast<const st2_f8*>(bp1 + bbase);
-            const st2_f8 bq0 = bs[0], bq1 = bs[1], bq2 = bs[2], bq3 = bs[3];
-            auto pick4 = [&](int g) -> float4 {
-                const int sel = (g - bbase) >> 2;      // 0 .. 7: which group of four
-                unsigned km[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) km[k] = 0u - (unsigned)(sel == k);
-                float4 r;
-                float* rp = &r.x;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    rp[j] = __uint_as_float((__float_as_uint(bq0[j]) & km[0]) | (__float_as_uint(bq0[4 + j]) & km[1]) | (__float_as_uint(bq1[j]) & km[2]) |
-                                            (__float_as_uint(bq1[4 + j]) & km[3]) | (__float_as_uint(bq2[j]) & km[4]) | (__float_as_uint(bq2[4 + j]) & km[5]) |
-                                            (__float_as_uint(bq3[j]) & km[6]) | (__float_as_uint(bq3[4 + j]) & km[7]));
-                return r;
-            };
-            const float4 bias0 = pick4(g0), bias1 = pick4(g1);
-            ltg_f32x4 acc[2][NTB];
-#pragma unroll
-            for (int nt = 0; nt < NTB; ++nt) {
-                acc[0][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[1][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int ks = 0; ks < ST_KS; ++ks) {
-                ltg_u32x4 bfr[NTB];
-#pragma unroll
-                for (int nt = 0; nt < NTB; ++nt) bfr[nt] = Hl[(ks * NTB + nt) * 64];
-                const ltg_bf16x8 a0 = __builtin_bit_cast(ltg_bf16x8, Wr[(2 * ks) % ST2_RING]);
-                const ltg_bf16x8 a1 = __builtin_bit_cast(ltg_bf16x8, Wr[(2 * ks + 1) % ST2_RING]);
-#pragma unroll
-                for (int nt = 0; nt < NTB; ++nt) {
-                    const ltg_bf16x8 b = __builtin_bit_cast(ltg_bf16x8, bfr[nt]);
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][nt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // refill: units 2 ks + 19 and 2 ks + 20 (this tile's second half, then the next tile's first half) into the registers just consumed
-                if (2 * ks + ST2_RING < ST2_UNITS) { ST2_LOAD(2 * ks + ST2_RING, c0, c1) } else { ST2_LOAD(2 * ks + ST2_RING - ST2_UNITS, n0, n1) }
-                if (2 * ks + 1 + ST2_RING < ST2_UNITS) { ST2_LOAD(2 * ks + 1 + ST2_RING, c0, c1) } else { ST2_LOAD(2 * ks + 1 + ST2_RING - ST2_UNITS, n0, n1) }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // epilogue: + bias, 16-B stores (row 16 nt + lr, items g .. g + 3), running softmax statistics of the row over this lane's items
-            const bool in0 = i0 < I, in1 = i1 < I;
-            int lr_v = lr;      // (opaque: hoisted out of the loop the NTB row offsets cost registers the ring needs)
-            asm volatile("" : "+v"(lr_v));
-#pragma unroll
-            for (int nt = 0; nt < NTB; ++nt) {
-                const unsigned ro = (unsigned)min(16 * nt + lr_v, M - 1) * (unsigned)I;
-                const ltg_f32x4 v0{acc[0][nt][0] + bias0.x, acc[0][nt][1] + bias0.y, acc[0][nt][2] + bias0.z, acc[0][nt][3] + bias0.w};
-                const ltg_f32x4 v1{acc[1][nt][0] + bias1.x, acc[1][nt][1] + bias1.y, acc[1][nt][2] + bias1.z, acc[1][nt][3] + bias1.w};
-                *(ltg_f32x4 __attribute__((address_space(1)))*)(Lg + (ro + (unsigned)g0) * 4u) = v0;
-                *(ltg_f32x4 __attribute__((address_space(1)))*)(Lg + (ro + (unsigned)g1) * 4u) = v1;
-                if constexpr (STATS) {
-                    const float m0 = in0 ? fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v0[2], v0[3])) : -INFINITY;
-                    const float m1 = in1 ? fmaxf(fmaxf(v1[0], v1[1]), fmaxf(v1[2], v1[3])) : -INFINITY;
-                    const float mn = fmaxf(rm[nt], fmaxf(m0, m1)), mr = fmaxf(mn, -1e30f);
-                    float e = rs[nt] * __expf(rm[nt] - mr);
-                    const float e0 = (__expf(v0[0] - mr) + __expf(v0[1] - mr)) + (__expf(v0[2] - mr) + __expf(v0[3] - mr));
-                    const float e1 = (__expf(v1[0] - mr) + __expf(v1[1] - mr)) + (__expf(v1[2] - mr) + __expf(v1[3] - mr));
-                    e += in0 ? e0 : 0.f;
-                    e += in1 ? e1 : 0.f;
-                    rs[nt] = e;
-                    rm[nt] = mn;
-                }
-            }
-            c0 = n0;
-            c1 = n1;
-        }
-    }
-#undef ST2_LOAD
-    if constexpr (STATS) {
-        // the four lane groups of a row, then the eight waves through LDS (the h2 image is dead: one barrier in front)
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) {
-#pragma unroll
-            for (int o = 16; o < 64; o <<= 1) {
-                const float m2 = __shfl_xor(rm[nt], o), s2 = __shfl_xor(rs[nt], o);
-                const float mn = fmaxf(rm[nt], m2), mr = fmaxf(mn, -1e30f);
-                rs[nt] = rs[nt] * __expf(rm[nt] - mr) + s2 * __expf(m2 - mr);
-                rm[nt] = mn;
-            }
-        }
-        __syncthreads();
-        float2* red = reinterpret_cast<float2*>(Hs);   // [8 waves][NTB * 16 rows]
-        if (lq == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NTB; ++nt) red[w * (NTB * 16) + 16 * nt + lr] = make_float2(rm[nt], rs[nt]);
-        }
-        __syncthreads();
-        if (tid < M) {
-            float m = -INFINITY, sum = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 8; ++ww) {
-                const float2 q = red[ww * (NTB * 16) + tid];
-                const float mn = fmaxf(m, q.x), mr = fmaxf(mn, -1e30f);
-                sum = sum * __expf(m - mr) + q.y * __expf(q.x - mr);
-                m = mn;
-            }
-            float* o2 = stat + ((size_t)blockIdx.x * M + tid) * 2;
-            o2[0] = m;
-            o2[1] = sum;
-        }
-    }
-}
-
-// part[blockIdx.x][b][h]: this workgroup's share of dh2 (k_da2 sums the slabs)
-// NH = 2: blockIdx.y = which HALF of the 608 columns this workgroup produces, over a chunk of twice the items -- the same number of
-// workgroups and the same W bytes per workgroup, but half the partial slabs (at 25 024 items 98 x 240 KB instead of 196: the slab sum
-// that follows on the critical stream reads 23.5 MB instead of 47) and half the accumulator registers (76 instead of 152)
-template <bool D16, int NH = 1>
-__global__ __launch_bounds__(ST_NT) void k_dh2_stream(int B, int I, int H, int chunk, const float* __restrict__ dlog,
-                                                      const unsigned short* __restrict__ Wb, float* __restrict__ part,
-                                                      LtgGate started = LTG_NO_GATE) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short st_lds[];  // 2 x [ST_BN][ST_LDW]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    // started: opened by the first workgroup as soon as this kernel runs -- dlogits is complete.  With TWO shadow buffers (ltg_pipe.shadow_out)
-    // that is all the forked weight update waits for: it writes the other buffer while this product reads Wb.
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) ltg_gate_set(started);
-    constexpr int NTL = ST_KP / 16 / NH;  // 38 (19) column tiles of the accumulator
-    const int half = NH == 2 ? (int)blockIdx.y : 0;
-    auto fetch_w = [&](int i0_, StW& r_) {
-        if constexpr (NH == 2) st_fetch_w_half(Wb, I, i0_, half, r_);
-        else st_fetch_w(Wb, I, i0_, r_);
-    };
-    auto stash_w = [&](unsigned short* Wl_, const StW& r_) {
-        if constexpr (NH == 2) st_stash_w_half(Wl_, r_);
-        else st_stash_w(Wl_, r_);
-    };
-    ltg_f32x4 acc[NTL];
-#pragma unroll
-    for (int n = 0; n < NTL; ++n) acc[n] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ibeg = blockIdx.x * chunk, iend = min(I, ibeg + chunk);
-    if (ibeg >= iend) return;
-    const int row = 16 * w + lr;
-    const float* drow = dlog + (size_t)min(row, B - 1) * I;
-    const unsigned short* drow16 = reinterpret_cast<const unsigned short*>(dlog) + (size_t)min(row, B - 1) * I;   // D16: [B][I] bf16
-    const int ilast = ibeg + (iend - ibeg - 1) / ST_BN * ST_BN;      // start of the chunk's last 32-item step
-    // A fragment of a 32-item step: dlog[row][i0 + 8*lq .. +7] (I % 8 == 0: whole 32-B groups, 16-B aligned).  Loads are
-    // unconditional (clamped); rows >= B and steps past the end of the chunk are zeroed with a bit mask, so a clamped
-    // duplicate step adds nothing.  No branch in the loop: every s_waitcnt is an exact count.
-#define DH_LOAD_A(i0, X0, X1)                                                      \
-    {                                                                              \
-        const int ib_ = min(min((i0), ilast) + 8 * lq, I - 8);                     \
-        if constexpr (D16) X0 = *reinterpret_cast<const float4*>(drow16 + ib_);    \
-        else {                                                                     \
-            X0 = *reinterpret_cast<const float4*>(drow + ib_);                     \
-            X1 = *reinterpret_cast<const float4*>(drow + ib_ + 4);                 \
-        }                                                                          \
-    }
-    StW r0, r1;
-    float4 e0, e1, o0, o1;     // A fragments of the even / odd steps
-    // (round 5: all four requests of the prologue first, THEN the first tile's way into LDS -- stashed right behind its own request it made
-    // the prologue two dependent round trips, in workgroups whose whole chunk is five or six steps)
-    fetch_w(ibeg, r0);
-    DH_LOAD_A(ibeg, e0, e1)
-    fetch_w(min(ibeg + ST_BN, ilast), r1);
-    DH_LOAD_A(ibeg + ST_BN, o0, o1)
-    __builtin_amdgcn_sched_barrier(0);
-    stash_w(st_lds, r0);
-    __syncthreads();
-    int cur = 0;
-    const int tq = lr >> 2, tp = lr & 3;
-    // DH_STEP(RL, RS, X0, X1): LDS[cur] = W tile of step i0, RS = W tile of the next step (in flight), X = A fragment of
-    // step i0 (requested two steps ago); requests the W tile two steps ahead into RL and, once X is converted, the A
-    // fragment two steps ahead into X again -- two steps of HBM loads are always outstanding.
-#define DH_STEP(RL, RS, X0, X1)                                                                                                 \
-    {                                                                                                                           \
-        fetch_w(min(i0 + 2 * ST_BN, ilast), RL);                                                                                \
-        const unsigned keep = (row < B && i0 + 8 * lq < iend) ? 0xFFFFFFFFu : 0u;                                               \
-        ltg_u32x4 au;                                                                                                           \
-        if constexpr (D16) {                                                                                                    \
-            au[0] = __float_as_uint(X0.x) & keep; au[1] = __float_as_uint(X0.y) & keep;                                         \
-            au[2] = __float_as_uint(X0.z) & keep; au[3] = __float_as_uint(X0.w) & keep;                                         \
-        } else {                                                                                                                \
-            const uint2 pa = ltg_pack4(X0), pb = ltg_pack4(X1);                                                                 \
-            au[0] = pa.x & keep; au[1] = pa.y & keep; au[2] = pb.x & keep; au[3] = pb.y & keep;                                 \
-        }                                                                                                                       \
-        const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);                                                               \
-        DH_LOAD_A(i0 + 2 * ST_BN, X0, X1)                                                                                       \
-        const unsigned short* Wl = st_lds + cur * ST_BN * ST_LDW;                                                               \
-        /* transposed fragment reads: lane 4q+p of each 16-lane group addresses row (8*lq + q), columns 4p..4p+3; it */        \
-        /* receives column (lane & 15) of the four rows -> k = 8*lq + q (first read), 8*lq + 4 + q (second) */                  \
-        const unsigned short* tbase = Wl + (8 * lq + tq) * ST_LDW + 4 * tp;                                                     \
-        _Pragma("unroll") for (int n = 0; n < NTL; ++n) {                                                                       \
-            typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;                                                        \
-            const ltg_s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + n * 16));                              \
-            const ltg_s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tbase + 4 * ST_LDW + n * 16));                 \
-            ltg_u16x8 bu;                                                                                                       \
-            bu[0] = b0[0]; bu[1] = b0[1]; bu[2] = b0[2]; bu[3] = b0[3];                                                         \
-            bu[4] = b1[0]; bu[5] = b1[1]; bu[6] = b1[2]; bu[7] = b1[3];                                                         \
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(ltg_bf16x8, bu), acc[n], 0, 0, 0);          \
-        }                                                                                                                       \
-        stash_w(st_lds + (cur ^ 1) * ST_BN * ST_LDW, RS);                                                                       \
-        __syncthreads();                                                                                                        \
-        cur ^= 1;                                                                                                               \
-        i0 += ST_BN;                                                                                                            \
-    }
-    for (int i0 = ibeg; i0 < iend;) {
-        DH_STEP(r0, r1, e0, e1)
-        DH_STEP(r1, r0, o0, o1)
-    }
-#undef DH_STEP
-#undef DH_LOAD_A
-    float* out = part + (size_t)blockIdx.x * B * H;
-#pragma unroll
-    for (int n = 0; n < NTL; ++n) {
-        const int h = half * (ST_KP / 2) + n * 16 + lr;
-        if (h < H) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = 16 * w + 4 * lq + q;
-                if (rr < B) out[(size_t)rr * H + h] = acc[n][q];
-            }
-        }
-    }
-}
-
-// dW_p1t[i][h] = sum_b dlog[b][i] * h2[b][h] (+ ones column h == H -> db_p1[i]) fused with the Adam update of
-// W_p1t / b_p1 and the refresh of the bf16 shadow, streaming: persistent 8-wave workgroups, h2 fragments
-// stationary in registers (wave w owns columns [80w, 80w+80)), dlog read ONCE in [128 rows][32 items] tiles
-// (row-major bf16 LDS image, consumed transposed by ds_read_b64_tr_b16), theta/m/v touched exactly once.
-constexpr int DW_LDD = 40;  // LDS row stride of the dlog tile in bf16 (80 B: 16-B aligned)
-constexpr int DW_LDC = 84;  // row stride of a wave's fp32 gradient block (80 columns + 4)
-// read_h2: the one-call step's hand-over of h2 (ltg_pipe.sync words 8 / 1).  h2 is read in the prologue only; a workgroup that has its
-// fragments counts itself in word 8, and the one that completes the grid stores the call's ordinal into word 1 -- from then on the next
-// step's dec-0 may overwrite h2 although this kernel still runs (a write-after-read hazard: the reads have returned, nothing is published).
-struct LtgH2Done {
-    unsigned* count;   // NULL: no hand-over
-    unsigned* word;
-    unsigned seq;
-    const unsigned* poison;
-};
-template <bool D16>
-__global__ __launch_bounds__(ST_NT) void k_dec1_bwd_adam_stream(int B, int I, int H, const float* __restrict__ dlog,
-                                                                const float* __restrict__ h2, ltg_gen_state st, AdamC ad,
-                                                                LtgH2Done hd = LtgH2Done{nullptr, nullptr, 0u, nullptr}) {
-    __shared__ __attribute__((aligned(16))) unsigned short Dl[2][128 * DW_LDD];
-    __shared__ __attribute__((aligned(16))) float Cs[8 * 32 * DW_LDC];   // per-wave [32][80] gradient blocks
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    if (ltg_poisoned(hd.poison)) return;
-    float4 *W4 = reinterpret_cast<float4*>(st.p[3]), *M4 = reinterpret_cast<float4*>(st.m[3]), *V4 = reinterpret_cast<float4*>(st.v[3]);
-#if defined(LTG_X_SPIN)
-    // MEASUREMENT BUILD ONLY (results wrong): the kernel's footprint (registers, LDS, one workgroup per CU) for LTG_X_SPIN us, no memory traffic
-    {
-        Dl[0][tid] = 0;
-        Cs[tid] = 0.f;
-        asm volatile("v_mov_b32 v220, 0" ::: "v220");
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)(LTG_X_SPIN) * 100ull) __builtin_amdgcn_s_sleep(16);
-        if (Dl[0][tid] == 1) W4[0].x = Cs[tid];
-        return;
-    }
-#elif defined(LTG_X_NOUPDATE)
-    // MEASUREMENT BUILD ONLY (weights do not move): no update at all -- what the chain costs with nothing beside it
-    if (B >= 0) return;
-#endif
-    float *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
-    unsigned short* Wb = st.wp1t_bf16;
-    // stationary B fragments: B[k = b][n] = h2[b][n] (n < H), 1 (n == H), 0 beyond.  Built through LDS in four
-    // 32-row slices (coalesced float4 reads, bf16 image with a conflict-free 650-element row stride); gathering the
-    // 160 values of a lane straight from global memory makes the compiler hoist 160 loads and spill the fragments.
-    ltg_bf16x8 bf[5][4];
-    {
-        constexpr int HS = 650;
-        unsigned short* Hs = reinterpret_cast<unsigned short*>(Cs);   // [32][HS] bf16 = 41.6 KB of the 86 KB slab area
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            for (int e = tid; e < 32 * 160; e += ST_NT) {
-                const int rr = e / 160, n = 4 * (e % 160), b = ks * 32 + rr;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b < B && n < H) v = *reinterpret_cast<const float4*>(h2 + (size_t)b * H + n);
-                uint2 pk = ltg_pack4(v);
-                if (b < B && n == H) pk.x = 0x3F80u;                  // the ones column
-                unsigned* dst = reinterpret_cast<unsigned*>(Hs + rr * HS + n);
-                dst[0] = pk.x;
-                dst[1] = pk.y;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt) {
-                const int n = 80 * w + 16 * nt + lr;
-                ltg_u16x8 t;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = Hs[(8 * lq + j) * HS + n];
-                bf[nt][ks] = __builtin_bit_cast(ltg_bf16x8, t);
-            }
-            __syncthreads();
-        }
-    }
-    if (hd.count && tid == 0) {   // (behind the prologue's last barrier: every h2 value this workgroup needs sits in registers)
-        if (atomicAdd(hd.count, 1u) + 1u == gridDim.x) {
-            __hip_atomic_store(hd.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next call's kernel starts behind this one on its stream)
-            __hip_atomic_store(hd.word, hd.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    const int ntiles = I / 32, G = gridDim.x;   // full tiles only: the host sends the ragged tail (I % 32 rows) to k_dec1_bwd_adam
-    // dlog tile loader: thread -> (row b = tid / 4, 8 items at 8 * (tid % 4))
-    const int lb = tid >> 2, lseg = tid & 3;
-    const float* lrow = dlog + (size_t)min(lb, B - 1) * I;
-    const unsigned short* lrow16 = reinterpret_cast<const unsigned short*>(dlog) + (size_t)min(lb, B - 1) * I;   // D16: [B][I] bf16
-    auto fetch = [&](int t, float4& x0, float4& x1) {
-        const int ib = min(t * 32 + 8 * lseg, I - 8);
-        if constexpr (D16) x0 = *reinterpret_cast<const float4*>(lrow16 + ib);   // eight bf16 = the LDS image as it is
-        else {
-            x0 = *reinterpret_cast<const float4*>(lrow + ib);
-            x1 = *reinterpret_cast<const float4*>(lrow + ib + 4);
-        }
-    };
-    auto stash = [&](unsigned short* D, int t, const float4& x0, const float4& x1) {
-        const bool ok = lb < B && t * 32 + 8 * lseg < I;
-        ltg_u32x4 p;
-        if constexpr (D16) {
-            p[0] = ok ? __float_as_uint(x0.x) : 0u; p[1] = ok ? __float_as_uint(x0.y) : 0u;
-            p[2] = ok ? __float_as_uint(x0.z) : 0u; p[3] = ok ? __float_as_uint(x0.w) : 0u;
-        } else {
-            const uint2 a = ltg_pack4(x0), c = ltg_pack4(x1);
-            p[0] = ok ? a.x : 0u; p[1] = ok ? a.y : 0u; p[2] = ok ? c.x : 0u; p[3] = ok ? c.y : 0u;
-        }
-        *reinterpret_cast<ltg_u32x4*>(D + lb * DW_LDD + 8 * lseg) = p;
-    };
-    int t = blockIdx.x, cur = 0;
-    float4 x0, x1;
-    if (t < ntiles) {
-        fetch(t, x0, x1);
-        stash(Dl[0], t, x0, x1);
-        fetch(t + G < ntiles ? t + G : t, x0, x1);
-    }
-    __syncthreads();
-    const int tq = lr >> 2, tp = lr & 3;
-    // ---- Adam epilogue geometry.  The 32 rows of a tile are CONTIGUOUS in theta / m / v (32 x H floats, the tile starts on
-    // a 256-B boundary), so ownership is by rows, not by the column blocks the products were computed in: wave w walks
-    // rows 4w..4w+3 = 4 H/4 consecutive float4 as ten 1-KiB wave accesses (float4 e = 64 jj + lane; the tail lanes of
-    // the tenth access mirror the last element: same load, same result, same store).  The gradient of element (row,
-    // chunk) is fetched from the LDS slab of whichever wave computed that column block.  No lane predicates, no
-    // wave-dependent branches: every s_waitcnt in the loop is an exact count.  theta / m / v travel in six
-    // software-pipelined stages (2+2+2+2+1+1 float4 per lane) rotating over three register sets; the loads of the stage
-    // after next -- at the end of a tile: of the NEXT tile's first two stages -- are issued before the current stage is
-    // consumed, so HBM requests stay in flight through the MFMA phase and the barriers.  (A fourth set does not fit: the
-    // stationary fragments hold 80 of the 256 VGPRs, the kernel uses 248.)
-    float* Cw = Cs + w * (32 * DW_LDC);                        // this wave's product slab
-    const int H4 = H >> 2, nel = 4 * H4;                       // float4 per row / per wave and tile (host: 9 * 64 < nel <= 10 * 64)
-    const unsigned rowB = (unsigned)H * 4u;
-    const unsigned lo = 16u * lane, lo9 = 16u * (unsigned)(min(576 + lane, nel - 1) - 576);
-    ltg_f32x4 Ap[2], Am[2], Av[2], Bp[2], Bm[2], Bv[2], Cp[2], Cm[2], Cv[2];
-#define DW_ADAM1(f)                                  \
-    {                                                \
-        float p_ = p.f, m_ = mm.f, v_ = v2.f;        \
-        adam1(p_, m_, v_, g.f, ad.lr_t, ad);         \
-        p.f = p_; mm.f = m_; v2.f = v_;              \
-    }
-    // addressing: (uniform row base, computed on the scalar unit) + (one 32-bit lane offset per pass) -- global_load with
-    // an SGPR base, so the unrolled stages do not pin a VGPR pair per access
-#define DW_AT(T, BASE, UB, LB) (*(T __attribute__((address_space(1)))*)(ltg_uniform_ptr(reinterpret_cast<const char*>(BASE) + (UB)) + (LB)))
-    // theta / m / v as NON-TEMPORAL accesses (the nt bit of global_load / global_store): each element is touched exactly once per step, by
-    // this kernel only (the forward reads the bf16 shadow) -- 360 MB per step at 25 024 items that would otherwise push everything else
-    // out of the L2s and the memory-side cache.  Measured (same box, interleaved): per-rank proxy 197-204 -> 194 us per G step, C4-shaped
-    // phase G 272-274 -> 256-262 ms, C3-shaped 117.6 -> 114.7 ms.  -DLTG_DW_TEMPORAL builds the plain accesses.
-#ifndef LTG_DW_TEMPORAL
-#define DW_LDG(P) __builtin_nontemporal_load(P)
-#define DW_STG(V, P) __builtin_nontemporal_store(V, P)
-#else
-#define DW_LDG(P) (*(P))
-#define DW_STG(V, P) (*(P) = (V))
-#endif
-#define DW_LD(S, tt, NJ, J0, LOFF)                                                      \
-    _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
-        const size_t u = (size_t)((tt) * 32 + 4 * w) * rowB + 1024u * ((J0) + jj);      \
-        S##p[jj] = DW_LDG(&DW_AT(const ltg_f32x4, W4, u, LOFF));                        \
-        S##m[jj] = DW_LDG(&DW_AT(const ltg_f32x4, M4, u, LOFF));                        \
-        S##v[jj] = DW_LDG(&DW_AT(const ltg_f32x4, V4, u, LOFF));                        \
-    }
-#define DW_AP(S, tt, NJ, J0, LOFF)                                                      \
-    _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                 \
-        const int e = min(64 * ((J0) + jj) + lane_v, nel - 1);                          \
-        const int rl = e / H4, ch = e - rl * H4, wb = ch / 20, lc = ch - 20 * wb;       \
-        const float4 g = *reinterpret_cast<const float4*>(Cs + wb * (32 * DW_LDC) + (4 * w + rl) * DW_LDC + 4 * lc); \
-        ltg_f32x4 p = S##p[jj], mm = S##m[jj], v2 = S##v[jj];                           \
-        DW_ADAM1(x) DW_ADAM1(y) DW_ADAM1(z) DW_ADAM1(w)                                 \
-        const size_t u = (size_t)((tt) * 32 + 4 * w) * rowB + 1024u * ((J0) + jj);      \
-        DW_STG(p, &DW_AT(ltg_f32x4, W4, u, LOFF));                                      \
-        DW_STG(mm, &DW_AT(ltg_f32x4, M4, u, LOFF));                                     \
-        DW_STG(v2, &DW_AT(ltg_f32x4, V4, u, LOFF));                                     \
-        const uint2 pk = ltg_pack4(make_float4(p.x, p.y, p.z, p.w));                    \
-        DW_AT(ltg_u32x2, Wb, (size_t)((tt) * 32 + 4 * w) * (ST_KP * 2), (unsigned)(rl * (ST_KP * 2) + 8 * ch)) = ltg_u32x2{pk.x, pk.y}; \
-    }
-    // THREE register sets rotate over the six stages (A B C A B C: the next tile starts on A again), so two stages of loads are in flight
-    // behind the one being consumed and the next tile's first two stages through its MFMA phase: 248 VGPRs, no scratch.  Against two
-    // sets (round 4, interleaved, two boxes): 200 000 items 741-774 against 755-806 us per step, 20 000 and 25 024 items equal
-    // (138.0-142.6 / 137.5-139.2, 151.8-153.7 / 151.4-155.0).  (Two sets that only keep BOTH loaded through the MFMA phase: equal everywhere.)
-#define DW_SB __builtin_amdgcn_sched_barrier(0);
-#define DW_STAGES() \
-        DW_LD(C, t, 2, 4, lo) DW_SB   DW_AP(A, t, 2, 0, lo) DW_SB \
-        DW_LD(A, t, 2, 6, lo) DW_SB   DW_AP(B, t, 2, 2, lo) DW_SB \
-        DW_LD(B, t, 1, 8, lo) DW_SB   DW_AP(C, t, 2, 4, lo) DW_SB \
-        DW_LD(C, t, 1, 9, lo9) DW_SB  DW_AP(A, t, 2, 6, lo) DW_SB \
-        DW_LD(A, tn, 2, 0, lo) DW_SB  DW_AP(B, t, 1, 8, lo) DW_SB   /* the next tile's first two stages (of this one again at the end: unused) */ \
-        DW_LD(B, tn, 2, 2, lo) DW_SB  DW_AP(C, t, 1, 9, lo9) DW_SB
-#define DW_FIRST(tt) DW_LD(A, tt, 2, 0, lo) DW_LD(B, tt, 2, 2, lo)
-    // one tile: sets A and B hold its first two stages (requested at the end of the previous tile) -- one loop body, no register-set swap
-    // (a swap would have to wait for loads in flight)
-#define DW_BODY()                                                                                              \
-    {                                                                                                                \
-        const bool more = t + G < ntiles;                                                                            \
-        const int tn = more ? t + G : t;                                                                             \
-        int lane_v = lane; /* opaque per tile: keeps the ten (row, chunk) -> LDS / shadow offsets of a lane from being   \
-                              hoisted out of the loop into 20+ VGPRs (they are a handful of VALU ops to recompute) */  \
-        asm volatile("" : "+v"(lane_v));                                                                           \
-        ltg_f32x4 acc[2][5];                                                                                         \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                             \
-            _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = ltg_f32x4{0.f, 0.f, 0.f, 0.f};            \
-        const unsigned short* D = Dl[cur];                                                                           \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                       \
-                typedef ltg_s16x4 __attribute__((address_space(3))) * lds_p;                                         \
-                const unsigned short* base = D + (ks * 32 + 8 * lq + tq) * DW_LDD + mt * 16 + 4 * tp;                \
-                const ltg_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)base);                           \
-                const ltg_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * DW_LDD));            \
-                ltg_u16x8 au;                                                                                        \
-                au[0] = a0[0]; au[1] = a0[1]; au[2] = a0[2]; au[3] = a0[3];                                          \
-                au[4] = a1[0]; au[5] = a1[1]; au[6] = a1[2]; au[7] = a1[3];                                          \
-                const ltg_bf16x8 af = __builtin_bit_cast(ltg_bf16x8, au);                                            \
-                _Pragma("unroll") for (int nt = 0; nt < 5; ++nt)                                                     \
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt][ks], acc[mt][nt], 0, 0, 0);     \
-            }                                                                                                        \
-        }                                                                                                            \
-        /* the wave's gradient block takes a round trip through its private LDS slab (MFMA C layout -> row chunks) */ \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                             \
-            _Pragma("unroll") for (int nt = 0; nt < 5; ++nt)                                                         \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) Cw[(mt * 16 + 4 * lq + q) * DW_LDC + 16 * nt + lr] = acc[mt][nt][q]; \
-        __syncthreads();                                                                                             \
-        /* dlog: x (tile t + G, requested one tile ago) -> the idle LDS buffer; request tile t + 2G.  Both             \
-           unconditional (clamped): a branch around either ends in vmcnt(0) at its join. */                          \
-        stash(Dl[cur ^ 1], more ? t + G : t, x0, x1);                                                                \
-        fetch(t + 2 * G < ntiles ? t + 2 * G : t, x0, x1);                                                           \
-        /* bias b_p1 of rows 4w .. 4w+3 (gradient = the ones column, column H of the product): lanes >= 4 mirror    \
-           lane 3, loads here, update at the end of the tile -- no predicate, nothing waits for these loads */       \
-        const int ib = t * 32 + 4 * w + min(lane, 3);                                                                \
-        float pbv = bb[ib], mbv = mb[ib], vbv = vb[ib];                                                              \
-        DW_STAGES()                                                                                                  \
-        {                                                                                                            \
-            const float gbias = Cs[(H / 80) * (32 * DW_LDC) + (4 * w + min(lane, 3)) * DW_LDC + H % 80];             \
-            adam1(pbv, mbv, vbv, gbias, ad.lr_t, ad);                                                                \
-            mb[ib] = mbv;                                                                                            \
-            vb[ib] = vbv;                                                                                            \
-            bb[ib] = pbv;                                                                                            \
-        }                                                                                                            \
-        __syncthreads();                                                                                             \
-        cur ^= 1;                                                                                                    \
-    }
-    if (t < ntiles) { DW_FIRST(t) }
-    for (; t < ntiles; t += G) DW_BODY()
-#undef DW_STAGES
-#undef DW_SB
-#undef DW_FIRST
-#undef DW_LDG
-#undef DW_STG
-#undef DW_AT
-#undef DW_LD
-#undef DW_AP
-#undef DW_ADAM1
-#undef DW_BODY
-}
-
-// out[i] = the e4m3 value the fp8 GEMM mode stores for in[i] (verification helper: pins the oracle's rounding model)
-__global__ __launch_bounds__(NT) void k_fp8_roundtrip(int n, const float* __restrict__ in, float* __restrict__ out) {
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT)
-        out[i] = __builtin_amdgcn_cvt_f32_fp8((int)ltg_f2fp8(in[i]), 0);
-}
-
-// C[M][N] = A[M][K] . B[K][N] through the block template in one of its operand modes (verification helper)
-template <int MODE>
-__global__ __launch_bounds__(NT) void k_debug_gemm(int M, int N, int K, const float* __restrict__ A, const float* __restrict__ Bm,
-                                                   float* __restrict__ Cm) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return A[(size_t)m * K + k]; };
-    auto b = [=] __device__(int k, int n) -> float { return Bm[(size_t)k * N + n]; };
-    auto epi = [=] __device__(int m, int n, float acc) { Cm[(size_t)m * N + n] = acc; };
-    ltg_gemm_block<MODE, 32, 32, 128, 2, 2, false, true, false, 4, 4>(M, N, m0, n0, 0, K, a, b, epi);
-}
-
-// (re)build the bf16 shadow of W_p1t from the fp32 master rows (set-up / after loading weights)
-__global__ __launch_bounds__(NT) void k_refresh_shadow(int I, int H, const float* __restrict__ W, unsigned short* __restrict__ Wb) {
-    const size_t total = (size_t)I * ST_KP;
-    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
-        const size_t i = e / ST_KP;
-        const int k = (int)(e % ST_KP);
-        Wb[e] = k < H ? ltg_f2bf(W[i * H + k]) : (unsigned short)0;
-    }
-}
-
-// row log-sum-exp of the logits (log_softmax / softmax, MultiVAE.py:108,143)
-__global__ __launch_bounds__(NT) void k_row_lse(int I, const float* __restrict__ logits, float* __restrict__ lse) {
-    __shared__ float red[NT / 64];
-    const float* row = logits + (size_t)blockIdx.x * I;
-    float mx = -INFINITY;
-    for (int i = threadIdx.x; i < I; i += NT) mx = fmaxf(mx, row[i]);
-    mx = block_max(mx, red);
-    float s = 0.f;
-    for (int i = threadIdx.x; i < I; i += NT) s += expf(row[i] - mx);
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) lse[blockIdx.x] = mx + logf(s);
-}
-
-__global__ __launch_bounds__(NT) void k_softmax_write(int I, const float* __restrict__ logits, const float* __restrict__ lse,
-                                                      float* __restrict__ probs) {
-    const size_t base = (size_t)blockIdx.y * I;
-    const float l = lse[blockIdx.y];
-    for (int i = blockIdx.x * NT + threadIdx.x; i < I; i += gridDim.x * NT) probs[base + i] = expf(logits[base + i] - l);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Discriminator (discriminator.py:3-58).  A "pair batch" is the logical concatenation of the real
-// tower rows [0, nr) and the fake tower rows [nr, nr+nf); both towers share the weights.
-// ---------------------------------------------------------------------------------------------
-struct PairView {
-    int nr, nf;
-    const int32_t *r_pop, *r_nic, *f_pop, *f_nic;
-    // pointer/index selects + ONE unconditional load (no divergent branch around the load)
-    __device__ __forceinline__ int pop(int r) const {
-        const int32_t* p = r < nr ? r_pop : f_pop;
-        return p[r < nr ? r : r - nr];
-    }
-    __device__ __forceinline__ int nic(int r) const {
-        const int32_t* p = r < nr ? r_nic : f_nic;
-        return p[r < nr ? r : r - nr];
-    }
-    // (both ids requested unconditionally: with `&&` the niche id was loaded only under the popular id's sign -- a dependent round trip)
-    __device__ __forceinline__ bool valid(int r) const { return (pop(r) | nic(r)) >= 0; }
-};
-struct DropView {
-    const uint8_t *real, *fake;  // optional injected keep flags [rows][width]
-    int nr;
-    int row0;                    // logical pair row of local row 0 (a rank that owns rows [row0, ...) of the pair batch draws the
-                                 // mask the whole batch draws: the counter RNG is indexed by the GLOBAL row)
-    // several pair batches in one pass (ltg_fake_tower_batched): row r belongs to batch seg_of[r], which starts at row seg_row0[.]
-    // and draws with counter seg_step[.]
-    const int32_t *seg_of = nullptr, *seg_row0 = nullptr;
-    const uint64_t* seg_step = nullptr;
-    __device__ __forceinline__ bool keep(int r, int c, int width, uint64_t seed, uint32_t stream, uint64_t step, float kp) const {
-        if (real || fake) return r < nr ? (real[(size_t)r * width + c] != 0) : (fake[(size_t)(r - nr) * width + c] != 0);
-        if (seg_of) {
-            const int sg = seg_of[r];
-            return ltg_rng_keep(seed, stream, seg_step[sg], (uint64_t)(r - seg_row0[sg]) * width + c, kp);
-        }
-        return ltg_rng_keep(seed, stream, step, (uint64_t)(r + row0) * width + c, kp);
-    }
-};
-
-// Discriminator GEMM precision (ltg_config.d_precision): 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 operands,
-// 2 = OCP e4m3 operands with STATIC power-of-two scales per operand class (no amax pass: the classes are bounded --
-// embeddings and weights are N(0, 0.1) truncated at 2 sigma at initialisation, activations are tanh / keep, the gradient
-// classes are bounded by products of those); accumulation is fp32 in every mode.  TS = tile size (32: latency-bound
-// default sizes; 128 = the wide discriminator of BASELINE config 5: 128x128x64 tiles fed by 16-B vector loads, every
-// dimension a multiple of 4).
-constexpr int FP8_S_EMB = 8, FP8_S_W = 8, FP8_S_ACT = 6, FP8_S_G3 = 8, FP8_S_G1 = 7;
-// branch layers (discriminator.py:16-19,25,30,51,52): blockIdx.z = 0 popular->h1, 1 niche->h2
-template <int MODE, int TS, int V>
-__global__ __launch_bounds__(NT) void k_d_l1(PairView pv, int h0, int h1, int h2, const float* __restrict__ emb,
-                                             const float* __restrict__ w1, const float* __restrict__ b1,
-                                             const float* __restrict__ w2, const float* __restrict__ b2, DropView dA,
-                                             DropView dB, float keep, uint64_t seed, uint64_t step,
-                                             float* __restrict__ A1) {
-    const int n = pv.nr + pv.nf, h12 = h1 + h2;
-    const bool br = blockIdx.z != 0;
-    const int N = br ? h2 : h1;
-    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
-    if (n0 >= N) return;
-    const float* W = br ? w2 : w1;
-    const float* bias = br ? b2 : b1;
-    auto a = [=] __device__(int m, int k) -> float {
-        const int id = br ? pv.nic(m) : pv.pop(m);
-        const float v = emb[(size_t)max(id, 0) * h0 + k];
-        return id >= 0 ? v : 0.f;
-    };
-    auto b = [=] __device__(int k, int nn) -> float { return W[(size_t)k * N + nn]; };
-    auto epi = [=] __device__(int m, int nn, float acc) {
-        const float t = tanhf(acc + bias[nn]);
-        const bool kp = br ? dB.keep(m, nn, h2, seed, LTG_STREAM_D_DROP_B, step, keep)
-                           : dA.keep(m, nn, h1, seed, LTG_STREAM_D_DROP_A, step, keep);
-        A1[(size_t)m * h12 + (br ? h1 : 0) + nn] = kp ? t / keep : 0.f;
-    };
-    if constexpr (V) {
-        auto a4 = [=] __device__(int m, int k) -> float4 {
-            const int id = br ? pv.nic(min(m, n - 1)) : pv.pop(min(m, n - 1));
-            return ltg_ld4(emb + (size_t)max(id, 0) * h0, k, h0, m < n && id >= 0);
-        };
-        auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(W + (size_t)min(k, h0 - 1) * N, nn, N, k < h0); };
-        if constexpr (V == 3) ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, 3>(n, N, m0, n0, 0, h0, a4, b4, epi);
-        else ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W, 1>(n, N, m0, n0, 0, h0, a4, b, epi);   // h1 / h2 not multiples of 4
-    } else {
-        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_EMB, FP8_S_W>(n, N, m0, n0, 0, h0, a, b, epi);
-    }
-}
-
-// fully connected layer (discriminator.py:44, :54)
-template <int MODE, int TS, int V>
-__global__ __launch_bounds__(NT) void k_d_l2(int n, int h12, int h3, const float* __restrict__ A1,
-                                             const float* __restrict__ w3, const float* __restrict__ b3, DropView dC,
-                                             float keep, uint64_t seed, uint64_t step, float* __restrict__ A3) {
-    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
-    auto a = [=] __device__(int m, int k) -> float { return A1[(size_t)m * h12 + k]; };
-    auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)k * h3 + nn]; };
-    auto epi = [=] __device__(int m, int nn, float acc) {
-        const float t = tanhf(acc + b3[nn]);
-        A3[(size_t)m * h3 + nn] = dC.keep(m, nn, h3, seed, LTG_STREAM_D_DROP_C, step, keep) ? t / keep : 0.f;
-    };
-    if constexpr (V) {
-        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(A1 + (size_t)min(m, n - 1) * h12, k, h12, m < n); };
-        auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(k, h12 - 1) * h3, nn, h3, k < h12); };
-        ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, true, false, FP8_S_ACT, FP8_S_W, 3>(n, h3, m0, n0, 0, h12, a4, b4, epi);
-    } else {
-        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, true, false, FP8_S_ACT, FP8_S_W>(n, h3, m0, n0, 0, h12, a, b, epi);
-    }
-}
-
-// output unit + loss terms (discriminator.py:45,55; train.py:142): one wave per pair row.
-// y[r] (0 for holes), ds[r] = d d_loss / d s_r, lrow[r] = loss term, and (WITH_BWD) the gradient at
-// the fc layer's pre-activation dpre3[r][c] = ds * w4[c] * dact(A3[r][c]) for the backward GEMMs.
-template <bool WITH_BWD>
-__global__ __launch_bounds__(NT) void k_d_out(PairView pv, int h3, const float* __restrict__ A3,
-                                              const float* __restrict__ w4, const float* __restrict__ b4, float keep,
-                                              float* __restrict__ y, float* __restrict__ ds, float* __restrict__ lrow,
-                                              float* __restrict__ dpre3) {
-    const int n = pv.nr + pv.nf;
-    const int r = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= n) return;
-    float s = 0.f;
-    for (int c = lane; c < h3; c += 64) s += A3[(size_t)r * h3 + c] * w4[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    s += b4[0];
-    const float yy = 1.f / (1.f + expf(-s));
-    const bool ok = pv.valid(r);
-    const bool real = r < pv.nr;
-    const float dsr = ok ? (real ? -(1.f - yy) : yy) : 0.f;
-    if (lane == 0) {
-        y[r] = ok ? yy : 0.f;
-        ds[r] = dsr;
-        lrow[r] = ok ? (real ? -logf(yy) : -logf(1.f - yy)) : 0.f;
-    }
-    if (WITH_BWD) {
-        const float ik = 1.f / keep;
-        for (int c = lane; c < h3; c += 64) {
-            const float a = A3[(size_t)r * h3 + c];
-            const float t = a * keep;
-            dpre3[(size_t)r * h3 + c] = a != 0.f ? dsr * w4[c] * (1.f - t * t) * ik : 0.f;
-        }
-    }
-}
-
-// derivative through dropout(tanh(.)): a = t/keep*mask  =>  d pre = d a * (1 - t^2)/keep where mask=1
-__device__ __forceinline__ float dact(float a, float keep) {
-    const float t = a * keep;
-    return a != 0.f ? (1.f - t * t) / keep : 0.f;
-}
-
-// Flat layout of the discriminator's trainable tensors (discriminator.py:47 order) used by the
-// split-K gradient slabs and the single Adam sweep.
-struct DLayout {
-    int off[9];  // off[i] = start of tensor i, off[8] = total
-};
-__host__ __device__ inline DLayout d_layout(int h0, int h1, int h2, int h3) {
-    DLayout L;
-    const int sz[8] = {h0 * h1, h1, h0 * h2, h2, (h1 + h2) * h3, h3, h3, 1};
-    L.off[0] = 0;
-    for (int i = 0; i < 8; ++i) L.off[i + 1] = L.off[i] + sz[i];
-    return L;
-}
-constexpr int D_KCHUNK = 256;  // pair rows per split-K slab
-
-// Backward stage 1, ONE launch, three independent jobs selected by the block index:
-//   job A  dpre1 = (dpre3 . w3^T) * dact(A1)                       [n][h1+h2]     tiles 64x64
-//   job B  slab[z] += A1^T . dpre3 (+ ones row -> db3), split-K     [(h12+1)][h3]  tiles 32x32
-//   job C  slab[z] += A3^T . ds, sum ds (dw4, db4), split-K         column reduce
-template <int MODE, int TS, int V>
-__global__ __launch_bounds__(NT) void k_d_bwd1(int n, int h12, int h3, int nA, int nB, int ks, DLayout L,
-                                               const float* __restrict__ A1, const float* __restrict__ A3,
-                                               const float* __restrict__ ds, const float* __restrict__ dpre3,
-                                               const float* __restrict__ w3, float keep, float* __restrict__ dpre1,
-                                               float* __restrict__ slab) {
-    int bid = blockIdx.x;
-    if (bid < nA) {
-        const int tn = (h12 + TS - 1) / TS;
-        const int m0 = (bid / tn) * TS, n0 = (bid % tn) * TS;
-        auto a = [=] __device__(int m, int k) -> float { return dpre3[(size_t)m * h3 + k]; };
-        auto b = [=] __device__(int k, int nn) -> float { return w3[(size_t)nn * h3 + k]; };
-        auto epi = [=] __device__(int m, int nn, float acc) {
-            // (MODE 2, e4m3 operands: the derivative rounded to bf16 -- the form the operand-format backward stores it in (ltg_fp8bwd.h:
-            // dA1T_16), so that both fp8 paths feed the e4m3 conversion of dpre1 the same values)
-            const float da = dact(A1[(size_t)m * h12 + nn], keep);
-            dpre1[(size_t)m * h12 + nn] = acc * (MODE == 2 ? __uint_as_float((unsigned)ltg_f2bf(da) << 16) : da);
-        };
-        if constexpr (V) {
-            auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dpre3 + (size_t)min(m, n - 1) * h3, k, h3, m < n); };
-            auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(w3 + (size_t)min(nn, h12 - 1) * h3, k, h3, nn < h12); };
-            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, false, false, false, FP8_S_G3, FP8_S_W, 3>(n, h12, m0, n0, 0, h3, a4, b4, epi);
-        } else {
-            ltg_gemm_block<MODE, TS, TS, 128, 2, 2, false, false, false, FP8_S_G3, FP8_S_W>(n, h12, m0, n0, 0, h3, a, b, epi);
-        }
-        return;
-    }
-    bid -= nA;
-    const int P = L.off[8];
-    if (bid < nB) {
-        const int tm = (h12 + 1 + TS - 1) / TS, tn = (h3 + TS - 1) / TS;
-        const int z = bid / (tm * tn), t = bid % (tm * tn);
-        const int m0 = (t / tn) * TS, n0 = (t % tn) * TS;
-        const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
-        float* out = slab + (size_t)z * P;
-        const int ow = L.off[4], ob = L.off[5];
-        auto a = [=] __device__(int m, int k) -> float {
-            const float v = A1[(size_t)k * h12 + min(m, h12 - 1)];
-            return m < h12 ? v : 1.f;
-        };
-        auto b = [=] __device__(int k, int nn) -> float { return dpre3[(size_t)k * h3 + nn]; };
-        auto epi = [=] __device__(int m, int nn, float g) {
-            if (m < h12) out[ow + (size_t)m * h3 + nn] = g;
-            else out[ob + nn] = g;
-        };
-        if constexpr (V) {
-            // rows m < h12: A1^T; row m == h12: ones (bias gradient); h12 % 4 == 0, so the ones row opens its own group
-            auto a4 = [=] __device__(int m, int k) -> float4 {
-                float4 v = ltg_ld4(A1 + (size_t)min(k, kend - 1) * h12, m, h12, k < kend);
-                if (m == h12 && k < kend) v.x = 1.f;
-                return v;
-            };
-            auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre3 + (size_t)min(k, kend - 1) * h3, nn, h3, k < kend); };
-            ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3, 3>(h12 + 1, h3, m0, n0, kbeg, kend, a4, b4, epi);
-        } else {
-            ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_ACT, FP8_S_G3>(h12 + 1, h3, m0, n0, kbeg, kend, a, b, epi);
-        }
-        return;
-    }
-    bid -= nB;
-    {
-        __shared__ float part[8][33];
-        const int tc = (h3 + 1 + 31) / 32;
-        const int z = bid / tc;
-        const int tn = threadIdx.x & 31, tr = threadIdx.x >> 5;
-        const int c = (bid % tc) * 32 + tn;  // c == h3 is the bias column
-        const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
-        float acc = 0.f;
-        if (c <= h3) {
-#pragma unroll 8
-            for (int r = kbeg + tr; r < kend; r += 8) acc += (c < h3 ? A3[(size_t)r * h3 + c] : 1.f) * ds[r];
-        }
-        part[tr][tn] = acc;
-        __syncthreads();
-        if (tr == 0 && c <= h3) {
-            float g = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) g += part[i][tn];
-            slab[(size_t)z * P + (c < h3 ? L.off[6] + c : L.off[7])] = g;
-        }
-    }
-}
-
-// Backward stage 2: dw1/db1 and dw2/db2 slabs (E_pop^T . dpre1[:, :h1], E_niche^T . dpre1[:, h1:]), split-K.
-template <int MODE, int TS, int V>
-__global__ __launch_bounds__(NT) void k_d_bwd2(PairView pv, int h0, int h1, int h2, int ks, DLayout L,
-                                               const float* __restrict__ emb, const float* __restrict__ dpre1,
-                                               float* __restrict__ slab) {
-    const int n = pv.nr + pv.nf, h12 = h1 + h2;
-    const int tm = (h0 + 1 + TS - 1) / TS;
-    const int tn1 = (h1 + TS - 1) / TS, tn2 = (h2 + TS - 1) / TS;
-    const int per_z = tm * (tn1 + tn2);
-    const int z = blockIdx.x / per_z, t = blockIdx.x % per_z;
-    const int m0 = (t / (tn1 + tn2)) * TS;
-    const int tcol = t % (tn1 + tn2);
-    const bool br = tcol >= tn1;
-    const int n0 = (br ? tcol - tn1 : tcol) * TS;
-    const int N = br ? h2 : h1;
-    const int coff = br ? h1 : 0;
-    const int ow = L.off[br ? 2 : 0], ob = L.off[br ? 3 : 1];
-    const int kbeg = z * D_KCHUNK, kend = min(n, kbeg + D_KCHUNK);
-    float* out = slab + (size_t)z * L.off[8];
-    auto a = [=] __device__(int m, int k) -> float {
-        const int id = br ? pv.nic(k) : pv.pop(k);
-        const float v = emb[(size_t)max(id, 0) * h0 + min(m, h0 - 1)];
-        return m < h0 ? (id >= 0 ? v : 0.f) : 1.f;
-    };
-    auto b = [=] __device__(int k, int nn) -> float { return dpre1[(size_t)k * h12 + coff + nn]; };
-    auto epi = [=] __device__(int m, int nn, float g) {
-        if (m < h0) out[ow + (size_t)m * N + nn] = g;
-        else out[ob + nn] = g;
-    };
-    if constexpr (V) {
-        auto a4 = [=] __device__(int m, int k) -> float4 {
-            const int kc = min(k, kend - 1);
-            const int id = br ? pv.nic(kc) : pv.pop(kc);
-            float4 v = ltg_ld4(emb + (size_t)max(id, 0) * h0, m, h0, k < kend && id >= 0);
-            if (m == h0 && k < kend) v.x = 1.f;       // the ones row: bias gradient (also for pairs with a hole: like the scalar path)
-            return v;
-        };
-        auto b4 = [=] __device__(int k, int nn) -> float4 { return ltg_ld4(dpre1 + (size_t)min(k, kend - 1) * h12 + coff, nn, N, k < kend); };
-        if constexpr (V == 3) ltg_gemm_block<MODE, TS, TS, (TS == 32 ? 128 : 64), 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, 3>(h0 + 1, N, m0, n0, kbeg, kend, a4, b4, epi);
-        else ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1, 1>(h0 + 1, N, m0, n0, kbeg, kend, a4, b, epi);
-    } else {
-        ltg_gemm_block<MODE, TS, TS, 128, 2, 2, true, true, false, FP8_S_EMB, FP8_S_G1>(h0 + 1, N, m0, n0, kbeg, kend, a, b, epi);
-    }
-}
-
-// One Adam sweep over all 8 discriminator tensors (train.py:163): g = sum of the split-K slabs.
-// Block 0 additionally reduces the per-row loss terms into loss_out[0] (d_loss, train.py:142).
-__global__ __launch_bounds__(NT) void k_d_adam(int ks, DLayout L, int SP, const float* __restrict__ slab, ltg_disc_state st, AdamC ad,
-                                               int n, const float* __restrict__ lrow, float* __restrict__ loss_out) {
-    __shared__ float red[NT / 64];
-    const int P = L.off[8];     // SP = stride of a slab (>= P); lrow == nullptr: the loss sum sits in slot P of every slab
-    for (int e = blockIdx.x * NT + threadIdx.x; e < P; e += gridDim.x * NT) {
-        float g = 0.f;
-        for (int z = 0; z < ks; ++z) g += slab[(size_t)z * SP + e];
-        int t = 0;
-#pragma unroll
-        for (int i = 1; i < 8; ++i) t += e >= L.off[i] ? 1 : 0;
-        const size_t i = (size_t)(e - L.off[t]);
-        adam_update(st.p[t], st.m[t], st.v[t], i, g, ad);
-        if (st.w1t_fp8 && (t == 0 || t == 2 || t == 4)) {   // operand-format shadow of the weight just written: [n][k], k contiguous
-            const int nn_w = L.off[t + 2] - L.off[t + 1];   // row length of the weight = size of the bias that follows it
-            const size_t k = i / nn_w, nn = i % nn_w;
-            const size_t kdim = (size_t)(L.off[t + 1] - L.off[t]) / nn_w;
-            uint8_t* dst = t == 0 ? st.w1t_fp8 : (t == 2 ? st.w2t_fp8 : st.w3t_fp8);
-            dst[nn * kdim + k] = ltg_f2fp8(st.p[t][i] * (float)(1 << FP8_S_W));
-            if (t == 4 && st.w3_fp8) st.w3_fp8[i] = ltg_f2fp8(st.p[t][i] * (float)(1 << FP8_S_W));   // w3 in its own layout (backward operand)
-        }
-    }
-    if (blockIdx.x == 0) {
-        float s = 0.f;
-        if (lrow) for (int i = threadIdx.x; i < n; i += NT) s += lrow[i];
-        else for (int z = threadIdx.x; z < ks; z += NT) s += slab[(size_t)z * SP + P];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) loss_out[0] = s;
-    }
-}
-
-// One gradient vector from the chunk slabs: out[e] = sum_z slab[z][e], out[P] = the loss sum (from lrow, or from slot P of the
-// slabs) -- what a rank contributes to the gradient all-reduce when the pair rows are split over ranks (ltg_d_grad).
-__global__ __launch_bounds__(NT) void k_d_grad_sum(int ks, int P, int stride, const float* __restrict__ slab, int n,
-                                                   const float* __restrict__ lrow, float* __restrict__ out) {
-    __shared__ float red[NT / 64];
-    for (int e = blockIdx.x * NT + threadIdx.x; e < P; e += gridDim.x * NT) {
-        float g = 0.f;
-        for (int z = 0; z < ks; ++z) g += slab[(size_t)z * stride + e];
-        out[e] = g;
-    }
-    if (blockIdx.x == 0) {
-        float s = 0.f;
-        if (lrow) for (int i = threadIdx.x; i < n; i += NT) s += lrow[i];
-        else for (int z = threadIdx.x; z < ks; z += NT) s += slab[(size_t)z * stride + P];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) out[P] = s;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Generator step: losses (train.py:145-157) and backward (closed forms: SURVEY 8 row a10)
-// ---------------------------------------------------------------------------------------------
-
-// Per-row partial statistics over THIS rank's item slab (5 floats per row):
-//   [0] m  = max_i logit            [1] s  = sum_i exp(logit - m)
-//   [2] xl = sum_i x_bi * logit     [3] ps = sum_{(b,i) in S, i local} exp(logit - m)     [4] nx = sum_i x_bi
-// Fake pairs carry GLOBAL item ids.  The shards' partials are all-gathered and combined in k_g_combine.
-constexpr int RP = 5;
-__global__ __launch_bounds__(NT) void k_row_partial(int I, int item_lo, const int32_t* __restrict__ indptr,
-                                                    const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                    const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
-                                                    const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
-                                                    float* __restrict__ rowpart) {
-    __shared__ float red[NT / 64];
-    const int b = blockIdx.x;
-    const float* row = logits + (size_t)b * I;
-    float mx = -INFINITY;
-    for (int i = threadIdx.x; i < I; i += NT) mx = fmaxf(mx, row[i]);
-    mx = block_max(mx, red);
-    float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
-    for (int i = threadIdx.x; i < I; i += NT) s += expf(row[i] - mx);
-    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
-        const float v = values ? values[e] : 1.f;
-        xl += v * row[indices[e]];
-        nx += v;
-    }
-    for (int q = threadIdx.x; q < nf; q += NT) {
-        const int it = f_gen[q] - item_lo;
-        if (f_row[q] == b && f_gen[q] >= 0 && f_pop[q] >= 0 && it >= 0 && it < I) ps += expf(row[it] - mx);
-    }
-    s = block_sum(s, red);
-    xl = block_sum(xl, red);
-    nx = block_sum(nx, red);
-    ps = block_sum(ps, red);
-    if (threadIdx.x == 0) {
-        float* o = rowpart + (size_t)b * RP;
-        o[0] = mx;
-        o[1] = s;
-        o[2] = xl;
-        o[3] = ps;
-        o[4] = nx;
-    }
-}
-
-// Large item slabs: the same statistics per (4096-item segment, row) in one pass over the logits (the segment
-// lives in registers between the max and the exp-sum), merged per row by k_row_partial_merge.
-constexpr int RS_SEG = 4096;
-// scratch of the row statistics: 5 floats per (4096-item segment, row) for k_row_partial_seg, or 2 floats per (workgroup of
-// k_dec1_fwd_stream<true>, row) -- at most 256 workgroups
-inline size_t segpart_floats(int I, int rows) {
-    const size_t a = ((size_t)I + RS_SEG - 1) / RS_SEG * rows * 5, b = (size_t)256 * rows * 2;
-    return a > b ? a : b;
-}
-__global__ __launch_bounds__(NT) void k_row_partial_seg(int I, int item_lo, const int32_t* __restrict__ indptr,
-                                                        const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                        const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
-                                                        const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
-                                                        float* __restrict__ segpart) {
-    __shared__ float red[NT / 64];
-    const int b = blockIdx.y, sg = blockIdx.x, B = gridDim.y;
-    const int i0 = sg * RS_SEG, i1 = min(I, i0 + RS_SEG);
-    const float* row = logits + (size_t)b * I;
-    float v[RS_SEG / NT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < RS_SEG / NT; ++j) {
-        const int i = i0 + threadIdx.x + NT * j;
-        v[j] = i < i1 ? row[i] : -INFINITY;
-        mx = fmaxf(mx, v[j]);
-    }
-    mx = block_max(mx, red);
-    float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < RS_SEG / NT; ++j) s += expf(v[j] - mx);  // exp(-inf) = 0 for the tail
-    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
-        const int it = indices[e];
-        if (it >= i0 && it < i1) {
-            const float x = values ? values[e] : 1.f;
-            xl += x * row[it];
-            nx += x;
-        }
-    }
-    for (int q = threadIdx.x; q < nf; q += NT) {
-        const int it = f_gen[q] - item_lo;
-        if (f_row[q] == b && f_gen[q] >= 0 && f_pop[q] >= 0 && it >= i0 && it < i1) ps += expf(row[it] - mx);
-    }
-    s = block_sum(s, red);
-    xl = block_sum(xl, red);
-    nx = block_sum(nx, red);
-    ps = block_sum(ps, red);
-    if (threadIdx.x == 0) {
-        float* o = segpart + ((size_t)sg * B + b) * RP;
-        o[0] = mx;
-        o[1] = s;
-        o[2] = xl;
-        o[3] = ps;
-        o[4] = nx;
-    }
-}
-
-// merge the segment partials of a row into one partial (same 5-float format); optionally also the row's lse
-__global__ __launch_bounds__(64) void k_row_partial_merge(int B, int nseg, const float* __restrict__ segpart,
-                                                          float* __restrict__ rowpart, float* __restrict__ lse) {
-    // one wave per row, lanes over the segments (49 at 200 000 items): every partial is requested at once
-    const int b = blockIdx.x, lane = threadIdx.x;
-    float M = -INFINITY;
-    for (int g = lane; g < nseg; g += 64) M = fmaxf(M, segpart[((size_t)g * B + b) * RP]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
-    float s = 0.f, xl = 0.f, ps = 0.f, nx = 0.f;
-    for (int g = lane; g < nseg; g += 64) {
-        const float* q = segpart + ((size_t)g * B + b) * RP;
-        const float sc = expf(q[0] - M);
-        s += q[1] * sc;
-        xl += q[2];
-        ps += q[3] * sc;
-        nx += q[4];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        xl += __shfl_xor(xl, o);
-        ps += __shfl_xor(ps, o);
-        nx += __shfl_xor(nx, o);
-    }
-    if (lane == 0) {
-        if (rowpart) {
-            float* o = rowpart + (size_t)b * RP;
-            o[0] = M;
-            o[1] = s;
-            o[2] = xl;
-            o[3] = ps;
-            o[4] = nx;
-        }
-        if (lse) lse[b] = M + logf(s);
-    }
-}
-
-// Row partial (same 5 floats) from the statistics k_dec1_fwd_stream<true> left: fold the G workgroups' (max, sum exp) pairs
-// of the row, then the sparse terms -- sum x logit and sum x over the row's entries, sum exp(logit - max) over its fake pairs
-__global__ __launch_bounds__(NT) void k_row_stats_merge(int B, int G, int I, int item_lo, const float* __restrict__ stat, const int32_t* __restrict__ indptr,
-                                                        const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                        const float* __restrict__ logits, int nf, const int32_t* __restrict__ f_row,
-                                                        const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
-                                                        float* __restrict__ rowpart, float* __restrict__ lse) {
-    __shared__ float red[NT / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* row = logits + (size_t)b * I;
-    // Round 5, second pass: TWO levels of requests for the common case (G <= NT, a row of at most NT entries, nf <= 4 NT fake pairs) -- level 1:
-    // the thread's (max, sum exp) pair, its first sparse entry and its first batch of fake-pair triples; level 2: the logits those point at.
-    // As written before -- max loop, barrier, the pairs AGAIN, indptr -> indices -> logit, triples -> logit -- the row cost seven dependent trips.
-    // Every sum below adds the same terms in the same order as before.
-    constexpr int FU = 4;
-    const int e0 = indptr[b], e1 = indptr[b + 1];
-    float st0 = -INFINITY, st1 = 0.f;
-    if (tid < G) {
-        const float* q = stat + ((size_t)tid * B + b) * 2;
-        st0 = q[0];
-        st1 = q[1];
-    }
-    int tg0[FU], tr0[FU], tp0[FU];
-#pragma unroll
-    for (int u = 0; u < FU; ++u) tg0[u] = tr0[u] = tp0[u] = -1;
-    if (nf > 0) {      // (ONE uniform branch around the twelve requests: a select per element made a basic block -- and a wait -- of each)
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int q = min(tid + u * NT, nf - 1);
-            tg0[u] = f_gen[q];
-            tr0[u] = f_row[q];
-            tp0[u] = f_pop[q];
-        }
-    }
-    int idx0 = -1;
-    float x0 = 1.f;
-    if (e0 + tid < e1) {
-        idx0 = indices[e0 + tid];
-        if (values) x0 = values[e0 + tid];
-    }
-    // level 2
-    const float rl0 = row[max(idx0, 0)];
-    float lg0[FU];
-    bool ok0[FU];
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int it = tg0[u] - item_lo;
-        ok0[u] = tid + u * NT < nf && tr0[u] == b && tg0[u] >= 0 && tp0[u] >= 0 && it >= 0 && it < I;
-        lg0[u] = row[ok0[u] ? it : 0];
-    }
-    float mx = fmaxf(-INFINITY, st0);
-    for (int g = tid + NT; g < G; g += NT) mx = fmaxf(mx, stat[((size_t)g * B + b) * 2]);
-    mx = block_max(mx, red);
-    float s = 0.f, xl = 0.f, nx = 0.f, ps = 0.f;
-    if (tid < G) s += st1 * expf(st0 - mx);
-    for (int g = tid + NT; g < G; g += NT) {
-        const float* q = stat + ((size_t)g * B + b) * 2;
-        s += q[1] * expf(q[0] - mx);
-    }
-    if (idx0 >= 0) {
-        xl += x0 * rl0;
-        nx += x0;
-    }
-    for (int e = e0 + tid + NT; e < e1; e += NT) {
-        const float x = values ? values[e] : 1.f;
-        xl += x * row[indices[e]];
-        nx += x;
-    }
-#pragma unroll
-    for (int u = 0; u < FU; ++u)
-        if (ok0[u]) ps += expf(lg0[u] - mx);
-    // (the thread's further fake pairs in batches of four -- the triples requested together, then the logits of the pairs that count,
-    // added in the loop's order)
-    for (int q0 = tid + FU * NT; q0 < nf; q0 += FU * NT) {
-        int tg[FU], tr[FU], tp[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int q = min(q0 + u * NT, nf - 1);
-            tg[u] = f_gen[q];
-            tr[u] = f_row[q];
-            tp[u] = f_pop[q];
-        }
-        float lg[FU];
-        bool ok[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int it = tg[u] - item_lo;
-            ok[u] = q0 + u * NT < nf && tr[u] == b && tg[u] >= 0 && tp[u] >= 0 && it >= 0 && it < I;
-            lg[u] = row[ok[u] ? it : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < FU; ++u)
-            if (ok[u]) ps += expf(lg[u] - mx);
-    }
-    s = block_sum(s, red);
-    xl = block_sum(xl, red);
-    nx = block_sum(nx, red);
-    ps = block_sum(ps, red);
-    if (threadIdx.x == 0) {
-        if (rowpart) {
-            float* o = rowpart + (size_t)b * RP;
-            o[0] = mx;
-            o[1] = s;
-            o[2] = xl;
-            o[3] = ps;
-            o[4] = nx;
-        }
-        if (lse) lse[b] = mx + logf(s);
-    }
-}
-
-// The R shards' partials of row rb folded into (lse, n_b, P_b, sum x logit): max over the ranks, then the sums in ascending rank order
-// (k_g_combine's arithmetic and order).  Round 5: for R <= 8 the R x 5 floats are requested AT ONCE (clamped, masked) -- as three plain loops
-// over a runtime rank count every partial was a round trip of its own, 3 R of them in front of the first logit k_dlogits_combine reads
-// (24 at eight ranks).
-__device__ __forceinline__ void ltg_rank_terms(const float* __restrict__ rowpart_all, int R, int B, int rb, float& l, float& nx, float& pb, float& xl) {
-    constexpr int RU = 8;
-    if (R == 1) {      // one rank: the five floats, the same operations in the same order as the general form
-        const float* q = rowpart_all + (size_t)rb * RP;
-        const float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
-        const float M = fmaxf(-INFINITY, a0);
-        const float se = 0.f + a1 * expf(a0 - M);
-        xl = 0.f + a2;
-        nx = 0.f + a4;
-        l = M + logf(se);
-        pb = 0.f + a3 * expf(a0 - l);
-        return;
-    }
-    if (R <= RU) {
-        float q0[RU], q1[RU], q2[RU], q3[RU], q4[RU];
-#pragma unroll
-        for (int r = 0; r < RU; ++r) {
-            const float* q = rowpart_all + ((size_t)min(r, R - 1) * B + rb) * RP;
-            q0[r] = q[0]; q1[r] = q[1]; q2[r] = q[2]; q3[r] = q[3]; q4[r] = q[4];
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < RU; ++r)
-            if (r < R) M = fmaxf(M, q0[r]);
-        float se = 0.f;
-        xl = 0.f;
-        nx = 0.f;
-#pragma unroll
-        for (int r = 0; r < RU; ++r)
-            if (r < R) {
-                se += q1[r] * expf(q0[r] - M);
-                xl += q2[r];
-                nx += q4[r];
-            }
-        l = M + logf(se);
-        pb = 0.f;
-#pragma unroll
-        for (int r = 0; r < RU; ++r)
-            if (r < R) pb += q3[r] * expf(q0[r] - l);
-        return;
-    }
-    float M = -INFINITY;
-    for (int r = 0; r < R; ++r) M = fmaxf(M, rowpart_all[((size_t)r * B + rb) * RP]);
-    float se = 0.f;
-    xl = 0.f;
-    nx = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
-        se += q[1] * expf(q[0] - M);
-        xl += q[2];
-        nx += q[4];
-    }
-    l = M + logf(se);
-    pb = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float* q = rowpart_all + ((size_t)r * B + rb) * RP;
-        pb += q[3] * expf(q[0] - l);
-    }
-}
-
-// Combine the R shards' row partials: lse, n_b, P_b per row, then the step scalars (train.py:145-157):
-// out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
-__global__ __launch_bounds__(NT) void k_g_combine(int B, int R, const float* __restrict__ rowpart_all, int nf,
-                                                  const float* __restrict__ kl_rows, const float* __restrict__ y,
-                                                  const int32_t* __restrict__ cnt, float anneal, float lam, float* __restrict__ lse,
-                                                  float* __restrict__ nb, float* __restrict__ Pb, float* __restrict__ out,
-                                                  float* __restrict__ out2) {
-    __shared__ float red[NT / 64];
-    float a = 0.f, k = 0.f, p = 0.f, sy = 0.f;
-    for (int b = threadIdx.x; b < B; b += NT) {
-        float l, nx, pb, xl;
-        ltg_rank_terms(rowpart_all, R, B, b, l, nx, pb, xl);
-        lse[b] = l;
-        nb[b] = nx;
-        Pb[b] = pb;
-        a += -xl + nx * l;  // neg_ll_row = -sum x (logit - lse)
-        if (kl_rows) k += kl_rows[b];
-        p += pb;
-    }
-    if (y)
-        for (int i = threadIdx.x; i < nf; i += NT) sy += y[i];
-    a = block_sum(a, red);
-    k = block_sum(k, red);
-    p = block_sum(p, red);
-    sy = block_sum(sy, red);
-    if (threadIdx.x == 0 && out) {
-        const float negll = a / (float)B, KL = k / (float)B;
-        const float c = (cnt && cnt[0] > 0) ? lam / (float)cnt[0] * sy : 0.f;
-        const float vae = negll + anneal * KL;
-        const float gan = -c * p;
-        const float r[6] = {vae + gan, vae, gan, p, sy, c};
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            out[i] = r[i];
-            if (out2) out2[i] = r[i];  // the caller's loss buffer (no separate device-to-device copy)
-        }
-    }
-}
-
-// candidate logits of this rank's slab (0 elsewhere): summed over ranks they give every rank the
-// logits of all candidates (the sampler needs nothing else of the [B, I] matrix)
-__global__ __launch_bounds__(NT) void k_gather_cand(int I, int item_lo, const int32_t* __restrict__ cand_ptr,
-                                                    const int32_t* __restrict__ cand_idx, const float* __restrict__ logits,
-                                                    float* __restrict__ out) {
-    const int b = blockIdx.x;
-    for (int j = cand_ptr[b] + threadIdx.x; j < cand_ptr[b + 1]; j += NT) {
-        const int it = cand_idx[j] - item_lo;
-        out[j] = (it >= 0 && it < I) ? logits[(size_t)b * I + it] : 0.f;
-    }
-}
-
-// dlogits[b][i] = p*(n_b/B + c*P_b) - x_bi/B - c*p*[(b,i) in S]; grid (segments, rows).
-constexpr int DL_SEG = 2048;
-__global__ __launch_bounds__(NT) void k_dlogits(int B, int I, const int32_t* __restrict__ indptr,
-                                                const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                const float* __restrict__ logits, const float* __restrict__ lse,
-                                                const float* __restrict__ nb, const float* __restrict__ Pb,
-                                                const float* __restrict__ scal, int nf, const int32_t* __restrict__ f_row,
-                                                const int32_t* __restrict__ f_gen, const int32_t* __restrict__ f_pop,
-                                                float* __restrict__ dlog, int item_lo) {
-    __shared__ float s_x[DL_SEG];
-    __shared__ uint8_t s_s[DL_SEG];
-    const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG;
-    const int i1 = min(I, i0 + DL_SEG);
-    for (int j = threadIdx.x; j < DL_SEG; j += NT) {
-        s_x[j] = 0.f;
-        s_s[j] = 0;
-    }
-    __syncthreads();
-    for (int e = indptr[b] + threadIdx.x; e < indptr[b + 1]; e += NT) {
-        const int it = indices[e];
-        if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
-    }
-    for (int s = threadIdx.x; s < nf; s += NT) {
-        const int it = f_gen[s] - item_lo;  // fake pairs carry global item ids
-        if (f_row[s] == b && f_gen[s] >= 0 && it >= i0 && it < i1 && f_pop[s] >= 0) s_s[it - i0] = 1;
-    }
-    __syncthreads();
-    const float invB = 1.f / (float)B, c = scal[5], l = lse[b];
-    const float alpha = nb[b] * invB + c * Pb[b];
-    const size_t base = (size_t)b * I;
-    for (int i = i0 + threadIdx.x; i < i1; i += NT) {
-        const float p = expf(logits[base + i] - l);
-        dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
-    }
-}
-
-// The same with the combine of the R shards' row partials folded in (no k_g_combine launch in front): every workgroup merges
-// the R x 5 partials of ITS row (uniform addresses: scalar loads) and adds up sum_j y_j itself; the segment-0 workgroups also
-// publish lse, and workgroup (0, 0) the step's scalars (train.py:154-157).  Same arithmetic and order as k_g_combine.
-// D16: dlog is stored as bf16 (the streaming consumers feed it to the bf16 MFMA anyway: same operand bits, half the bytes)
-template <bool D16>
-__global__ __launch_bounds__(NT) void k_dlogits_combine(int B, int I, int R, const int32_t* __restrict__ indptr,
-                                                        const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                        const float* __restrict__ logits, const float* __restrict__ rowpart_all,
-                                                        const float* __restrict__ kl_rows, const float* __restrict__ y,
-                                                        const int32_t* __restrict__ cnt, float anneal, float lam, int nf,
-                                                        const int32_t* __restrict__ f_row, const int32_t* __restrict__ f_gen,
-                                                        const int32_t* __restrict__ f_pop, float* __restrict__ dlog, float* __restrict__ lse,
-                                                        float* __restrict__ out, float* __restrict__ out2, int item_lo) {
-    __shared__ float s_x[DL_SEG];
-    __shared__ uint8_t s_s[DL_SEG];
-    __shared__ float red[NT / 64];
-    const int b = blockIdx.y, i0 = blockIdx.x * DL_SEG, tid = threadIdx.x;
-    const int i1 = min(I, i0 + DL_SEG);
-    const size_t base = (size_t)b * I;
-    // Round 5, second pass: every request that depends on nothing FIRST -- the segment's logits themselves (they were the LAST thing the kernel
-    // asked for, one dependent trip per 512 items behind five others), the first batch of y's and fake-pair triples, the thread's first sparse
-    // entry, the ranks' row partials and cnt[0].  Sums and stores are the same terms in the same order as before.
-    constexpr int FU = 4;
-    constexpr int NL = D16 ? DL_SEG / (2 * NT) : DL_SEG / NT;
-    float2 lg2[D16 ? NL : 1];
-    float lg1[D16 ? 1 : NL];
-    if constexpr (D16) {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) lg2[j] = *reinterpret_cast<const float2*>(logits + base + min(i0 + 2 * tid + 2 * NT * j, I - 2));   // (I % 8 == 0)
-    } else {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) lg1[j] = logits[base + min(i0 + tid + NT * j, I - 1)];
-    }
-    float ty0[FU];
-    int tg0[FU], tr0[FU], tp0[FU];
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        ty0[u] = 0.f;
-        tg0[u] = tr0[u] = tp0[u] = -1;
-    }
-    if (nf > 0) {      // (ONE uniform branch around the requests: a select per element made a basic block -- and a wait -- of each)
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int q = min(tid + u * NT, nf - 1);
-            tg0[u] = f_gen[q];
-            tr0[u] = f_row[q];
-            tp0[u] = f_pop[q];
-        }
-        if (y) {
-#pragma unroll
-            for (int u = 0; u < FU; ++u) ty0[u] = y[min(tid + u * NT, nf - 1)];
-        }
-    }
-    const int e0 = indptr[b], e1 = indptr[b + 1];
-    int it0 = -1;
-    float x0 = 1.f;
-    if (e0 + tid < e1) {
-        it0 = indices[e0 + tid];
-        if (values) x0 = values[e0 + tid];
-    }
-    auto row_terms = [=] __device__(int rb, float& l, float& nx, float& pb, float& xl) { ltg_rank_terms(rowpart_all, R, B, rb, l, nx, pb, xl); };
-    float l, nx, pb, xl;
-    row_terms(b, l, nx, pb, xl);
-    const int cntv = cnt ? cnt[0] : 0;
-    for (int j = tid; j < DL_SEG; j += NT) {
-        s_x[j] = 0.f;
-        s_s[j] = 0;
-    }
-    float sy = 0.f;
-    if (y) {
-#pragma unroll
-        for (int u = 0; u < FU; ++u)
-            if (tid + u * NT < nf) sy += ty0[u];
-        for (int q0 = tid + FU * NT; q0 < nf; q0 += FU * NT) {
-            float ty[FU];
-#pragma unroll
-            for (int u = 0; u < FU; ++u) ty[u] = y[min(q0 + u * NT, nf - 1)];
-#pragma unroll
-            for (int u = 0; u < FU; ++u)
-                if (q0 + u * NT < nf) sy += ty[u];
-        }
-    }
-    __syncthreads();
-    if (it0 >= i0 && it0 < i1) s_x[it0 - i0] = x0;
-    for (int e = e0 + tid + NT; e < e1; e += NT) {
-        const int it = indices[e];
-        if (it >= i0 && it < i1) s_x[it - i0] = values ? values[e] : 1.f;
-    }
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int it = tg0[u] - item_lo;  // fake pairs carry global item ids
-        if (tid + u * NT < nf && tr0[u] == b && tg0[u] >= 0 && it >= i0 && it < i1 && tp0[u] >= 0) s_s[it - i0] = 1;
-    }
-    for (int q0 = tid + FU * NT; q0 < nf; q0 += FU * NT) {
-        int tg[FU], tr[FU], tp[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int q = min(q0 + u * NT, nf - 1);
-            tg[u] = f_gen[q];
-            tr[u] = f_row[q];
-            tp[u] = f_pop[q];
-        }
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int it = tg[u] - item_lo;
-            if (q0 + u * NT < nf && tr[u] == b && tg[u] >= 0 && it >= i0 && it < i1 && tp[u] >= 0) s_s[it - i0] = 1;
-        }
-    }
-    sy = block_sum(sy, red);   // (its barriers also publish s_x / s_s)
-    const float invB = 1.f / (float)B;
-    const float c = cntv > 0 ? lam / (float)cntv * sy : 0.f;
-    const float alpha = nx * invB + c * pb;
-    if constexpr (D16) {   // I % 8 == 0 (stream_ok): pairs of items, one 8-B load and one 4-B store per lane
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = i0 + 2 * tid + 2 * NT * j;
-            if (i < i1) {
-                const float2 lg = lg2[j];
-                const float p0 = expf(lg.x - l), p1 = expf(lg.y - l);
-                const float d0 = p0 * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p0 : 0.f);
-                const float d1 = p1 * alpha - s_x[i + 1 - i0] * invB - (s_s[i + 1 - i0] ? c * p1 : 0.f);
-                reinterpret_cast<unsigned*>(dlog)[(base + i) >> 1] = (unsigned)ltg_f2bf(d0) | ((unsigned)ltg_f2bf(d1) << 16);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = i0 + tid + NT * j;
-            if (i < i1) {
-                const float p = expf(lg1[j] - l);
-                dlog[base + i] = p * alpha - s_x[i - i0] * invB - (s_s[i - i0] ? c * p : 0.f);
-            }
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) lse[b] = l;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {   // the step's scalars: out[0]=g_loss out[1]=vae_loss out[2]=gan_loss out[3]=sum_S p out[4]=sum_j y_j out[5]=c
-        float a = 0.f, k = 0.f, pp = 0.f;
-        for (int rb = threadIdx.x; rb < B; rb += NT) {
-            float l2, nx2, pb2, xl2;
-            row_terms(rb, l2, nx2, pb2, xl2);
-            a += -xl2 + nx2 * l2;
-            if (kl_rows) k += kl_rows[rb];
-            pp += pb2;
-        }
-        a = block_sum(a, red);
-        k = block_sum(k, red);
-        pp = block_sum(pp, red);
-        if (threadIdx.x == 0) {
-            const float negll = a / (float)B, KL = k / (float)B;
-            const float vae = negll + anneal * KL, gan = -c * pp;
-            const float r6[6] = {vae + gan, vae, gan, pp, sy, c};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                if (out) out[i] = r6[i];
-                if (out2) out2[i] = r6[i];
-            }
-        }
-    }
-}
-
-// dh2 partials: part[z][b][h] = sum_{i in split z} dlog[b][i] * W_p1t[i][h]   (split-K over items)
-template <bool BF16, bool BIG, bool V = false>
-__global__ __launch_bounds__(NT) void k_dh2_partial(int B, int I, int H, int kchunk, const float* __restrict__ dlog,
-                                                    const float* __restrict__ Wp1t, float* __restrict__ part) {
-    constexpr int BM = BIG ? 128 : 32, BN = BIG ? 64 : 32;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * kchunk, kend = min(I, kbeg + kchunk);
-    float* out = part + (size_t)blockIdx.z * B * H;
-    auto a = [=] __device__(int m, int k) -> float { return dlog[(size_t)m * I + k]; };
-    auto b = [=] __device__(int k, int n) -> float { return Wp1t[(size_t)k * H + n]; };
-    auto epi = [=] __device__(int m, int n, float acc) { out[(size_t)m * H + n] = acc; };
-    if constexpr (V) {   // 16-B loaders (I % 4 == 0, H % 4 == 0; the K chunks are multiples of 32)
-        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dlog + (size_t)min(m, B - 1) * I, k, kend, m < B); };
-        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp1t + (size_t)min(k, kend - 1) * H, n, H, k < kend); };
-        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, true, false, 0, 0, 3>(B, H, m0, n0, kbeg, kend, a4, b4, epi);
-    } else {
-        ltg_gemm_block<BF16, BM, BN, (BIG ? 64 : 128), 2, 2, false, true>(B, H, m0, n0, kbeg, kend, a, b, epi);
-    }
-}
-
-// da2 = (sum_z part) * (1 - h2^2)
-__global__ __launch_bounds__(NT) void k_da2(int n, int nsplit, const float* __restrict__ part, const float* __restrict__ h2,
-                                            float* __restrict__ da2, LtgGate started = LTG_NO_GATE) {
-    // started: opened by the first workgroup as soon as this kernel runs -- whatever preceded it on its stream (the dh2 product) is
-    // complete, which is what the forked weight update waits for
-    if (blockIdx.x == 0 && threadIdx.x == 0) ltg_gate_set(started);
-    // one output per thread (B H = 60 000 outputs -> 235 workgroups instead of 59 with float4), 16 slabs in flight; the slabs
-    // are added in ascending order whatever the unroll: bitwise the same sum as a serial walk
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-        // (round 5: 32 slabs in flight and the remainder as ONE clamped, masked batch -- with 16 and a serial remainder the 98 slabs of a
-        // 25 024-item step were eight dependent round trips in a 6-us launch on the caller's stream)
-        float s = 0.f;
-        constexpr int DU = 32;
-        const float t = h2 ? h2[i] : 0.f;      // (requested with the first slabs, not behind them)
-        for (int z = 0; z < nsplit; z += DU) {
-            float x[DU];
-#pragma unroll
-            for (int u = 0; u < DU; ++u) x[u] = part[(size_t)min(z + u, nsplit - 1) * n + i];
-#pragma unroll
-            for (int u = 0; u < DU; ++u)
-                if (z + u < nsplit) s += x[u];
-        }
-        da2[i] = s * __builtin_fmaf(-t, t, 1.f);   // (rounding pinned: fk_dz_dh2's operand loader computes the same expression)
-    }
-}
-
-// dW_p1t[i][h] = sum_b dlog[b][i] h2[b][h]; column H = ones -> db_p1[i]; fused Adam on both.
-template <bool BF16, int VAR, bool V = false, bool D16 = false>
-__global__ __launch_bounds__(NT) void k_dec1_bwd_adam(int B, int I, int H, const float* __restrict__ dlog,
-                                                      const float* __restrict__ h2, ltg_gen_state st, AdamC ad, int i_begin,
-                                                      const unsigned* __restrict__ poison = nullptr) {
-    if (ltg_poisoned(poison)) return;   // (the ragged tail of the one-call step's forked weight update)
-    // VAR 0: 32x32 tiles, scalar Adam epilogue; 1: 64x128, 2: 64x64, 3: 32x128 tiles with the float4 epilogue
-    constexpr bool BIG = VAR != 0;
-    constexpr int BM = VAR == 0 ? 32 : (VAR == 3 ? 32 : 64), BN = VAR == 0 ? 32 : (VAR == 2 ? 64 : 128);
-    const int m0 = i_begin + blockIdx.y * BM, n0 = blockIdx.x * BN;   // i_begin: first item row of this launch
-    float *W = st.p[3], *mW = st.m[3], *vW = st.v[3], *bb = st.p[7], *mb = st.m[7], *vb = st.v[7];
-    unsigned short* Wb = st.wp1t_bf16;  // optional bf16 shadow [I][ST_KP], kept in step with the master weights
-    auto a = [=] __device__(int m, int k) -> float {
-        if constexpr (D16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(dlog)[(size_t)k * I + m] << 16);   // dlog stored as bf16
-        else return dlog[(size_t)k * I + m];
-    };
-    auto b = [=] __device__(int k, int n) -> float {
-        const float v = h2[(size_t)k * H + min(n, H - 1)];
-        return n < H ? v : 1.f;
-    };
-    if constexpr (BIG) {
-        // Adam epilogue in float4 over whole 512-B row segments of W_p1t / m / v (H % 4 == 0)
-        auto epi = [=] __device__(int m, int n, float4 g) {
-            if (n < H) {
-                const size_t o = ((size_t)m * H + n) >> 2;
-                float4 p = reinterpret_cast<float4*>(W)[o], mm = reinterpret_cast<float4*>(mW)[o], vv = reinterpret_cast<float4*>(vW)[o];
-#define LTG_ADAM4(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
-                LTG_ADAM4(x) LTG_ADAM4(y) LTG_ADAM4(z) LTG_ADAM4(w)
-#undef LTG_ADAM4
-                reinterpret_cast<float4*>(W)[o] = p;
-                reinterpret_cast<float4*>(mW)[o] = mm;
-                reinterpret_cast<float4*>(vW)[o] = vv;
-                if (Wb) *reinterpret_cast<uint2*>(Wb + (size_t)m * ST_KP + n) = ltg_pack4(p);
-            } else {
-                adam_update(bb, mb, vb, m, g.x, ad);  // n == H: the ones column = bias gradient
-            }
-        };
-        ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
-    } else {
-        auto epi = [=] __device__(int m, int n, float g) {
-            if (n < H) {
-                adam_update(W, mW, vW, (size_t)m * H + n, g, ad);
-                if (Wb) Wb[(size_t)m * ST_KP + n] = ltg_f2bf(W[(size_t)m * H + n]);
-            } else adam_update(bb, mb, vb, m, g, ad);
-        };
-        if constexpr (V) {   // 16-B loaders (I % 4 == 0, H % 4 == 0: the ones column n == H opens its own group)
-            auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dlog + (size_t)min(k, B - 1) * I, m, I, k < B); };
-            auto b4 = [=] __device__(int k, int n) -> float4 {
-                float4 v = ltg_ld4(h2 + (size_t)min(k, B - 1) * H, n, H, k < B);
-                if (n == H && k < B) v.x = 1.f;
-                return v;
-            };
-            ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true, false, 0, 0, 3>(I, H + 1, m0, n0, 0, B, a4, b4, epi);
-        } else {
-            ltg_gemm_block<BF16, BM, BN, 128, 2, 2, true, true>(I, H + 1, m0, n0, 0, B, a, b, epi);
-        }
-    }
-}
-
-// dz = da2 . W_p0^T, then d mu / d logvar (KL + reparameterisation terms)
-template <bool V, int BKV = 128>
-__global__ __launch_bounds__(NT) void k_dz(int B, int Z, int H, const float* __restrict__ da2, const float* __restrict__ Wp0,
-                                           const float* __restrict__ mulv, const float* __restrict__ eps_in, float is_training,
-                                           float anneal, uint64_t seed, uint64_t step, float* __restrict__ dmlv) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const float invB = 1.f / (float)B;
-    auto a = [=] __device__(int m, int k) -> float { return da2[(size_t)m * H + k]; };
-    auto b = [=] __device__(int k, int n) -> float { return Wp0[(size_t)n * H + k]; };
-    auto epi = [=] __device__(int m, int n, float dz) {
-        const float mu = mulv[(size_t)m * 2 * Z + n], lv = mulv[(size_t)m * 2 * Z + Z + n];
-        float e = 0.f;
-        if (is_training != 0.f)
-            e = eps_in ? eps_in[(size_t)m * Z + n] : ltg_rng_normal(seed, LTG_STREAM_VAE_EPS, step, (uint64_t)m * Z + n);
-        dmlv[(size_t)m * 2 * Z + n] = dz + anneal * mu * invB;
-        dmlv[(size_t)m * 2 * Z + Z + n] = dz * is_training * e * expf(0.5f * lv) * 0.5f + anneal * 0.5f * (expf(lv) - 1.f) * invB;
-    };
-    if constexpr (V) {
-        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(da2 + (size_t)min(m, B - 1) * H, k, H, m < B); };
-        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wp0 + (size_t)min(n, Z - 1) * H, k, H, n < Z); };
-        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, 3>(B, Z, m0, n0, 0, H, a4, b4, epi);
-    } else {
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, Z, m0, n0, 0, H, a, b, epi);
-    }
-}
-
-// generic "weight gradient + Adam": G[m][n] = sum_k L(k,m) * R(k,n) with ones-augmented row m == Min
-// (bias gradient).  L: [K][Min] activations, R: [K][N] upstream gradient.
-template <bool V>
-__global__ __launch_bounds__(NT) void k_wgrad_adam(int K, int Min, int N, const float* __restrict__ L,
-                                                   const float* __restrict__ R, float* __restrict__ W, float* __restrict__ mW,
-                                                   float* __restrict__ vW, float* __restrict__ bias, float* __restrict__ mb,
-                                                   float* __restrict__ vb, AdamC ad) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float {
-        const float v = L[(size_t)k * Min + min(m, Min - 1)];
-        return m < Min ? v : 1.f;
-    };
-    auto b = [=] __device__(int k, int n) -> float { return R[(size_t)k * N + n]; };
-    auto epi = [=] __device__(int m, int n, float g) {
-        if (m < Min) adam_update(W, mW, vW, (size_t)m * N + n, g, ad);
-        else adam_update(bias, mb, vb, n, g, ad);
-    };
-    if constexpr (V) {   // Min % 4 == 0: the ones row (m == Min) opens its own group
-        auto a4 = [=] __device__(int m, int k) -> float4 {
-            float4 v = ltg_ld4(L + (size_t)min(k, K - 1) * Min, m, Min, k < K);
-            if (m == Min && k < K) v.x = 1.f;
-            return v;
-        };
-        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(R + (size_t)min(k, K - 1) * N, n, N, k < K); };
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true, false, 0, 0, 3>(Min + 1, N, m0, n0, 0, K, a4, b4, epi);
-    } else {
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, true, true>(Min + 1, N, m0, n0, 0, K, a, b, epi);
-    }
-}
-
-// dh1 = dmlv . W_q1^T ; da1 = dh1 * (1 - h1^2)
-template <bool V, int BKV = 128>
-__global__ __launch_bounds__(NT) void k_dh1(int B, int H, int Z2, const float* __restrict__ dmlv,
-                                            const float* __restrict__ Wq1, const float* __restrict__ h1, float* __restrict__ da1) {
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    auto a = [=] __device__(int m, int k) -> float { return dmlv[(size_t)m * Z2 + k]; };
-    auto b = [=] __device__(int k, int n) -> float { return Wq1[(size_t)n * Z2 + k]; };
-    auto epi = [=] __device__(int m, int n, float acc) {
-        const float t = h1[(size_t)m * H + n];
-        da1[(size_t)m * H + n] = acc * (1.f - t * t);
-    };
-    if constexpr (V) {
-        auto a4 = [=] __device__(int m, int k) -> float4 { return ltg_ld4(dmlv + (size_t)min(m, B - 1) * Z2, k, Z2, m < B); };
-        auto b4 = [=] __device__(int k, int n) -> float4 { return ltg_ld4(Wq1 + (size_t)min(n, H - 1) * Z2, k, Z2, n < H); };
-        ltg_gemm_block<false, 32, 32, BKV, 2, 2, false, false, false, 0, 0, 3>(B, H, m0, n0, 0, Z2, a4, b4, epi);
-    } else {
-        ltg_gemm_block<false, 32, 32, 128, 2, 2, false, false>(B, H, m0, n0, 0, Z2, a, b, epi);
-    }
-}
-
-// Sparse gradient rows of W_q0: G[u][:] = sum over the batch entries of item uitem[u] of
-// keep * val * row_scale[b] * da1[b][:]; row n_unique = bias gradient sum_b da1[b][:].
-// One workgroup per distinct item: the 4 waves split its entries (a popular item is in dozens of the
-// batch's rows), lanes own float4 column chunks, partials meet in LDS.
-constexpr int ENC0_BIAS_PARTS = 8;  // the bias gradient (column sum of da1 over the batch) is cut into this many partial rows
-__global__ __launch_bounds__(NT) void k_enc0_grad(int B, int I, int H, int nu, const int32_t* __restrict__ uptr,
-                                                  const int32_t* __restrict__ rowidx, const int32_t* __restrict__ csr_pos,
-                                                  const int32_t* __restrict__ indices, const float* __restrict__ values,
-                                                  const uint8_t* __restrict__ drop_keep, float keep, uint64_t seed, uint64_t step,
-                                                  const float* __restrict__ row_scale, const float* __restrict__ da1,
-                                                  float* __restrict__ G, int item_lo, int Ig) {
-    extern __shared__ __attribute__((aligned(16))) float s_g[];  // [4][H]
-    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int H4 = H >> 2;
-    constexpr int MAXQ = 4;
-    float4 acc[MAXQ];
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* d4 = reinterpret_cast<const float4*>(da1);
-    // workgroups u < nu: one distinct item each; u >= nu: part (u - nu) of the bias row = batch rows [q0, q1) (one long row
-    // of B entries would be the launch's critical path)
-    const int bp = u - nu, per = (B + ENC0_BIAS_PARTS - 1) / ENC0_BIAS_PARTS;
-    const int q0 = u < nu ? uptr[u] : min(B, bp * per), q1 = u < nu ? uptr[u + 1] : min(B, (bp + 1) * per);
-    // 4 entries per trip and wave: their (dependent) index chains and da1 row loads overlap
-    for (int q = q0 + w; q < q1; q += 4 * (NT / 64)) {
-        int b[4];
-        float sc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int qt = q + t * (NT / 64);
-            const bool ok = qt < q1;
-            const int qc = ok ? qt : q;
-            if (u < nu) {
-                b[t] = rowidx[qc];
-                const int pos = csr_pos[qc];
-                const int it = indices[pos];
-                const bool kp = drop_keep ? (drop_keep[pos] != 0)
-                                          : ltg_rng_keep(seed, LTG_STREAM_VAE_DROPOUT, step, (uint64_t)b[t] * (uint64_t)Ig + item_lo + it, keep);
-                sc[t] = (ok && kp) ? (values ? values[pos] : 1.f) * row_scale[b[t]] : 0.f;
-            } else {
-                b[t] = qc;  // bias row: every batch row, weight 1
-                sc[t] = ok ? 1.f : 0.f;
-            }
-        }
-#pragma unroll
-        for (int qq = 0; qq < MAXQ; ++qq) {
-            const int c4 = lane + 64 * qq;
-            if (c4 < H4) {
-                float4 d[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) d[t] = d4[(size_t)b[t] * H4 + c4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[qq].x += sc[t] * d[t].x;
-                    acc[qq].y += sc[t] * d[t].y;
-                    acc[qq].z += sc[t] * d[t].z;
-                    acc[qq].w += sc[t] * d[t].w;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int qq = 0; qq < MAXQ; ++qq) {
-        const int c4 = lane + 64 * qq;
-        if (c4 < H4) reinterpret_cast<float4*>(s_g + (size_t)w * H)[c4] = acc[qq];
-    }
-    __syncthreads();
-    for (int c = tid; c < H; c += NT) G[(size_t)u * H + c] = s_g[c] + s_g[H + c] + s_g[2 * H + c] + s_g[3 * H + c];
-}
-
-// Dense Adam sweep over W_q0 [I][H] (+ bias row I): pure streaming, 16 B per lane, the sparse gradient row
-// (if any) is picked up through slot[i].  TF's Adam touches every row every step (a zero gradient still
-// decays m, v and moves theta), so this sweep is the algorithmic 24 B/parameter.
-// item -> gradient row map of ONE batch, built on the fly when the caller keeps no per-batch slot[] cache (ltg_batch.slot ==
-// NULL): map[] was memset to -1; group u's item id is the column of its first entry
-__global__ __launch_bounds__(NT) void k_fill_i32(int n, int32_t v, int32_t* __restrict__ p) {
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) p[i] = v;
-}
-__global__ __launch_bounds__(NT) void k_slot_scatter(int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
-                                                     const int32_t* __restrict__ indices, int32_t* __restrict__ map) {
-    const int u = blockIdx.x * NT + threadIdx.x;
-    if (u < nu) map[indices[csr_pos[uptr[u]]]] = u;
-}
-
-__global__ __launch_bounds__(NT) void k_enc0_bwd_adam(int I, int H, int nu, const int32_t* __restrict__ slot,
-                                                      const float* __restrict__ G, ltg_gen_state st, AdamC ad) {
-    const int H4 = H >> 2;  // H % 4 == 0 (checked on the host)
-    const size_t total = (size_t)(I + 1) * H4;
-    float4* W4 = reinterpret_cast<float4*>(st.p[0]);
-    float4* m4 = reinterpret_cast<float4*>(st.m[0]);
-    float4* v4 = reinterpret_cast<float4*>(st.v[0]);
-    float4* b4 = reinterpret_cast<float4*>(st.p[4]);
-    float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
-    float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
-    const float4* G4 = reinterpret_cast<const float4*>(G);
-    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
-        const int i = (int)(e / H4), c = (int)(e % H4);
-        float4* P = i < I ? W4 + e : b4 + c;
-        float4* Mm = i < I ? m4 + e : mb4 + c;
-        float4* Vv = i < I ? v4 + e : vb4 + c;
-        float4 p = *P, mm = *Mm, vv = *Vv;
-        const int u = i < I ? slot[i] : nu;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u >= 0) g = G4[(size_t)u * H4 + c];
-        if (i >= I) {   // bias row: the remaining partial rows of k_enc0_grad
-#pragma unroll
-            for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
-                const float4 t = G4[(size_t)(nu + j) * H4 + c];
-                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-            }
-        }
-#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
-        LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
-#undef LTG_ADAM1
-        *P = p;
-        *Mm = mm;
-        *Vv = vv;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Lazy Adam clock of W_q0 (ltg_gen_state.q0_last, include/ltg.h).  A zero-gradient Adam step of a row is
-//     m <- b1 m,  v <- b2 v,  W <- W - lr_t m / (sqrt(v) + eps)
-// -- the dense sweep's expressions with g == 0 (b1 m + (1-b1) 0 rounds once either way) -- so a row that lags k steps is
-// brought up to date by running those k steps in registers: 24 B/parameter of traffic once per k steps instead of every
-// step.  The arithmetic (k x IEEE sqrt and divide per parameter) does not shrink; it moves off the HBM stream.
-// ---------------------------------------------------------------------------------------------
-#define LTG_Q0_MASK (LTG_Q0_HIST - 1)
-
-// One row (H4 float4 columns at W4/m4/v4) from ordinal `from` to ordinal `to`: zero-gradient steps, then -- if G4 is given --
-// the step `to` itself with gradient row G4 and learning rate ad.lr_t (the caller's current step).
-// (q0_row_steps: the zero-gradient steps from + 1 .. nz of one float4 column that is already in registers; true = it changed)
-__device__ __forceinline__ bool q0_row_steps(float4& p, float4& mm, float4& vv, int from, int nz, const float* __restrict__ lr_hist, const AdamC ad) {
-    const bool m0 = mm.x == 0.f && mm.y == 0.f && mm.z == 0.f && mm.w == 0.f;
-    const bool v0 = vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
-    if (m0 && v0) return false;                           // a row no batch has touched yet: every step is the identity
-    if (m0) {                                             // W does not move (0 / (sqrt(v) + eps) == 0): only v decays
-        for (int j = from + 1; j <= nz; ++j) { vv.x *= ad.b2; vv.y *= ad.b2; vv.z *= ad.b2; vv.w *= ad.b2; }
-    } else {
-        for (int j = from + 1; j <= nz; ++j) {
-            const float lr = lr_hist[j & LTG_Q0_MASK];
-#define LTG_ADAM0(f)          \
-    mm.f = ad.b1 * mm.f;      \
-    vv.f = ad.b2 * vv.f;      \
-    p.f = adam_move(p.f, lr * mm.f, vv.f, ad.eps);   /* adam1 with g == 0: fma(b1, m, 0) rounds like b1 m */
-            LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
-#undef LTG_ADAM0
-        }
-    }
-    return true;
-}
-// ONE zero-gradient step with the learning rate given (the step the caller is performing: its rate is not in the ring yet)
-__device__ __forceinline__ bool q0_zero_step(float4& p, float4& mm, float4& vv, float lr, const AdamC ad) {
-    const bool m0 = mm.x == 0.f && mm.y == 0.f && mm.z == 0.f && mm.w == 0.f;
-    const bool v0 = vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
-    if (m0 && v0) return false;
-    if (m0) {
-        vv.x *= ad.b2; vv.y *= ad.b2; vv.z *= ad.b2; vv.w *= ad.b2;
-    } else {
-#define LTG_ADAM0(f)          \
-    mm.f = ad.b1 * mm.f;      \
-    vv.f = ad.b2 * vv.f;      \
-    p.f = adam_move(p.f, lr * mm.f, vv.f, ad.eps);
-        LTG_ADAM0(x) LTG_ADAM0(y) LTG_ADAM0(z) LTG_ADAM0(w)
-#undef LTG_ADAM0
-    }
-    return true;
-}
-__device__ __forceinline__ void q0_row_advance(float4* __restrict__ W4, float4* __restrict__ m4, float4* __restrict__ v4, int H4, int from, int to,
-                                               const float* __restrict__ lr_hist, const float4* __restrict__ G4, const AdamC ad) {
-    const int nz = G4 ? to - 1 : to;   // last zero-gradient step
-    for (int c = threadIdx.x; c < H4; c += blockDim.x) {
-        float4 p = W4[c], mm = m4[c], vv = v4[c];
-        const bool moved = q0_row_steps(p, mm, vv, from, nz, lr_hist, ad);
-        if (!G4 && !moved) continue;
-        if (G4) {
-            const float4 g = G4[c];
-#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
-            LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
-#undef LTG_ADAM1
-        }
-        W4[c] = p;
-        m4[c] = mm;
-        v4[c] = vv;
-    }
-}
-
-#define Q0_NT 192
-// rows of the batch's distinct items (G-step batches carry the list): up to `target`, before enc-0 reads them
-__global__ __launch_bounds__(Q0_NT) void k_q0_touch_unique(int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
-                                                           const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target,
-                                                           ltg_gen_state st, AdamC ad, const unsigned* __restrict__ poison = nullptr,
-                                                           int32_t* __restrict__ mark = nullptr, unsigned seq = 0u) {
-    // (one-call step, slice on the side stream: the slice of the previous call is done with every row before this kernel starts -- the
-    // previous call's last kernel on this stream waited for word 6, ltg_gate_wait_tail; poison: that wait gave up)
-    // mark: ltg_pipe.q0_mark -- "call seq's batch holds this row" for the ahead kernel of the same call (k_q0_touch_ahead)
-    if (ltg_poisoned(poison)) return;
-    const int u = blockIdx.x;
-    if (u >= nu) return;
-    const int H4 = H >> 2;
-    if (uitem && H4 <= Q0_NT) {   // the item in one load; its clock and its row requested together (three dependent round trips, not six)
-        const int i = uitem[u];
-        const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
-        const int from = st.q0_last[i];
-        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
-               vv = reinterpret_cast<const float4*>(st.v[0])[off];
-        if (mark && threadIdx.x == 0) mark[i] = (int32_t)seq;
-        __syncthreads();   // every thread has read q0_last[i]
-        if (from >= target) return;
-        if ((int)threadIdx.x < H4 && q0_row_steps(p, mm, vv, from, target, st.q0_lr_hist, ad)) {
-            reinterpret_cast<float4*>(st.p[0])[off] = p;
-            reinterpret_cast<float4*>(st.m[0])[off] = mm;
-            reinterpret_cast<float4*>(st.v[0])[off] = vv;
-        }
-        if (threadIdx.x == 0) st.q0_last[i] = target;
-        return;
-    }
-    const int i = uitem ? uitem[u] : indices[csr_pos[uptr[u]]];
-    const int from = st.q0_last[i];
-    if (mark && threadIdx.x == 0) mark[i] = (int32_t)seq;
-    if (from >= target) return;
-    const size_t off = (size_t)i * H4;
-    q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
-                   from, target, st.q0_lr_hist, nullptr, ad);
-    __syncthreads();   // every thread has read q0_last[i]
-    if (threadIdx.x == 0) st.q0_last[i] = target;
-}
-
-// The NEXT batch's rows, during the current call (ordinal `seq`, Adam step `cur` = q0_ord + 1), on the side stream behind the slice:
-// up to `cur` -- zero-gradient steps from the ring up to cur - 1, then step cur itself with this call's learning rate (the sparse gradient
-// kernel stores it into the ring, possibly later) -- for every row the CURRENT batch does not hold (mark != seq: nobody else reads or
-// writes those rows during this call); the rows it holds reach `cur` through the sparse gradient kernel.  Either way the row is marked
-// for the next call (seq + 1), whose catch-up launch the host then leaves out (ltg_pipe.caught_up).
-__global__ __launch_bounds__(Q0_NT) void k_q0_touch_ahead(int H, int nu, const int32_t* __restrict__ uitem, int cur, ltg_gen_state st, AdamC ad,
-                                                          int32_t* __restrict__ mark, unsigned seq, const unsigned* __restrict__ poison) {
-    if (ltg_poisoned(poison)) return;
-    const int u = blockIdx.x;
-    if (u >= nu) return;
-    const int H4 = H >> 2;
-    const int i = uitem[u];
-    const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
-    const bool held = (unsigned)mark[i] == seq;
-    const int from = st.q0_last[i];
-    // (requested beside the mark and the clock; a held row's values may be mid-update by the sparse gradient kernel: they are discarded)
-    float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
-           vv = reinterpret_cast<const float4*>(st.v[0])[off];
-    __syncthreads();   // every thread has read mark[i] and q0_last[i]
-    if (threadIdx.x == 0) mark[i] = (int32_t)(seq + 1u);
-    if (held || from >= cur) return;
-    if ((int)threadIdx.x < H4) {
-        bool moved = q0_row_steps(p, mm, vv, from, cur - 1, st.q0_lr_hist, ad);
-        moved = q0_zero_step(p, mm, vv, ad.lr_t, ad) || moved;
-        if (moved) {
-            reinterpret_cast<float4*>(st.p[0])[off] = p;
-            reinterpret_cast<float4*>(st.m[0])[off] = mm;
-            reinterpret_cast<float4*>(st.v[0])[off] = vv;
-        }
-    }
-    if (threadIdx.x == 0) st.q0_last[i] = cur;
-}
-
-// The catch-up of a batch's rows AND the rotating slice (rows start, start + stride, ...) in ONE launch, both up to `target`: a row
-// that is in both sets belongs to the workgroup whose atomic max on its clock comes first (the other one sees `target` and leaves);
-// the consumers are later launches.  The one-call step's form of the two kernels above and below (one launch, no side-stream join).
-__global__ __launch_bounds__(Q0_NT) void k_q0_touch_slice(int I, int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
-                                                          const int32_t* __restrict__ indices, const int32_t* __restrict__ uitem, int target, int start,
-                                                          int stride, ltg_gen_state st, AdamC ad) {
-    __shared__ int s_from;
-    const int b = blockIdx.x;
-    int i;
-    if (b < nu) i = uitem ? uitem[b] : indices[csr_pos[uptr[b]]];
-    else {
-        i = start + (b - nu) * stride;
-        if (i >= I) return;
-    }
-    const int H4 = H >> 2;
-    if (H4 <= Q0_NT) {   // the row requested beside the claim (rows are never written by two launches at once: whoever loses the claim
-                         // only discards what it loaded)
-        if (threadIdx.x == 0) s_from = atomicMax(st.q0_last + i, target);
-        const size_t off = (size_t)i * H4 + min((int)threadIdx.x, H4 - 1);
-        float4 p = reinterpret_cast<const float4*>(st.p[0])[off], mm = reinterpret_cast<const float4*>(st.m[0])[off],
-               vv = reinterpret_cast<const float4*>(st.v[0])[off];
-        __syncthreads();
-        const int from = s_from;
-        if (from >= target) return;
-        if ((int)threadIdx.x < H4 && q0_row_steps(p, mm, vv, from, target, st.q0_lr_hist, ad)) {
-            reinterpret_cast<float4*>(st.p[0])[off] = p;
-            reinterpret_cast<float4*>(st.m[0])[off] = mm;
-            reinterpret_cast<float4*>(st.v[0])[off] = vv;
-        }
-        return;
-    }
-    if (threadIdx.x == 0) s_from = atomicMax(st.q0_last + i, target);
-    __syncthreads();
-    const int from = s_from;
-    if (from >= target) return;
-    const size_t off = (size_t)i * H4;
-    q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
-                   from, target, st.q0_lr_hist, nullptr, ad);
-}
-
-// forward-only batches (no distinct-item list): one workgroup per user row walks its entries; the first workgroup to claim
-// a lagging item row (compare-and-swap on its clock) brings it up to date, the consumers are later launches
-__global__ __launch_bounds__(Q0_NT) void k_q0_touch_rows(int H, int R, const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int target,
-                                                         ltg_gen_state st, AdamC ad) {
-    __shared__ int s_from;
-    const int r = blockIdx.x;
-    const int H4 = H >> 2;
-    const int e1 = indptr[r + 1];
-    for (int e = indptr[r]; e < e1; ++e) {
-        const int i = indices[e];
-        if (threadIdx.x == 0) {
-            const int old = __hip_atomic_load(st.q0_last + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_from = (old < target && atomicCAS(st.q0_last + i, old, target) == old) ? old : -1;
-        }
-        __syncthreads();
-        const int from = s_from;
-        __syncthreads();
-        if (from < 0) continue;
-        const size_t off = (size_t)i * H4;
-        q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off,
-                       H4, from, target, st.q0_lr_hist, nullptr, ad);
-    }
-}
-
-// G step `ord` on the batch's rows: gradient row u of G (k_enc0_grad layout) for distinct item u; block nu = the bias row
-// (dense: its gradient is never zero) + the learning rate of this step into the history ring
-__global__ __launch_bounds__(Q0_NT) void k_q0_step_touched(int I, int H, int nu, const int32_t* __restrict__ uptr, const int32_t* __restrict__ csr_pos,
-                                                           const int32_t* __restrict__ indices, const float* __restrict__ G, int ord, ltg_gen_state st,
-                                                           AdamC ad) {
-    const int u = blockIdx.x;
-    const int H4 = H >> 2;
-    const float4* G4 = reinterpret_cast<const float4*>(G);
-    if (u == nu) {
-        if (threadIdx.x == 0) st.q0_lr_hist[ord & LTG_Q0_MASK] = ad.lr_t;
-        float4* b4 = reinterpret_cast<float4*>(st.p[4]);
-        float4* mb4 = reinterpret_cast<float4*>(st.m[4]);
-        float4* vb4 = reinterpret_cast<float4*>(st.v[4]);
-        for (int c = threadIdx.x; c < H4; c += blockDim.x) {
-            float4 g = G4[(size_t)nu * H4 + c];
-#pragma unroll
-            for (int j = 1; j < ENC0_BIAS_PARTS; ++j) {
-                const float4 t = G4[(size_t)(nu + j) * H4 + c];
-                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-            }
-            float4 p = b4[c], mm = mb4[c], vv = vb4[c];
-#define LTG_ADAM1(f) adam1(p.f, mm.f, vv.f, g.f, ad.lr_t, ad);
-            LTG_ADAM1(x) LTG_ADAM1(y) LTG_ADAM1(z) LTG_ADAM1(w)
-#undef LTG_ADAM1
-            b4[c] = p;
-            mb4[c] = mm;
-            vb4[c] = vv;
-        }
-        return;
-    }
-    const int i = indices[csr_pos[uptr[u]]];
-    const int from = st.q0_last[i];
-    const size_t off = (size_t)i * H4;
-    q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off, H4,
-                   from, ord, st.q0_lr_hist, G4 + (size_t)u * H4, ad);
-    __syncthreads();
-    if (threadIdx.x == 0) st.q0_last[i] = ord;
-}
-
-// rows start, start + stride, ...: zero-gradient steps up to `target` (the rotating slice of a G step; the flush: 0, 1)
-__global__ __launch_bounds__(Q0_NT) void k_q0_sweep(int I, int H, int start, int stride, int target, ltg_gen_state st, AdamC ad,
-                                                    const unsigned* __restrict__ poison = nullptr) {
-    if (ltg_poisoned(poison)) return;
-    const int H4 = H >> 2;
-    for (size_t i = (size_t)start + (size_t)blockIdx.x * stride; i < (size_t)I; i += (size_t)gridDim.x * stride) {
-        const int from = st.q0_last[i];
-        __syncthreads();   // every thread has read the row's clock before thread 0 may move it
-        if (from >= target) continue;
-        const size_t off = i * H4;
-        q0_row_advance(reinterpret_cast<float4*>(st.p[0]) + off, reinterpret_cast<float4*>(st.m[0]) + off, reinterpret_cast<float4*>(st.v[0]) + off,
-                       H4, from, target, st.q0_lr_hist, nullptr, ad);
-        if (threadIdx.x == 0) st.q0_last[i] = target;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Sampler: sample_from_generator_new (sample.py:40-67) + pair construction (train.py:227-251).
-// One wave per user.  Successive sampling without replacement == Gumbel-top-k on log p.
-// ---------------------------------------------------------------------------------------------
-constexpr int SP_NT = 1024;   // 16 waves: the rank loop is arithmetic over LDS broadcasts -- four waves per SIMD hide the LDS latency
-__global__ __launch_bounds__(SP_NT) void k_sample_pairs(int I, const int32_t* __restrict__ cand_ptr,
-                                                        const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ pop_ptr,
-                                                        const int32_t* __restrict__ pop_idx, const int32_t* __restrict__ n_sample,
-                                                        const int32_t* __restrict__ slot_ptr, const uint8_t* __restrict__ valid_item,
-                                                        const float* __restrict__ u_gumbel, const float* __restrict__ u_pick,
-                                                        uint64_t seed, uint64_t step, const float* __restrict__ logits,
-                                                        const float* __restrict__ lse, int32_t* __restrict__ gen_out,
-                                                        int32_t* __restrict__ pop_out, int32_t* __restrict__ cnt_out,
-                                                        const float* __restrict__ cand_logit, int rps) {
-    // I is the GLOBAL item count (RNG index space); cand_logit (optional, aligned with cand_idx) replaces
-    // the [B, I] logits matrix when the items are sharded over ranks.
-    extern __shared__ __attribute__((aligned(16))) float s_key[];
-    __shared__ int s_w[SP_NT / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ns = n_sample[b];
-    const int s0 = slot_ptr[b];
-    if (ns <= 0) return;  // uniform for the whole workgroup
-    // several batches in one launch (ltg_sample_inputs.rows_per_step): the row's own batch counter, its row there, its batch's count
-    const uint64_t kb = rps > 0 ? (uint64_t)(b % rps) : (uint64_t)b;
-    step += rps > 0 ? (uint64_t)(b / rps) : 0;
-    cnt_out += rps > 0 ? b / rps : 0;
-    const int c0 = cand_ptr[b], nc = cand_ptr[b + 1] - c0;
-    const float l = lse[b];
-    const float* row = logits + (size_t)b * I;
-    // sum over the workgroup of a small non-negative count (all threads get it)
-    auto block_count = [&](int x) -> int {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-        __syncthreads();
-        if (lane == 0) s_w[w] = x;
-        __syncthreads();
-        int t = 0;
-#pragma unroll
-        for (int i = 0; i < SP_NT / 64; ++i) t += s_w[i];
-        return t;
-    };
-    int nnz_l = 0;
-    for (int j = tid; j < nc; j += SP_NT) {
-        const int it = cand_idx[c0 + j];
-        const float lp = (cand_logit ? cand_logit[c0 + j] : row[it]) - l;
-        const bool pos = expf(lp) > 0.f;  // softmax underflow == "zero probability" of sample.py:45
-        float u = u_gumbel ? u_gumbel[c0 + j] : ltg_rng_uniform(seed, LTG_STREAM_GUMBEL, step, kb * (uint64_t)I + it);
-        u = fmaxf(u, 2.98023223876953125e-8f);  // 2^-25
-        s_key[j] = pos ? lp - logf(-logf(u)) : -INFINITY;
-        nnz_l += pos ? 1 : 0;
-    }
-    const int nnz = block_count(nnz_l);  // includes the barrier that publishes s_key
-    const int k_eff = min(ns, nnz);  // Q10: exception-driven decrement of to_sample
-    const int np = pop_ptr[b + 1] - pop_ptr[b];
-    // Selected = the k_eff largest keys, ties to the smaller index.  Fast pass: g(j) = #{t : key_t > key_j} (one compare per
-    // pair, 16-byte LDS broadcasts).  {j : g(j) < k_eff} is the selected set unless equal keys straddle the boundary -- then it
-    // is larger than k_eff, and the exact ranks (with the index tie-break) are counted instead.  A -inf key has g >= nnz >= k_eff.
-    const int nc4 = nc >> 2;
-    const ltg_f32x4* k4 = reinterpret_cast<const ltg_f32x4*>(s_key);
-    unsigned selmask = 0;   // bit p: candidate j = tid + p * SP_NT (<= 16 passes: max_cand <= 16384)
-    int nsel_l = 0;
-    for (int j = tid, p = 0; j < nc; j += SP_NT, ++p) {
-        const float kj = s_key[j];
-        int g = 0;
-        for (int t = 0; t < nc4; ++t) {
-            const ltg_f32x4 k = k4[t];
-            g += (k[0] > kj ? 1 : 0) + (k[1] > kj ? 1 : 0) + (k[2] > kj ? 1 : 0) + (k[3] > kj ? 1 : 0);
-        }
-        for (int t = nc4 * 4; t < nc; ++t) g += s_key[t] > kj ? 1 : 0;
-        if (g < k_eff) { selmask |= 1u << p; ++nsel_l; }
-    }
-    if (block_count(nsel_l) != k_eff) {   // equal keys at the boundary (uniform branch)
-        selmask = 0;
-        for (int j = tid, p = 0; j < nc; j += SP_NT, ++p) {
-            const float kj = s_key[j];
-            int rank = 0;
-            for (int t = 0; t < nc; ++t) {
-                const float kt = s_key[t];
-                rank += (kt > kj || (kt == kj && t < j)) ? 1 : 0;
-            }
-            if (rank < k_eff) selmask |= 1u << p;
-        }
-    }
-    int written = 0;
-    int ok_l = 0;
-    for (int j0 = 0, p = 0; j0 < nc; j0 += SP_NT, ++p) {
-        const int j = j0 + tid;
-        const bool sel = (selmask >> p) & 1u;
-        const unsigned long long bal = __ballot(sel);
-        __syncthreads();
-        if (lane == 0) s_w[w] = __popcll(bal);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int i = 0; i < SP_NT / 64; ++i) {
-            before += i < w ? s_w[i] : 0;
-            total += s_w[i];
-        }
-        if (sel) {
-            const int pos = written + before + __popcll(bal & ((1ull << lane) - 1ull));
-            const int s = s0 + pos;
-            const int gid = cand_idx[c0 + j];
-            const float u = u_pick ? u_pick[s] : ltg_rng_uniform(seed, LTG_STREAM_POP_PICK, step, kb * (uint64_t)I + gid);
-            const int pi = min((int)(u * (float)np), np - 1);  // np.random.choice(range(n)) train.py:236
-            const int pid = pop_idx[pop_ptr[b] + pi];
-            const bool ok = valid_item[gid] != 0 && valid_item[pid] != 0;  // train.py:240
-            gen_out[s] = ok ? gid : -1;
-            pop_out[s] = ok ? pid : -1;
-            ok_l += ok ? 1 : 0;
-        }
-        written += total;
-    }
-    for (int s = s0 + written + tid; s < s0 + ns; s += SP_NT) {
-        gen_out[s] = -1;
-        pop_out[s] = -1;
-    }
-    const int okcnt = block_count(ok_l);
-    if (tid == 0 && okcnt > 0) atomicAdd(cnt_out, okcnt);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Ranking metrics (eval_functions.py:11-62, train.py:341).  One workgroup per user.
-// rank(h) = #{i : score_i > score_h or (score_i == score_h and i < h)}, score = -inf on fold-in items.
-// ---------------------------------------------------------------------------------------------
-constexpr int RM_T = 16;  // held-out items processed per pass
-// Shared by the one-GPU path (score_in == nullptr, count_out == nullptr: everything in one launch) and the item-sharded
-// path (this rank's slab [item_lo, item_lo + I): scores of the held-out entries come all-reduced in score_in, the counts
-// of LOCAL items that beat each entry go to count_out for the all-reduce; te ids are GLOBAL, tr ids LOCAL).
-__device__ __forceinline__ void rank_finish_row(const int* cnt, int np, int k_ndcg, int k_r1, int k_r2, double* acc) {
-    for (int t = 0; t < np; ++t) {
-        const int r = cnt[t];
-        if (r < k_ndcg) acc[0] += 1.0 / log2((double)r + 2.0);
-        if (r < k_r1) acc[1] += 1.0;
-        if (r < k_r2) acc[2] += 1.0;
-    }
-}
-__device__ __forceinline__ void rank_write_row(float* out, const double* acc, int nte, int k_ndcg, int k_r1, int k_r2) {
-    double idcg = 0.0;
-    for (int r = 0; r < min(nte, k_ndcg); ++r) idcg += 1.0 / log2((double)r + 2.0);
-    out[0] = idcg != 0.0 ? (float)(acc[0] / idcg) : 0.f;
-    out[1] = nte > 0 ? (float)(acc[1] / (double)min(k_r1, nte)) : 0.f;
-    out[2] = nte > 0 ? (float)(acc[2] / (double)min(k_r2, nte)) : 0.f;
-    out[3] = idcg != 0.0 ? 1.f : 0.f;
-}
-
-__global__ __launch_bounds__(NT) void k_rank_metrics(int I, int item_lo, const float* __restrict__ logits, const int32_t* __restrict__ tr_ptr,
-                                                     const int32_t* __restrict__ tr_idx, const int32_t* __restrict__ te_ptr,
-                                                     const int32_t* __restrict__ te_idx, const float* __restrict__ score_in,
-                                                     int32_t* __restrict__ count_out, int k_ndcg, int k_r1, int k_r2,
-                                                     float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned s_bits[];  // ceil(I/32) words
-    __shared__ int s_cnt[RM_T];
-    __shared__ float s_sc[RM_T];
-    __shared__ int s_it[RM_T];
-    __shared__ double s_acc[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int nw = (I + 31) >> 5;
-    for (int w = tid; w < nw; w += NT) s_bits[w] = 0u;
-    if (tid < 4) s_acc[tid] = 0.0;
-    __syncthreads();
-    for (int e = tr_ptr[b] + tid; e < tr_ptr[b + 1]; e += NT) {
-        const int it = tr_idx[e];
-        atomicOr(&s_bits[it >> 5], 1u << (it & 31));
-    }
-    __syncthreads();
-    const float* row = logits + (size_t)b * I;
-    const int t0 = te_ptr[b], nte = te_ptr[b + 1] - t0;
-    for (int p0 = 0; p0 < nte; p0 += RM_T) {
-        const int np = min(RM_T, nte - p0);
-        if (tid < np) {
-            const int it = te_idx[t0 + p0 + tid];       // global id
-            s_it[tid] = it;
-            if (score_in) {
-                s_sc[tid] = score_in[t0 + p0 + tid];
-            } else {
-                const int l = it - item_lo;
-                s_sc[tid] = ((s_bits[l >> 5] >> (l & 31)) & 1u) ? -INFINITY : row[l];
-            }
-            s_cnt[tid] = 0;
-        }
-        __syncthreads();
-        int cnt[RM_T];
-#pragma unroll
-        for (int t = 0; t < RM_T; ++t) cnt[t] = 0;
-        for (int i = tid; i < I; i += NT) {
-            const float sc = ((s_bits[i >> 5] >> (i & 31)) & 1u) ? -INFINITY : row[i];
-            const int ig = i + item_lo;
-#pragma unroll
-            for (int t = 0; t < RM_T; ++t)
-                if (t < np) cnt[t] += (sc > s_sc[t] || (sc == s_sc[t] && ig < s_it[t])) ? 1 : 0;
-        }
-#pragma unroll
-        for (int t = 0; t < RM_T; ++t) {
-            if (t < np) {
-                int c = cnt[t];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-                if ((tid & 63) == 0) atomicAdd(&s_cnt[t], c);
-            }
-        }
-        __syncthreads();
-        if (count_out) {
-            if (tid < np) count_out[t0 + p0 + tid] = s_cnt[tid];
-        } else if (tid == 0) {
-            rank_finish_row(s_cnt, np, k_ndcg, k_r1, k_r2, s_acc);
-        }
-        __syncthreads();
-    }
-    if (tid == 0 && !count_out) rank_write_row(out + (size_t)b * 4, s_acc, nte, k_ndcg, k_r1, k_r2);
-}
-
-// scores of the held-out entries this rank owns (-inf on fold-in items), 0 for the others -> all-reduce(sum)
-__global__ __launch_bounds__(NT) void k_rank_scores(int I, int item_lo, int n_rows, const float* __restrict__ logits,
-                                                    const int32_t* __restrict__ tr_ptr, const int32_t* __restrict__ tr_idx,
-                                                    const int32_t* __restrict__ te_ptr, const int32_t* __restrict__ te_idx,
-                                                    float* __restrict__ score_out) {
-    const int b = blockIdx.x;
-    const int a0 = tr_ptr[b], a1 = tr_ptr[b + 1];
-    for (int e = te_ptr[b] + threadIdx.x; e < te_ptr[b + 1]; e += NT) {
-        const int l = te_idx[e] - item_lo;
-        float sc = 0.f;
-        if (l >= 0 && l < I) {
-            int lo = a0, hi = a1;                       // tr rows are sorted (CSR with sorted indices)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (tr_idx[mid] < l) lo = mid + 1; else hi = mid;
-            }
-            sc = (lo < a1 && tr_idx[lo] == l) ? -INFINITY : logits[(size_t)b * I + l];
-        }
-        score_out[e] = sc;
-    }
-}
-
-__global__ void k_rank_finish(int n_rows, const int32_t* __restrict__ te_ptr, const int32_t* __restrict__ counts, int k_ndcg, int k_r1,
-                              int k_r2, float* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_rows) return;
-    double acc[3] = {0.0, 0.0, 0.0};
-    const int t0 = te_ptr[b], nte = te_ptr[b + 1] - t0;
-    rank_finish_row(counts + t0, nte, k_ndcg, k_r1, k_r2, acc);
-    rank_write_row(out + (size_t)b * 4, acc, nte, k_ndcg, k_r1, k_r2);
-}
+#include "ltg_gen_fwd.h"
+#include "ltg_stream.h"
+#include "ltg_disc.h"
+#include "ltg_gstep.h"
+#include "ltg_clock.h"
+#include "ltg_sampler.h"
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -3313,7 +594,7 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
     const Probe pr{probe, st};
     const int n = pv.nr + pv.nf, h0 = cfg->d_h0, h1 = cfg->d_h1, h2 = cfg->d_h2, h3 = cfg->d_h3, h12 = h1 + h2;
     const int nmax = h1 > h2 ? h1 : h2;
-    if (!with_bwd && ft_wsp_capable(cfg) && (cfg->d_arith & 3) != LTG_DARITH_FP32 && (cfg->tuning & ((1 << 23) | (1 << 20))) == 0) {
+    if (!with_bwd && ft_wsp_capable(cfg) && (cfg->d_arith & 3) != LTG_DARITH_FP32 && (cfg->tuning & (1 << 20)) == 0) {
         // forward only, split arithmetic: ONE kernel from the id lists to y, A1 stays in LDS (ltg_tower.h).  (Tuning-knob bit 20: the three
         // launches below instead.)  The weights are split first: 1 MB at config.ini's sizes, ~3 us, once per call.
         ltg_ft_u32x4* wsp = reinterpret_cast<ltg_ft_u32x4*>(w.wsp);
@@ -3332,10 +613,10 @@ void disc_forward(const ltg_config* cfg, const ltg_disc_state* d, PairView pv, D
         pr.after(LTG_K_D_L1);
         return;
     }
-    if (d_fast(cfg) && !with_bwd && h0 >= 32 && h12 >= 32 && (h0 % 4) == 0 && (h12 % 4) == 0 && (cfg->tuning & (1 << 23)) == 0) {
+    if (d_fast(cfg) && !with_bwd && h0 >= 32 && h12 >= 32 && (h0 % 4) == 0 && (h12 % 4) == 0) {
         // forward only (the fake tower of the G steps, one batch or -- ltg_fake_tower_batched -- 10^5 pair rows): LDS-staged 64 x 64
         // tiles.  The choice depends on the layer sizes only, so the tower inside a step and the batched tower run the same
-        // kernels and produce the same bits.  (Tuning-knob bit 23: the register-resident 32 x 32 tiles.)
+        // kernels and produce the same bits.  (d_arith = fp32, tuning bit 20, or sizes the one-kernel tower does not take.)
         LTG_PROBED(pr, LTG_K_D_L1, hipLaunchKernelGGL(fks_d_l1, dim3((h1 + 63) / 64 + (h2 + 63) / 64, (n + 63) / 64), dim3(NT), 0, st, pv, h0, h1, h2, d->emb, d->p[0],
                                                       d->p[1], d->p[2], d->p[3], dA, dB, keep, cfg->seed, step, w.A1));
         LTG_PROBED(pr, LTG_K_D_L2, hipLaunchKernelGGL(fks_d_l2, dim3((h3 + 63) / 64, (n + 63) / 64), dim3(NT), 0, st, n, h12, h3, w.A1, d->p[4], d->p[5], d->p[6], dC, keep,

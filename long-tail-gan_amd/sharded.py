@@ -197,9 +197,10 @@ class ShardedTrainer(Trainer):
                 eng.d_apply(self.d_grad, loss_out=self.d_losses[j])
         return self.d_losses
 
-    def _g_one(self, j, b, v, a):
-        """one generator update of batch b over the item shards"""
+    def _g_one(self, j, b, v, a, loss_out=None):
+        """one generator update of batch b over the item shards (loss_out: Trainer.step_log's per-step row)"""
         d, eng = self.data, self.eng
+        loss_out = self.g_losses[j] if loss_out is None else loss_out
         B = v["batch"].n_rows
         pr = self.probe_hook("g", b) if self.probe_hook else None
         rs, ds = self._step(), self._step()
@@ -209,7 +210,7 @@ class ShardedTrainer(Trainer):
                         y_pre=self.y_all if self.batched_tower else None, y_off=j * d.n_slots + v["slot0"])
         if self.pipe is not None:
             # ONE call: every launch of the step and its three exchanges in-stream (ltg_g_step_sharded)
-            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=self.g_losses[j],
+            eng.g_step_sharded(v["batch"], v["fake"], self.acts, go, self.pipe, self.comm, loss_out=loss_out,
                                next_batch=getattr(self, "_next_batch", None))
             return
         # the step cut at its exchange points, collectives through torch.distributed (configurations ltg_g_step_sharded does not
@@ -225,7 +226,7 @@ class ShardedTrainer(Trainer):
         rp_all = self._forward(v, v["fake"], go.fwd)
         if go.fake_done:
             torch.cuda.current_stream().wait_event(self._ev_join)
-        eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, self.g_losses[j], self.dh2)
+        eng.g_bwd_dec(v["batch"], v["fake"], self.acts, go, rp_all, self.R, loss_out, self.dh2)
         if self.dec1_overlap:
             # the decoder weight update (HBM-bound, the largest kernel; needs only dlog and h2) on the side stream with 224
             # of its 256 workgroups; exchange 3 and then the rest of the backward chain (which needs only the all-reduced
