@@ -468,6 +468,27 @@ typedef struct ltg_comm {
     int (*all_gather)(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, ltg_stream stream);
 } ltg_comm;
 
+/* One-shot exchange over peer-mapped staging buffers: a second transport with ltg_comm's entry-point signatures (csrc/ltg_oneshot.h;
+ * correctness only -- RCCL is the transport of every measurement).  The caller allocates ltg_oneshot_stage_bytes() bytes of ZEROED device
+ * memory per rank, shares them between the ranks (hipIpcGetMemHandle / hipIpcOpenMemHandle: stage[q] = rank q's buffer as mapped into this
+ * process, stage[rank] = its own), and puts &ltg_oneshot into ltg_comm.comm with ltg_oneshot_all_reduce / ltg_oneshot_all_gather as the
+ * entry points.  HOST structure: the library advances `seq` with every exchange (all ranks issue the same sequence of exchanges); counts up
+ * to max_floats (all-gather: per rank); float32 / sum only.  Replaces nothing in the reference (Codes/train.py has no distributed code). */
+#define LTG_ONESHOT_MAX_RANKS 16
+typedef struct ltg_oneshot {
+    int32_t n_ranks;
+    int32_t rank;
+    uint32_t seq;      /* exchanges issued so far; 0 at start */
+    uint32_t limit_ms; /* bound of a device-side wait for a peer's message (0 = 30 s); a wait that gives up counts in `expired` of the stage */
+    size_t max_floats;
+    void* stage[LTG_ONESHOT_MAX_RANKS];
+} ltg_oneshot;
+size_t ltg_oneshot_stage_bytes(int32_t n_ranks, size_t max_floats);
+/* byte offset of the `expired` counter (uint32) inside a rank's stage: the host reads it after a synchronisation */
+size_t ltg_oneshot_expired_offset(int32_t n_ranks);
+int ltg_oneshot_all_reduce(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, ltg_stream stream);
+int ltg_oneshot_all_gather(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, ltg_stream stream);
+
 typedef struct ltg_pipe {
     ltg_stream side_stream;
     void* ev_fork; /* hipEvent_t x 2, timing disabled (LTG_PIPE_EVENTS and ltg_g_pipe_join) */

@@ -105,8 +105,20 @@ class ltg_pipe(C.Structure):
                 ("q0_mark", vp), ("next_uitem", vp), ("next_nu", C.c_int32), ("caught_up", C.c_int32), ("shadow_out", vp)]
 
 
+LTG_ONESHOT_MAX_RANKS = 16
+
+
+class ltg_oneshot(C.Structure):
+    _fields_ = [("n_ranks", C.c_int32), ("rank", C.c_int32), ("seq", C.c_uint32), ("limit_ms", C.c_uint32), ("max_floats", C.c_size_t),
+                ("stage", vp * LTG_ONESHOT_MAX_RANKS)]
+
+
 # every symbol include/ltg.h declares: name -> (restype, argtypes)
 SYMBOLS = {
+    "ltg_oneshot_stage_bytes": (C.c_size_t, [C.c_int32, C.c_size_t]),
+    "ltg_oneshot_expired_offset": (C.c_size_t, [C.c_int32]),
+    "ltg_oneshot_all_reduce": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp]),
+    "ltg_oneshot_all_gather": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp, vp]),
     "ltg_g_step_sharded_ok": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.c_int32]),
     "ltg_g_step_sharded_plan": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_batch), C.POINTER(ltg_pipe)]),
     "ltg_g_step_sharded": (C.c_int, [C.POINTER(ltg_config), C.POINTER(ltg_gen_state), C.POINTER(ltg_disc_state), C.POINTER(ltg_batch),

@@ -24,7 +24,66 @@ def _lib():
         _hip.hipEventDestroy.argtypes = [C.c_void_p]
         _hip.hipEventSynchronize.argtypes = [C.c_void_p]
         _hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip.hipFree.argtypes = [C.c_void_p]
+        _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipDeviceSynchronize.argtypes = []
+        _hip.hipIpcGetMemHandle.argtypes = [C.c_void_p, C.c_void_p]            # (hipIpcMemHandle_t*, void*): 64 opaque bytes
+        _hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), IpcHandle, C.c_uint]
+        _hip.hipIpcCloseMemHandle.argtypes = [C.c_void_p]
     return _hip
+
+
+class IpcHandle(C.Structure):
+    """hipIpcMemHandle_t (passed BY VALUE to hipIpcOpenMemHandle)"""
+    _fields_ = [("reserved", C.c_char * 64)]
+
+
+class IpcBuffer:
+    """Zeroed device memory of this process that other processes of the node can map (hipMalloc + hipIpcGetMemHandle); `open_peer` maps a
+    peer's.  The one-shot exchange's staging buffers (ltgan._rccl.OneShotComm).  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool."""
+
+    def __init__(self, nbytes):
+        h = _lib()
+        self.ptr = C.c_void_p()
+        if h.hipMalloc(C.byref(self.ptr), nbytes) != 0:
+            raise RuntimeError("hipMalloc(%d) failed" % nbytes)
+        self.nbytes = int(nbytes)
+        assert h.hipMemset(self.ptr, 0, nbytes) == 0 and h.hipDeviceSynchronize() == 0
+        hd = IpcHandle()
+        if h.hipIpcGetMemHandle(C.byref(hd), self.ptr) != 0:
+            h.hipGetLastError()
+            h.hipFree(self.ptr)
+            raise RuntimeError("hipIpcGetMemHandle failed")
+        self.handle = bytes(hd.reserved if isinstance(hd.reserved, bytes) and len(hd.reserved) == 64 else C.string_at(C.addressof(hd), 64))
+        self._peers = []
+
+    def open_peer(self, handle_bytes):
+        h = _lib()
+        hd = IpcHandle()
+        C.memmove(C.addressof(hd), handle_bytes, 64)
+        p = C.c_void_p()
+        if h.hipIpcOpenMemHandle(C.byref(p), hd, 1) != 0:      # hipIpcMemLazyEnablePeerAccess
+            h.hipGetLastError()
+            raise RuntimeError("hipIpcOpenMemHandle failed")
+        self._peers.append(p)
+        return p.value
+
+    def read_u32(self, offset):
+        h = _lib()
+        out = C.c_uint32()
+        assert h.hipMemcpy(C.byref(out), C.c_void_p(self.ptr.value + offset), 4, 2) == 0     # hipMemcpyDeviceToHost
+        return int(out.value)
+
+    def close(self):
+        h = _lib()
+        for p in self._peers:
+            h.hipIpcCloseMemHandle(p)
+        self._peers = []
+        if self.ptr:
+            h.hipFree(self.ptr)
+            self.ptr = C.c_void_p()
 
 
 class EventPair:

@@ -140,14 +140,16 @@ class HostComm:
     """ltg_comm whose entry points are host functions over the torch.distributed group (any backend).  `buffers`: the device
     tensors the library will hand in (looked up by address; the functions receive raw pointers)."""
 
-    def __init__(self, group, buffers):
-        self.group = group
+    def __init__(self, group, buffers, ordered=False):
+        """ordered: the all-reduce adds the ranks' contributions IN RANK ORDER (all-gather + a left-to-right sum) instead of in the backend's own
+        order -- the reference the one-shot transport (OneShotComm, same fixed order) is compared with bit for bit"""
+        self.group, self.ordered = group, bool(ordered)
         self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.bufs = [(t.data_ptr(), t.numel() * t.element_size(), t.view(-1)) for t in buffers]
         self._ar = cabi.ALL_REDUCE_FN(self._all_reduce)              # (kept alive with the object)
         self._ag = cabi.ALL_GATHER_FN(self._all_gather)
         self.c = cabi.ltg_comm(None, self.n_ranks, self.rank, C.cast(self._ar, C.c_void_p), C.cast(self._ag, C.c_void_p))
-        self.kind = "host (%s)" % dist.get_backend(group)
+        self.kind = "host%s (%s)" % ("-ordered" if self.ordered else "", dist.get_backend(group))
         self.count = self.n_ranks
 
     def _view(self, ptr, count):
@@ -162,7 +164,19 @@ class HostComm:
         try:
             if dtype != cabi.LTG_NCCL_FLOAT32 or op != cabi.LTG_NCCL_SUM or send != recv:
                 return 1
-            dist.all_reduce(self._view(recv, count), op=dist.ReduceOp.SUM, group=self.group)
+            t = self._view(recv, count)
+            if self.ordered:
+                # every rank's vector, one all-reduce of the zero-padded [R, count] buffer (x + 0 exactly), then acc = ((0 + x_0) + x_1) + ...
+                import torch
+                allv = torch.zeros(self.n_ranks, count, dtype=t.dtype, device=t.device)
+                allv[self.rank] = t
+                dist.all_reduce(allv, op=dist.ReduceOp.SUM, group=self.group)
+                acc = torch.zeros_like(t)
+                for q in range(self.n_ranks):
+                    acc += allv[q]
+                t.copy_(acc)
+                return 0
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return 0
         except Exception:                                             # an exception must not unwind through the C frame
             import traceback
@@ -193,3 +207,66 @@ class HostComm:
 
     def abort(self):
         pass
+
+
+class OneShotComm:
+    """ltg_comm over the library's own one-shot exchange (csrc/ltg_oneshot.h; include/ltg.h: ltg_oneshot): every rank's staging buffer
+    mapped into every other rank's address space through HIP IPC, one kernel per exchange, contributions added in rank order.  A second
+    transport for A/B on boxes with more than one GPU and for test rigs; correctness only -- RCCL (RcclComm) is the default."""
+
+    def __init__(self, group, device, max_floats, limit_ms=0):
+        import torch
+        from ._hip import IpcBuffer
+        self.group = group
+        self.n_ranks, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if not 1 <= self.n_ranks <= cabi.LTG_ONESHOT_MAX_RANKS:
+            raise ValueError("one-shot exchange: 1..%d ranks" % cabi.LTG_ONESHOT_MAX_RANKS)
+        lib = cabi.load()
+        self.lib = lib
+        torch.cuda.set_device(device)
+        self.max_floats = int(max_floats)
+        self.buf, err = None, None
+        try:
+            self.buf = IpcBuffer(lib.ltg_oneshot_stage_bytes(self.n_ranks, self.max_floats))
+        except Exception as e:      # (every rank must get past the handle exchange: agree on failure below)
+            err = repr(e)
+        handles = [None] * self.n_ranks
+        dist.all_gather_object(handles, None if self.buf is None else self.buf.handle, group=group)
+        if any(h is None for h in handles):
+            if self.buf is not None:
+                self.buf.close()
+            raise RuntimeError("one-shot exchange: a rank could not create its staging buffer (%s)" % err)
+        self.os = cabi.ltg_oneshot(self.n_ranks, self.rank, 0, int(limit_ms), self.max_floats)
+        ok = True
+        try:
+            for q in range(self.n_ranks):
+                self.os.stage[q] = self.buf.ptr.value if q == self.rank else self.buf.open_peer(handles[q])
+        except Exception as e:
+            ok, err = False, repr(e)
+        flags = [None] * self.n_ranks
+        dist.all_gather_object(flags, ok, group=group)      # (also the barrier behind which every stage is zeroed and mapped)
+        if not all(flags):
+            self.buf.close()
+            raise RuntimeError("one-shot exchange: a rank could not map a peer's staging buffer (%s)" % err)
+        self.c = cabi.ltg_comm(C.addressof(self.os), self.n_ranks, self.rank, C.cast(lib.ltg_oneshot_all_reduce, C.c_void_p),
+                               C.cast(lib.ltg_oneshot_all_gather, C.c_void_p))
+        self.kind = "oneshot-ipc"
+        self.count = self.n_ranks
+        self._expired_off = int(lib.ltg_oneshot_expired_offset(self.n_ranks))
+
+    def expired_waits(self):
+        """device-side waits for a peer's message that gave up (0 in a healthy run); synchronises the device"""
+        import torch
+        torch.cuda.synchronize()
+        return self.buf.read_u32(self._expired_off)
+
+    def close(self):
+        import torch
+        if self.buf is not None:
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)       # no peer may still be writing into this rank's stage
+            self.buf.close()
+            self.buf = None
+
+    def abort(self):
+        self.buf = None                          # (leak on the error path: a peer may still hold the mapping)

@@ -347,6 +347,7 @@ namespace {
 #include "ltg_fast.h"
 #include "ltg_fp8bwd.h"
 #include "ltg_tower.h"
+#include "ltg_oneshot.h"
 }
 namespace {
 
@@ -1374,6 +1375,42 @@ int ltg_g_fake_tower(const ltg_config* cfg, const ltg_disc_state* disc, const lt
     DropView dA{nullptr, o->drop_fake[0], 0, 0}, dB{nullptr, o->drop_fake[1], 0, 0}, dC{nullptr, o->drop_fake[2], 0, 0};
     disc_forward(cfg, disc, pv, dA, dB, dC, o->d_keep_prob, o->d_rng_step, w, false, nullptr, (hipStream_t)stream);
     return check_launch();
+}
+
+/* ---- one-shot exchange over peer-mapped staging buffers (csrc/ltg_oneshot.h) ---- */
+size_t ltg_oneshot_stage_bytes(int32_t n_ranks, size_t max_floats) {
+    if (n_ranks < 1 || n_ranks > LTG_ONESHOT_MAX_RANKS) return 0;
+    return os_data_off(n_ranks) + (size_t)2 * n_ranks * max_floats * sizeof(float);
+}
+size_t ltg_oneshot_expired_offset(int32_t n_ranks) { return ((size_t)2 * n_ranks + 2) * sizeof(uint32_t); }
+static int oneshot_exchange(bool gather, const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, ltg_stream stream) {
+    ltg_oneshot* os = static_cast<ltg_oneshot*>(comm);
+    if (!os || !sendbuf || !recvbuf || dtype != LTG_NCCL_FLOAT32 || (!gather && op != LTG_NCCL_SUM) || os->n_ranks < 1 || os->n_ranks > LTG_ONESHOT_MAX_RANKS ||
+        os->rank < 0 || os->rank >= os->n_ranks || count > os->max_floats)
+        return LTG_EINVAL;
+    if (count == 0) return LTG_OK;
+    OsView v;
+    for (int q = 0; q < LTG_ONESHOT_MAX_RANKS; ++q) v.stage[q] = q < os->n_ranks ? static_cast<char*>(os->stage[q]) : nullptr;
+    for (int q = 0; q < os->n_ranks; ++q)
+        if (!v.stage[q]) return LTG_EINVAL;
+    os->seq += 1u;
+    v.R = os->n_ranks;
+    v.rank = os->rank;
+    v.seq = os->seq;
+    v.limit_ms = os->limit_ms;
+    v.max_floats = os->max_floats;
+    const int nb = (int)((count + OS_NT - 1) / OS_NT);
+    const dim3 g(nb < OS_MAX_BLOCKS ? nb : OS_MAX_BLOCKS);
+    // (in place: the all-gather's own block is written from `send` -- which may BE that block -- element by element by the thread that read it)
+    if (gather) hipLaunchKernelGGL(k_oneshot_exchange<true>, g, dim3(OS_NT), 0, (hipStream_t)stream, v, (const float*)sendbuf, (float*)recvbuf, count);
+    else hipLaunchKernelGGL(k_oneshot_exchange<false>, g, dim3(OS_NT), 0, (hipStream_t)stream, v, (const float*)sendbuf, (float*)recvbuf, count);
+    return hipGetLastError() == hipSuccess ? LTG_OK : LTG_ELAUNCH;
+}
+int ltg_oneshot_all_reduce(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, ltg_stream stream) {
+    return oneshot_exchange(false, sendbuf, recvbuf, count, dtype, op, comm, stream);
+}
+int ltg_oneshot_all_gather(const void* sendbuf, void* recvbuf, size_t sendcount, int dtype, void* comm, ltg_stream stream) {
+    return oneshot_exchange(true, sendbuf, recvbuf, sendcount, dtype, LTG_NCCL_SUM, comm, stream);
 }
 
 int ltg_fake_tower_batched(const ltg_config* cfg, const ltg_disc_state* disc, const ltg_pairs* fake, const int32_t* seg_of,

@@ -258,6 +258,7 @@ class Engine:
         self.cfg = cabi.ltg_config(self.I, self.H, self.Z, self.feature_len, self.h0, self.h1, self.h2, self.h3,
                                    self.precision, 0, self.item_lo, n_items if self.sharded else 0, self.d_precision, d_arith_code,
                                    lr, beta1, beta2, eps, seed)
+        self.cfg.tuning = int(os.environ.get("LTGAN_TUNING", "0"), 0)     # measurement switch: ltg_config.tuning (include/ltg.h)
         self.lr, self.beta1, self.beta2 = lr, beta1, beta2
         self.adam_t = 0                                              # shared by D and G (Q5)
         if lazy_q0 is None:

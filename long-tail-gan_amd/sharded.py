@@ -47,8 +47,12 @@ def item_slab(n_items, rank, world):
 
 
 class ShardedTrainer(Trainer):
-    def __init__(self, engine, data, group=None, d_split=None, **kw):
+    def __init__(self, engine, data, group=None, d_split=None, transport=None, **kw):
+        """transport of the one-call step's three exchanges: None = environment LTGAN_COMM, default "rccl" (RCCL bound directly on the nccl backend,
+        host callbacks over the group otherwise); "host-ordered" = host callbacks adding in rank order; "oneshot" = the library's one-shot exchange
+        over HIP-IPC-mapped staging buffers (_rccl.OneShotComm; correctness only)"""
         super().__init__(engine, data, **kw)
+        self.transport = transport
         self.group = group
         self.R = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -75,7 +79,7 @@ class ShardedTrainer(Trainer):
         """ltg_g_step_sharded (one call per G step, exchanges in-stream) when the library serves this configuration.  Transport:
         RCCL bound directly (backend "nccl": the library calls ncclAllReduce / ncclAllGather itself on the step's stream), or host
         callbacks over the group for test rigs whose ranks share a GPU (gloo).  LTGAN_SHARDED_STEP=0: the cut-point sequence."""
-        from ._rccl import HostComm, RcclComm
+        from ._rccl import HostComm, OneShotComm, RcclComm
         self.pipe, self.comm = None, None
         mine = os.environ.get("LTGAN_SHARDED_STEP", "1") != "0" and engine.sharded_step_ok(B)
         # every rank must take the same path (a rank whose slab the one-call step does not serve -- e.g. a last slab that is not a
@@ -85,7 +89,16 @@ class ShardedTrainer(Trainer):
         if int(agree.item()) == 0:
             return
         self.pipe = Pipe(engine, B, self.R, flags=int(os.environ.get("LTGAN_PIPE_FLAGS", "0")))
-        if dist.get_backend(self.group) == "nccl" and os.environ.get("LTGAN_COMM", "rccl") == "rccl":
+        transport = self.transport or os.environ.get("LTGAN_COMM", "rccl")
+        if transport == "oneshot":
+            # the library's own one-shot exchange over HIP-IPC-mapped staging buffers (a second transport, correctness only: _rccl.OneShotComm)
+            self.comm = OneShotComm(self.group, engine.device, max(self.pipe.h1pre.numel(), self.pipe.rowpart_all.numel() // self.R),
+                                    limit_ms=int(os.environ.get("LTGAN_ONESHOT_LIMIT_MS", "0")))
+            return
+        if transport == "host-ordered":
+            self.comm = HostComm(self.group, self.pipe.buffers(), ordered=True)
+            return
+        if dist.get_backend(self.group) == "nccl" and transport == "rccl":
             comm, err = None, ""
             try:
                 comm = RcclComm(self.group, engine.device, warm_counts=(self.pipe.h1pre.numel(), self.pipe.rowpart_all.numel() // self.R))

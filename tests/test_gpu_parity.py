@@ -78,7 +78,10 @@ def test_forward_parity(precision, tol, I, B):
     # against the pure-fp32-operand oracle the bf16 path stays within 1e-2 on probabilities
     if precision == "bf16":
         F32 = O.vae_forward(P, X.toarray(), mask, keep, eps, 1.0, 1.0, np.float64, quant=False)
-        assert np.max(np.abs(p - F32["probs"]) / F32["probs"]) < 2e-2
+        gap = np.max(np.abs(p - F32["probs"]) / F32["probs"])
+        print("I=%d B=%d bf16 operands against the PURE fp32 oracle: max rel gap probs %.2e, logits %.2e (DESIGN.md section 6 quotes these)" %
+              (I, B, gap, Hh.rel_err(got["logits"], F32["logits"])))
+        assert gap < 2e-2
 
 
 @pytest.mark.parametrize("I,rows", [(20000, (100, 100, 50)), (1000, (100, 100, 100, 1))])

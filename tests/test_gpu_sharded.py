@@ -49,6 +49,20 @@ def test_eight_rank_item_sharding_matches_unsharded(workload, users, precision, 
     assert out.returncode == 0 and "SHARDED_OK world=8" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
 
 
+@pytest.mark.parametrize("world,workload,users", [(2, "c4", 200), (8, "c4", 200)])
+def test_one_shot_exchange_equals_the_rank_ordered_host_transport(world, workload, users):
+    """The second transport behind ltg_comm (csrc/ltg_oneshot.h, ltgan._rccl.OneShotComm; SURVEY 8/e1's one-shot exchange for the <= 240-KB
+    messages): every rank's staging buffer mapped into every peer through HIP IPC, one kernel per exchange, contributions added in rank order.
+    Against host callbacks that add in the same order the two-epoch run must leave the same bits on every rank -- fake pairs, losses, every
+    generator tensor and Adam moment -- at world sizes 2 and 8 (c4: 100 000-item slabs / seven slabs of 25 024 items and one of 24 832).
+    Correctness only: RCCL stays the transport of every measurement."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", LTGAN_ONESHOT_LIMIT_MS="20000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29583", os.path.join(ROOT, "tests", "dist_oneshot_worker.py"), workload, str(users)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)      # fresh children only
+    assert out.returncode == 0 and ("ONESHOT_OK world=%d" % world) in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
+
+
 def test_direct_rccl_transport_of_the_one_call_step_at_world_size_one():
     """The transport a GPU node uses: RCCL bound directly, its entry points called by the library in-stream (tests/dist_rccl_worker.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
