@@ -207,7 +207,8 @@ class KernelProfiler:
             "enc0_grad": (2 * sh["nnz"] * H, 4 * (sh["nnz"] * H + min(I, sh["nnz"]) * H)),
             # one launch = every Adam update of the generator: 24 B per parameter + the operands of the three gradient products
             "g_tail": (2 * B * ((2 * I if I <= 4096 else 0) * (H + 1) + (Z + 1) * H + (H + 1) * 2 * Z),
-                       24 * (((2 * H + 1) * I if I <= 4096 else (H + 1) * I) + H * 2 * Z + Z * H + 2 * H + 2 * Z) + 4 * B * (2 * I + 3 * H + 3 * Z)),
+                       # (item slabs above 4 096: the item-sized tensors are updated by dec1_bwd_adam / enc0_bwd_adam / enc0_grad, not by the tail)
+                       24 * (((2 * H + 1) * I if I <= 4096 else 0) + H * 2 * Z + Z * H + 2 * H + 2 * Z) + 4 * B * ((2 * I if I <= 4096 else 0) + 3 * H + 3 * Z)),
         }
         return w[name]
 
@@ -366,7 +367,7 @@ class KernelProfiler:
             ach, peak, unit, bound = fl / (avg * 1e-3) / 1e12, peak_f / 1e12, "TFLOP/s", "mfma"
         traffic = None
         one_rank = not self.eng.sharded or (self.eng.item_lo == 0 and self.eng.item_hi == self.eng.I_global)     # (world size 1 on the sharded code path: the slab is the table)
-        for fn in (() if not one_rank else ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3c_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):   # (the passes measured the UNSHARDED kernel sizes)   # PMC-derived HBM bytes per launch of this kernel on this workload,
+        for fn in (() if not one_rank else ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3c_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):   # (the passes measured the UNSHARDED kernel sizes)   # PMC-derived HBM bytes per launch of this kernel on this workload,
             try:                                                       # measured offline (profiles/README.md); newest round first
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     traffic = json.load(f)["workloads"][self.a.workload][name]["traffic_bytes"]
