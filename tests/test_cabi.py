@@ -53,7 +53,7 @@ def test_struct_layouts_match_the_header_as_gcc_lays_it_out(tmp_path):
     from ltgan import _cabi as cabi
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     names = ["ltg_config", "ltg_gen_state", "ltg_disc_state", "ltg_batch", "ltg_gen_acts", "ltg_probe", "ltg_fwd_opts", "ltg_pairs", "ltg_d_opts",
-             "ltg_g_opts", "ltg_sample_inputs", "ltg_comm", "ltg_pipe"]
+             "ltg_g_opts", "ltg_sample_inputs", "ltg_comm", "ltg_pipe", "ltg_oneshot"]
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "ltg.h"', "int main(void) {"]
     for n in names:
         st = getattr(cabi, n)
@@ -101,6 +101,25 @@ def test_argument_validation_returns_codes_without_gpu():
     assert lib.ltg_g_step_sharded(C.byref(good), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.ltg_g_step_sharded_ok(C.byref(good), None, 100) == 0 and lib.ltg_g_pipe_join(None, None) == -1
     assert lib.ltg_g_step_sharded_plan(C.byref(good), None, None, None) == 0
+    # ltg_config.d_arith (ABI v14): 0 / 1 / 2 + the measurement set in bits 4-7; anything else is rejected
+    for code, ok in ((0, True), (1, True), (2, True), (1 | (0xE << 4), True), (3, False), (1 | (1 << 8), False), (-1, False)):
+        c = cabi.ltg_config(1000, 600, 200, 1000, 100, 150, 250, 300, 0, 0, 0, 0, 1, code, 1e-4, 0.9, 0.999, 1e-8, 1)
+        assert (lib.ltg_workspace_bytes(C.byref(c), 100, 2000) > 0) == ok, code
+    # the forward-only tower's split weights live in the workspace only where that kernel serves the sizes (h0 <= 128, h3 <= 320, fp32 discriminator)
+    wide = cabi.ltg_config(1000, 600, 200, 1000, 2048, 1024, 512, 256, 0, 0, 0, 0, 1, 1, 1e-4, 0.9, 0.999, 1e-8, 1)
+    assert lib.ltg_workspace_bytes(C.byref(good), 1, 64) - lib.ltg_workspace_bytes(C.byref(cabi.ltg_config(1000, 600, 200, 1000, 100, 150, 250, 324, 0, 0, 0, 0, 1, 0, 1e-4, 0.9, 0.999, 1e-8, 1)), 1, 64) > 900000
+    assert lib.ltg_workspace_bytes(C.byref(wide), 1, 64) > 0
+    # the one-shot exchange (ABI v14): sizing and argument checks happen on the host
+    assert lib.ltg_oneshot_stage_bytes(0, 100) == 0 and lib.ltg_oneshot_stage_bytes(17, 100) == 0
+    assert lib.ltg_oneshot_stage_bytes(8, 60000) == 256 + 2 * 8 * 60000 * 4 and lib.ltg_oneshot_expired_offset(8) == (2 * 8 + 2) * 4
+    os_ = cabi.ltg_oneshot(2, 0, 0, 0, 100)
+    buf = (C.c_float * 4)()
+    assert lib.ltg_oneshot_all_reduce(None, None, 4, cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, C.byref(os_), None) == -1
+    assert lib.ltg_oneshot_all_reduce(buf, buf, 4, cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, None, None) == -1
+    assert lib.ltg_oneshot_all_reduce(buf, buf, 4, 0, cabi.LTG_NCCL_SUM, C.byref(os_), None) == -1               # not float32
+    assert lib.ltg_oneshot_all_reduce(buf, buf, 101, cabi.LTG_NCCL_FLOAT32, cabi.LTG_NCCL_SUM, C.byref(os_), None) == -1    # beyond max_floats
+    assert lib.ltg_oneshot_all_gather(buf, buf, 4, cabi.LTG_NCCL_FLOAT32, C.byref(os_), None) == -1              # stages not mapped
+    assert os_.seq == 0                                                                                            # nothing was issued
 
 
 def test_one_call_step_plan_is_a_pure_function_of_its_arguments():
@@ -293,3 +312,20 @@ def test_factory_registry_and_config_ini_defaults(tmp_path, monkeypatch):
     assert G._config_ini_defaults() == {}
     (tmp_path / "config.ini").write_text("[Long-Tail-GAN]\nh0_size = 64\nh1_size = 96\nh2_size = 160\nh3_size = 128\nLEARNING_RATE = 0.0003\n")
     assert G._config_ini_defaults() == {"h_sizes": (64, 96, 160, 128), "lr": 0.0003}
+
+
+def test_bench_reads_the_newest_tracked_rocprof_summary_and_leaves_the_gate_kernels_out():
+    """roofline.frac follows from profiles/: bench.py finds the newest r<N>_<workload>_kernel_stats.csv of a workload, adds up template
+    instantiations under the kernel's base name, and neither the dominant-kernel ranking nor its percentages count the parked one-wave gates."""
+    bench = _bench_module()
+    rows, fn = bench.rocprof_summary("askubuntu")
+    assert fn is not None and int(fn[1:fn.index("_")].rstrip("abc")) >= 6 and fn.endswith("_askubuntu_kernel_stats.csv"), fn
+    assert "fk_d_bwd1" in rows and rows["fk_d_bwd1"][0] == 4040 and "k_gate_wait" in rows           # (both launches of the forked kernel in one row)
+    work = {k: v for k, v in rows.items() if k not in bench.ROCPROF_NOT_WORK}
+    assert max(work, key=lambda k: work[k][1]) == "fk_d_bwd1"
+    for wl in ("c4", "ml20m", "custom:25024"):
+        r, f = bench.rocprof_summary(wl)
+        assert f is not None and "k_dec1_bwd_adam_stream" in r, wl
+    assert bench.rocprof_summary("custom:777") == (None, None)
+    for probe, names in bench.ROCPROF_KERNELS.items():
+        assert isinstance(names, tuple) and names, probe
