@@ -210,6 +210,18 @@ class ShardedTrainer(Trainer):
                 eng.d_apply(self.d_grad, loss_out=self.d_losses[j])
         return self.d_losses
 
+    def g_phase(self):
+        out = super().g_phase()
+        # the one-shot transport's waits are bounded: a peer's message that never came leaves garbage behind a counter, not a hang -- the phase
+        # ends by looking at it (RCCL and the host transports raise through their own error paths)
+        waits = getattr(self.comm, "expired_waits", None)
+        if waits is not None:
+            n = waits()
+            if n > 0:
+                from ._cabi import LtgError
+                raise LtgError("one-shot exchange: %d device-side waits for a peer's message gave up during the phase; the model is not to be trusted" % n)
+        return out
+
     def _g_one(self, j, b, v, a, loss_out=None):
         """one generator update of batch b over the item shards (loss_out: Trainer.step_log's per-step row)"""
         d, eng = self.data, self.eng
