@@ -373,7 +373,8 @@ inline bool d_fast(const ltg_config* c) {
 #define LTG_D_SPLIT_SET 0xE      // l2, bwd1, bwd2 (l1: one 16 x 16 output per wave -- the split's 36 vector instructions per block buy 4 MFMAs of 32 cycles)
 #endif
 inline int d_spl(const ltg_config* c, int which) {
-    const int mode = c->d_arith & 3, set = ((c->d_arith >> 4) & 15) ? ((c->d_arith >> 4) & 15) : LTG_D_SPLIT_SET;
+    // (the four-term form is cheap enough to pay in fk_d_l1 too: D phase 45.5 against 45.9 ms, profiles/r6_ab_d_arith.txt)
+    const int mode = c->d_arith & 3, set = ((c->d_arith >> 4) & 15) ? ((c->d_arith >> 4) & 15) : (mode == LTG_DARITH_BF16X4 ? 0xF : LTG_D_SPLIT_SET);
     if (mode == LTG_DARITH_FP32 || !((set >> which) & 1)) return 0;
     return mode == LTG_DARITH_BF16X4 ? 4 : 6;
 }
