@@ -70,7 +70,11 @@ __global__ __launch_bounds__(ENC1_NT) void fk_enc1(int B, int H, int Z, const fl
         }
     };
     // the block sees logical columns [0, 32) of this tile (all "in range"; the real bounds are the functors' business)
-    ltg_rgemm<1, 2, 1, 1, 8, 5, false, false, 11>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);      // (5 blocks of 16 per slice: H <= 640)
+#ifndef LTG_ENC1_SPL
+#define LTG_ENC1_SPL 0      // (6: this product as six bf16 cross terms, ltg_rgemm.h -- measured in round 6 and NOT kept: a 1 x 2 tile per wave over eight K slices, the
+                            // split's vector instructions cost what the matrix pipe gives back: G phase 63.27 -> 63.42 ms, profiles/r6_ab_generator_split.txt)
+#endif
+    ltg_rgemm<1, 2, 1, 1, 8, 5, false, false, 11, LTG_ENC1_SPL>(B, 32, H, m0, 0, a_ld, a_xf, b_ld, LtgXfId(), epi, lds);      // (5 blocks of 16 per slice: H <= 640)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ltg_gate_wait_tail(end_wait);
 }
 

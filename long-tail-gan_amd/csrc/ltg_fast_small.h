@@ -303,8 +303,13 @@ __device__ __forceinline__ void wgrad_adam_tile(int K, int Min, int Nin, const f
     // lane instead of 56 (one 16 x 16 product over all of K per wave), so that six workgroups fit a CU and the ~1 600 tiles of an
     // Askubuntu-sized tail are resident in (almost) one round instead of two
     // (RND = the decoder's weight gradient under LTG_PREC_BF16: bf16-rounded operands on the bf16 matrix pipe, one 32-deep block per K slice)
+#ifndef LTG_TAIL_SPL
+#define LTG_TAIL_SPL 6      // the fp32 tiles' products (dW_q0 of small slabs, dW_q1, dW_p0: 2 x 2 tiles per wave, K = the batch rows) as six bf16 cross terms of
+                            // the split operands (ltg_rgemm.h; fp32-accurate): G phase 63.27 -> 62.93 ms per epoch of Askubuntu_Sample, same box
+                            // (profiles/r6_ab_generator_split.txt); 0 = v_mfma_f32_16x16x4_f32
+#endif
     if constexpr (RND) ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 1, true>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
-    else ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 2>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
+    else ltg_rgemm_v4<2, LTG_TAIL_BN / 16, 1, 1, 4, 2, false, LTG_TAIL_SPL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, prefetch, epi4, lds);
 }
 
 // The Adam updates of the generator step as jobs riding with the backward chain (train.py:164; each is independent once

@@ -421,7 +421,7 @@ __device__ __forceinline__ void ltg_rgemm(int M, int N, int K, int m0, int n0, A
 // ragged last group -- N % 4 != 0 -- is the caller's business).  pre = prefetch(m, n, in_range) is evaluated for the same
 // (m, n) BEFORE the product: the epilogue's own operands (theta / m / v of an Adam update) are requested first, so the
 // whole workgroup costs one memory round trip.
-template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, class ALD, class AXF, class BLD, class BXF, class PF, class EF>
+template <int TM, int TN, int WM, int WN, int WK, int NBLK, bool BFM = false, int SPL = 0, class ALD, class AXF, class BLD, class BXF, class PF, class EF>
 __device__ __forceinline__ void ltg_rgemm_v4(int M, int N, int K, int m0, int n0, ALD a_ld, AXF a_xf, BLD b_ld, BXF b_xf, PF prefetch, EF epi4,
                                              float* __restrict__ lds) {
     typedef LtgRg<TM, TN, WM, WN, WK> G;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void ltg_rgemm_v4(int M, int N, int K, int m0, int n0
     };
     if constexpr (BFM) ltg_rgemm_product_bf16<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, pre_mid);
     else
-    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, pre_mid);
+    ltg_rgemm_product<TM, TN, WM, WN, WK, NBLK, false, 0, SPL>(M, N, K, m0, n0, a_ld, a_xf, b_ld, b_xf, lds, pre_mid);
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
         const int id = tid + 256 * e;
