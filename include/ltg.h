@@ -574,6 +574,9 @@ int ltg_rank_finish(const ltg_batch* te, const int32_t* counts, int32_t k_ndcg, 
 /* Verification helper of the LTG_PREC_FP8 mode: out[i] = the value the fp8 GEMM operands carry for in[i]
  * (clamp to +-448, round to nearest-even OCP e4m3) -- lets a test pin its CPU model of the rounding to the hardware. */
 int ltg_fp8_roundtrip(const float* in, float* out, int32_t n, ltg_stream stream);
+/* verification helper (ABI v14): the three bf16 terms (hi, mid, lo as fp32 values) into which the d_arith = BF16X6 loaders split every fp32 operand:
+ * out[3 i + t] for in[i], n % 4 == 0.  The claim the tests pin: hi + mid + lo == in exactly, each term the round-to-nearest bf16 of its residual. */
+int ltg_debug_split(const float* in, float* out, int32_t n, ltg_stream stream);
 /* Verification helper: C[M][N] = A[M][K] . B[K][N] (row-major fp32) through the MFMA block template every GEMM-shaped
  * kernel is an instance of; mode 0 = fp32 operands, 1 = bf16, 2 = e4m3 with scale 2^4 on both operands. */
 int ltg_debug_gemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* A, const float* B, float* C, ltg_stream stream);

@@ -166,6 +166,7 @@ SYMBOLS = {
     "ltg_rank_counts": (C.c_int, [C.POINTER(ltg_config), vp, C.POINTER(ltg_batch), C.POINTER(ltg_batch), vp, vp, vp]),
     "ltg_rank_finish": (C.c_int, [C.POINTER(ltg_batch), vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
     "ltg_fp8_roundtrip": (C.c_int, [vp, vp, C.c_int32, vp]),
+    "ltg_debug_split": (C.c_int, [vp, vp, C.c_int32, vp]),
     "ltg_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
 }
 

@@ -1795,6 +1795,16 @@ int ltg_fp8_roundtrip(const float* in, float* out, int32_t n, ltg_stream stream)
     return check_launch();
 }
 
+int ltg_debug_split(const float* in, float* out, int32_t n, ltg_stream stream) {
+    clear_errors();
+    if (!in || !out || n < 0 || (n % 4) != 0) return LTG_EINVAL;
+    if (n == 0) return LTG_OK;
+    const int n4 = n / 4;
+    hipLaunchKernelGGL(k_debug_split, dim3((n4 + NT - 1) / NT < 1024 ? (n4 + NT - 1) / NT : 1024), dim3(NT), 0, (hipStream_t)stream, n4,
+                       reinterpret_cast<const ltg_f32x4*>(in), out);
+    return check_launch();
+}
+
 int ltg_debug_gemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* A, const float* B, float* C, ltg_stream stream) {
     clear_errors();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return LTG_EINVAL;

@@ -79,9 +79,15 @@ __device__ __forceinline__ LtgSplit ltg_split_bf16(ltg_f32x4 v) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const ltg_rg_f32x2 x = {v[2 * h], v[2 * h + 1]};
-        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, ltg_rg_bf16x2));
+        const ltg_rg_bf16x2 hb = __builtin_convertvector(x, ltg_rg_bf16x2);
+        const unsigned hu = __builtin_bit_cast(unsigned, hb);
+        // (Measured and not kept, round 6: the residual as v_dot2c_f32_bf16 -- x + hi.lo * -1 + hi.hi * 0, one instruction per element instead of
+        // the unpacking shift / and + half a v_pk_add_f32.  No gain -- D phase 47.97 -> 47.78, G phase 62.88 -> 63.01 ms -- and as hipcc 7.2 compiles
+        // the builtin here (the packed selector becomes an inline constant of the instruction) the terms come out WRONG: every D-step parity case
+        // and test_bf16_split_is_exact fail on that build.)
         const ltg_rg_f32x2 r1 = x - ltg_rg_f32x2{__uint_as_float(hu << 16), __uint_as_float(hu & 0xFFFF0000u)};
-        const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, ltg_rg_bf16x2));
+        const ltg_rg_bf16x2 mb = __builtin_convertvector(r1, ltg_rg_bf16x2);
+        const unsigned mu = __builtin_bit_cast(unsigned, mb);
         s.hi[h] = hu;
         s.mid[h] = mu;
         s.lo[h] = 0u;

@@ -51,6 +51,20 @@ __global__ __launch_bounds__(NT) void fkt_split_weights(int h0, int h1, int h2, 
     out[128] = ltg_ft_u32x4{s0.lo[0], s0.lo[1], s1.lo[0], s1.lo[1]};
 }
 
+// verification helper (ltg_debug_split): the three bf16 terms of every input value, as the GEMM loaders form them -- out[3 i + t] = term t of in[i] as fp32
+__global__ __launch_bounds__(NT) void k_debug_split(int n4, const ltg_f32x4* __restrict__ in, float* __restrict__ out) {
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n4; i += gridDim.x * NT) {
+        const LtgSplit s = ltg_split_bf16<6>(in[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned sh = (e & 1) ? 0u : 16u;
+            out[3 * (4 * i + e) + 0] = __uint_as_float(e & 1 ? (s.hi[e >> 1] & 0xFFFF0000u) : (s.hi[e >> 1] << sh));
+            out[3 * (4 * i + e) + 1] = __uint_as_float(e & 1 ? (s.mid[e >> 1] & 0xFFFF0000u) : (s.mid[e >> 1] << sh));
+            out[3 * (4 * i + e) + 2] = __uint_as_float(e & 1 ? (s.lo[e >> 1] & 0xFFFF0000u) : (s.lo[e >> 1] << sh));
+        }
+    }
+}
+
 // tanh: 1 - 2 / (1 + e^(2x)) through v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; saturates cleanly), the odd polynomial where that
 // form cancels (|x| < 0.04: next term 17/315 x^7 < 1e-11)
 __device__ __forceinline__ float ft_tanh(float x) {

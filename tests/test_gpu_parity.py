@@ -937,6 +937,41 @@ def test_rank_metrics_cut_at_exchange_points_equals_fused():
 # ------------------------------------------------------------------------------------------------
 # discriminator GEMM precision modes (ltg_config.d_precision; BASELINE config 5 asks for fp8 on the wide discriminator)
 # ------------------------------------------------------------------------------------------------
+def test_bf16_split_is_exact():
+    """d_arith = bf16x6 rests on ONE claim: every fp32 operand x is the exact sum of three bf16 terms, hi = bf16(x), mid = bf16(x - hi),
+    lo = bf16(x - hi - mid) (round to nearest even), so that the six cross terms leave out only 2^-26 of a product.  ltg_debug_split runs the
+    loaders' own split (csrc/ltg_rgemm.h: ltg_split_bf16) over random values of every magnitude the path meets, powers of two, values on bf16
+    rounding boundaries, zeros and signed tiny values; the oracle's bf16 rounding model gives the expected terms bit for bit."""
+    import torch
+    from ltgan import _cabi as cabi
+    from ltgan.engine import _ptr
+    lib = cabi.load()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.normal(0, 1, 400000), rng.normal(0, 1e-4, 100000), rng.normal(0, 300, 100000), rng.uniform(-1, 1, 100000) * 10.0 ** rng.integers(-20, 20, 100000),
+        2.0 ** rng.integers(-60, 60, 1000) * rng.choice([-1, 1], 1000), [0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -9, 1.0 + 2.0 ** -8 + 2.0 ** -23, 3.0 * 2.0 ** -9, 65504.0],
+        (1.0 + 2.0 ** -8 * (rng.integers(0, 256, 2000) + 0.5)) * 2.0 ** rng.integers(-10, 10, 2000),      # exactly half-way between two bf16 values
+    ]).astype(np.float32)
+    x = np.concatenate([x, np.zeros((-len(x)) % 4, np.float32)])
+    dev = "cuda:0"
+    xi = torch.from_numpy(x).to(dev)
+    out = torch.empty(3 * len(x), dtype=torch.float32, device=dev)
+    cabi.check(lib.ltg_debug_split(_ptr(xi), _ptr(out), len(x), None), "ltg_debug_split")
+    torch.cuda.synchronize()
+    t = out.cpu().numpy().reshape(-1, 3)
+    hi, mid, lo = t[:, 0], t[:, 1], t[:, 2]
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64)), "hi + mid + lo != x"
+    want_hi = O.bf16_round(x)
+    r1 = (x.astype(np.float64) - want_hi.astype(np.float64)).astype(np.float32)          # exact in fp32
+    want_mid = O.bf16_round(r1)
+    r2 = (r1.astype(np.float64) - want_mid.astype(np.float64)).astype(np.float32)
+    want_lo = O.bf16_round(r2)
+    assert np.array_equal(hi.view(np.uint32), want_hi.view(np.uint32)) and np.array_equal(mid.view(np.uint32), want_mid.view(np.uint32))
+    assert np.array_equal(lo.view(np.uint32), want_lo.view(np.uint32)) and np.array_equal(lo.astype(np.float64), r2.astype(np.float64))
+    nz = x != 0
+    assert np.all(np.abs(mid[nz]) <= 2.0 ** -8 * np.abs(x[nz])) and np.all(np.abs(lo[nz]) <= 2.0 ** -16 * np.abs(x[nz]))
+
+
 def test_fp8_rounding_model_matches_hardware():
     """the oracle's e4m3 model (oracle.fp8_e4m3_round) against the conversion the kernels use, bit for bit"""
     import torch
