@@ -478,7 +478,8 @@ def _d_step_case(nr, nf, warm, knob=0, d_arith=None, loosen=1.0):
 
 
 @pytest.mark.parametrize("d_arith,tol", [("bf16x6", 2e-6), ("bf16x4", 2e-5), ("fp32", 2e-6)])
-@pytest.mark.parametrize("hs,segs", [((100, 150, 250, 300), (1, 63, 64, 65, 700, 1311)), ((12, 20, 28, 16), (5, 130)), ((64, 96, 200, 320), (257,))])
+@pytest.mark.parametrize("hs,segs", [((100, 150, 250, 300), (1, 63, 64, 65, 700, 1311)), ((12, 20, 28, 16), (5, 130)), ((64, 96, 200, 320), (257,)),
+                                     ((8, 5, 9, 3), (70,)), ((128, 33, 17, 7), (129,))])
 def test_forward_only_tower_matches_oracle(hs, segs, d_arith, tol):
     """ltg_fake_tower_batched (discriminator.py:51-55 for many pair batches in one pass; consumed at train.py:155): y of every slot against the
     oracle's tower, segment by segment with the segment's own dropout counter -- through the ONE-kernel tower (csrc/ltg_tower.h: d_arith bf16x6 /
