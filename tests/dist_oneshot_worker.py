@@ -25,6 +25,32 @@ def main():
     idx, _ = synthetic_index(workload, users=users, seed=5)
     I = idx.n_items
     lo, hi = item_slab(I, rank, world)
+    if len(sys.argv) > 3 and sys.argv[3] == "expiry":
+        # a peer that never sends: rank 1 sits out the G phase, so every exchange of rank 0 waits its bound (LTGAN_ONESHOT_LIMIT_MS) and gives up --
+        # a counter, not a hang -- and the phase must end in an error, not in silently wrong weights
+        from ltgan._cabi import LtgError
+        eng = Engine(I, h_sizes=(16, 24, 40, 32), lr=1e-3, precision="bf16", seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi)
+        data = DeviceData(idx, 100, dev, item_lo=lo, item_hi=hi)
+        tr = ShardedTrainer(eng, data, num_sub_epochs=1, shuffle_seed=1, transport="oneshot")
+        assert tr.comm is not None and tr.comm.kind == "oneshot-ipc"
+        tr.create_phase()
+        tr.d_phase()
+        torch.cuda.synchronize()
+        dist.barrier()
+        raised = False
+        if rank == 0:
+            try:
+                tr.g_phase()
+            except LtgError as e:
+                raised = "gave up" in str(e)
+            assert raised, "the G phase of a rank whose peer never sends must raise"
+            assert tr.comm.expired_waits() > 0
+        dist.barrier()
+        tr.close()
+        if rank == 0:
+            print("ONESHOT_EXPIRY_OK world=%d" % world)
+        dist.destroy_process_group()
+        return
     runs = []
     for transport in ("oneshot", "host-ordered"):
         eng = Engine(I, h_sizes=(16, 24, 40, 32), lr=1e-3, precision="bf16", seed=77, d_seed=3, device=dev, item_lo=lo, item_hi=hi)

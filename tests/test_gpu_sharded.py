@@ -63,6 +63,17 @@ def test_one_shot_exchange_equals_the_rank_ordered_host_transport(world, workloa
     assert out.returncode == 0 and ("ONESHOT_OK world=%d" % world) in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
 
 
+def test_one_shot_exchange_gives_up_and_raises_when_a_peer_never_sends():
+    """The one-shot transport's device-side waits are bounded (ltg_oneshot.limit_ms): with a peer that sits out the G phase every exchange of the
+    other rank gives up after its bound, counts it in the stage, and the phase ends in an LtgError (ShardedTrainer.g_phase) -- a forced expiry,
+    not a hang."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", LTGAN_ONESHOT_LIMIT_MS="40")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29585", os.path.join(ROOT, "tests", "dist_oneshot_worker.py"), "c4", "200", "expiry"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "ONESHOT_EXPIRY_OK world=2" in out.stdout, out.stdout[-3000:] + out.stderr[-6000:]
+
+
 def test_direct_rccl_transport_of_the_one_call_step_at_world_size_one():
     """The transport a GPU node uses: RCCL bound directly, its entry points called by the library in-stream (tests/dist_rccl_worker.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
