@@ -75,13 +75,13 @@ def test_forward_parity(precision, tol, I, B):
     perr = np.max(np.abs(p - F["probs"]) / F["probs"])
     print("I=%d B=%d %s: max rel err probs %.2e logits %.2e" % (I, B, precision, perr, Hh.rel_err(got["logits"], F["logits"])))
     assert perr < 1e-3
-    # against the pure-fp32-operand oracle the bf16 path stays within 1e-2 on probabilities
+    # against the pure-fp32-operand oracle the bf16 path stays within 1e-2 on probabilities (element-wise)
     if precision == "bf16":
         F32 = O.vae_forward(P, X.toarray(), mask, keep, eps, 1.0, 1.0, np.float64, quant=False)
         gap = np.max(np.abs(p - F32["probs"]) / F32["probs"])
         print("I=%d B=%d bf16 operands against the PURE fp32 oracle: max rel gap probs %.2e, logits %.2e (DESIGN.md section 6 quotes these)" %
               (I, B, gap, Hh.rel_err(got["logits"], F32["logits"])))
-        assert gap < 2e-2
+        assert gap < 1e-2          # (measured 5.3e-4 .. 5.0e-3 over the eight shapes: profiles/r6_bf16_vs_pure_fp32_gap.txt; the bound was 2e-2 until round 6)
 
 
 @pytest.mark.parametrize("I,rows", [(20000, (100, 100, 50)), (1000, (100, 100, 100, 1))])
