@@ -50,6 +50,16 @@ if __name__ == "__main__":
         SEEDS, EPOCHS, out = (11, 12), 30, "ndcg_gate_long.npz"
     if len(sys.argv) > 2 and sys.argv[2] == "long_more":     # round 6: two MORE seeds of the 30-epoch gate (merged into ndcg_gate_long.npz by
         SEEDS, EPOCHS, out = (13, 14), 30, "ndcg_gate_long_more.npz"   # merge_long below): with two seeds the curve statistic sat ON its 0.004 bound
+    if len(sys.argv) > 2 and sys.argv[2] == "full_more":     # round 6: two more seeds of the 80-epoch gate as well (its Recall@50 curve statistic sat at 0.0039)
+        SEEDS, EPOCHS, out = (13, 14), 80, "ndcg_gate_full_more.npz"
+    if len(sys.argv) > 2 and sys.argv[2] == "merge_full":
+        a = np.load(os.path.join(ROOT, "tests", "golden", "ndcg_gate_full.npz"))
+        b = np.load(os.path.join(ROOT, "tests", "golden", "ndcg_gate_full_more.npz"))
+        assert int(a["epochs"]) == int(b["epochs"]) == 80 and not set(a["seeds"].tolist()) & set(b["seeds"].tolist())
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ndcg_gate_full.npz"), seeds=np.concatenate([a["seeds"], b["seeds"]]), epochs=80, S=S,
+                            hs=np.array(HS), lr=LR, batch_size=BS, curves=np.concatenate([a["curves"], b["curves"]]), d_seed_offset=1000)
+        print("merged:", np.concatenate([a["seeds"], b["seeds"]]))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "merge_long":
         a = np.load(os.path.join(ROOT, "tests", "golden", "ndcg_gate_long.npz"))
         b = np.load(os.path.join(ROOT, "tests", "golden", "ndcg_gate_long_more.npz"))
