@@ -58,7 +58,7 @@ if __name__ == "__main__":
         assert int(a["epochs"]) == int(b["epochs"]) == 80 and not set(a["seeds"].tolist()) & set(b["seeds"].tolist())
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ndcg_gate_full.npz"), seeds=np.concatenate([a["seeds"], b["seeds"]]), epochs=80, S=S,
                             hs=np.array(HS), lr=LR, batch_size=BS, curves=np.concatenate([a["curves"], b["curves"]]), d_seed_offset=1000)
-        print("merged:", np.concatenate([a["seeds"], b["seeds"]]))
+        print("merged full")
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "merge_long":
         a = np.load(os.path.join(ROOT, "tests", "golden", "ndcg_gate_long.npz"))
@@ -66,7 +66,7 @@ if __name__ == "__main__":
         assert int(a["epochs"]) == int(b["epochs"]) == 30 and not set(a["seeds"].tolist()) & set(b["seeds"].tolist())
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ndcg_gate_long.npz"), seeds=np.concatenate([a["seeds"], b["seeds"]]), epochs=30, S=S,
                             hs=np.array(HS), lr=LR, batch_size=BS, curves=np.concatenate([a["curves"], b["curves"]]), d_seed_offset=1000)
-        print("merged:", np.concatenate([a["seeds"], b["seeds"]]))
+        print("merged long")
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "full":          # config.ini's whole schedule: NUM_EPOCH = 80 global epochs (train.py:369)
         SEEDS, EPOCHS, out = (11, 12), 80, "ndcg_gate_full.npz"
