@@ -763,6 +763,9 @@ static void d_apply(const ltg_config* cfg, const ltg_disc_state* disc, const DLa
 
 // forward + backward of the pair rows in `pv` into gradient slabs; then either the Adam sweep (grad_out == NULL: the
 // whole step, train.py:300) or one summed gradient vector in grad_out (this rank's share: ltg_d_grad)
+#ifndef LTG_D_FORK_MIN_ROWS
+#define LTG_D_FORK_MIN_ROWS 1024
+#endif
 static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairView pv, DropView dA, DropView dB, DropView dC,
                        const ltg_d_opts* o, float* grad_out, float* loss_out, const Workspace& w, hipStream_t st) {
     const int n = pv.nr + pv.nf;
@@ -786,8 +789,12 @@ static int d_step_impl(const ltg_config* cfg, const ltg_disc_state* disc, PairVi
         // launch structure: the five grids returning at once take 18 us.)
         // (only with the FLAT tensor layout: the poison word reaches fk_d_adam alone -- separate tensors take k_d_adam, which has no early
         // return, so a direct C-ABI caller with that layout keeps the whole step on one stream)
+        // (Round 6: only from LTG_D_FORK_MIN_ROWS pair rows.  At the ~300 rows per step of the synthetic tables the two jobs are one or two slabs of work and
+        // the fork's two gate kernels and its poll cost more than they hide -- and not steadily: D step 32.6-38.9 us with the fork against 34.1 +- 0.1
+        // without at 20 000 items, 34.1-38.2 against 32.4 at 200 000 -- profiles/r6_ab_d_fork_small.txt.  Either way the same kernels write the same slab
+        // entries: same bits.)
         const bool fork = o->aux_stream && o->sync && !grad_out && (cfg->tuning & 64) == 0 &&      // (tuning-knob bit 6: no fork)
-                          d_adam_flat(cfg, disc, L, SP, w.slab, nullptr);
+                          n >= LTG_D_FORK_MIN_ROWS && d_adam_flat(cfg, disc, L, SP, w.slab, nullptr);
         const unsigned* poison = fork ? o->sync + 2 : nullptr;
         const int spl1 = d_spl(cfg, 2), spl2 = d_spl(cfg, 3);
         LTG_PROBED(pr, LTG_K_D_BWD1, LTG_D_SPL_LAUNCH(spl1, fk_d_bwd1, dim3(fork ? nA : nA + nB + nC), dim3(NT), 0, st, pv, h12, h3, nA, nB, ntile, L, SP, w.A1, w.A3, w.G3,
